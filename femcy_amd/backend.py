@@ -1,0 +1,341 @@
+"""ctypes binding of libfemcy_hip.so (include/femcy.h) -- the only compute backend of femcy_amd.
+
+There is deliberately no CPU fallback: if the HIP library is missing, or no MI355X is visible,
+construction of a `Context` raises `FemcyError`.  (The CPU restatement of the reference lives in
+`oracle/` and is test infrastructure only.)
+
+`import torch` happens before the library is loaded so that libfemcy_hip.so binds to the HIP
+runtime (and, for multi-GPU runs, the RCCL) that PyTorch already mapped into the process: the
+wheel bundles its own libamdhip64.so/librccl.so with the same SONAMEs as /opt/rocm's, and two
+HIP runtimes in one process do not mix.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfemcy_hip.so")
+
+# enum femcy_vec
+VEC_DOF, VEC_RHS, VEC_RESIDUAL, VEC_FORCE, VEC_DU, VEC_DOF_OLD, VEC_X, VEC_TMP0, VEC_TMP1 = range(9)
+# enum femcy_gpfield
+GP_DSDX, GP_VOL, GP_F, GP_SIGMA = range(4)
+# enum femcy_option
+OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT = range(4)
+ASM_GATHER, ASM_ATOMIC = 0, 1
+
+EXPORTS = [
+    "femcy_ctx_create", "femcy_ctx_destroy", "femcy_last_error", "femcy_version", "femcy_set_option", "femcy_sync",
+    "femcy_set_mesh", "femcy_set_element", "femcy_set_material", "femcy_build_pattern", "femcy_get_pattern_info",
+    "femcy_vec_upload", "femcy_vec_download", "femcy_vec_fill", "femcy_vec_copy", "femcy_vec_scatter",
+    "femcy_vec_sub", "femcy_vec_axpy", "femcy_vec_scale", "femcy_vec_norm", "femcy_vec_absmax",
+    "femcy_assemble_K", "femcy_internal_force", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
+    "femcy_spmv", "femcy_pcg", "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
+    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_init", "femcy_iface_sum",
+]
+
+
+class FemcyError(RuntimeError):
+    pass
+
+
+class PatternInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nnzb", C.c_int64), ("nnz", C.c_int64), ("max_row_blocks", C.c_int32),
+                ("ell_width", C.c_int32), ("stored_blocks", C.c_int64), ("nslices", C.c_int32),
+                ("max_node_elems", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("geom_ms", C.c_double), ("geom_launches", C.c_int64),
+                ("assemble_ms", C.c_double), ("assemble_launches", C.c_int64),
+                ("force_ms", C.c_double), ("force_launches", C.c_int64),
+                ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64),
+                ("pcg_ms", C.c_double), ("pcg_iters", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library(require_gpu_runtime: bool = True):
+    """dlopen libfemcy_hip.so.  Raises FemcyError when the in-tree library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FemcyError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(femcy_amd has no CPU fallback)")
+    if require_gpu_runtime:
+        import torch  # noqa: F401  (maps PyTorch's HIP runtime first; see module docstring)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    p, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    cint = C.c_int
+    sig = {
+        "femcy_ctx_create": [cint, C.POINTER(p)], "femcy_ctx_destroy": [p], "femcy_version": [],
+        "femcy_set_option": [p, cint, i64], "femcy_sync": [p],
+        "femcy_set_mesh": [p, i32, i32, p, i32, i32, p], "femcy_set_element": [p, i32, p, p, i32],
+        "femcy_set_material": [p, i32, p, p, i32], "femcy_build_pattern": [p],
+        "femcy_get_pattern_info": [p, C.POINTER(PatternInfo)],
+        "femcy_vec_upload": [p, cint, p, i64], "femcy_vec_download": [p, cint, p, i64],
+        "femcy_vec_fill": [p, cint, f64], "femcy_vec_copy": [p, cint, cint],
+        "femcy_vec_scatter": [p, cint, p, p, i32], "femcy_vec_sub": [p, cint, cint, cint],
+        "femcy_vec_axpy": [p, cint, cint, f64, cint], "femcy_vec_scale": [p, cint, f64],
+        "femcy_vec_norm": [p, cint, C.POINTER(f64)], "femcy_vec_absmax": [p, cint, C.POINTER(f64)],
+        "femcy_assemble_K": [p, cint], "femcy_internal_force": [p, cint, cint],
+        "femcy_apply_dirichlet_linear": [p, p, p, i32, cint], "femcy_apply_dirichlet_newton": [p, p, i32, cint],
+        "femcy_spmv": [p, cint, cint],
+        "femcy_pcg": [p, cint, cint, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)],
+        "femcy_get_K_ell": [p, p, p], "femcy_get_K_bsr": [p, p, p, p], "femcy_get_gp_field": [p, cint, p],
+        "femcy_timing": [p, C.POINTER(Timing)], "femcy_timing_reset": [p],
+        "femcy_comm_unique_id": [p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
+        "femcy_iface_sum": [p, cint],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = cint
+    lib.femcy_last_error.argtypes = []
+    lib.femcy_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class DeviceVector:
+    """handle to one of the context's HBM-resident solver vectors; quacks like the ti.field the
+    reference exposes (`to_numpy`, `from_numpy`, `fill`, `copy_from`, `shape`)."""
+
+    def __init__(self, ctx: "Context", vec_id: int):
+        self.ctx, self.id = ctx, vec_id
+
+    @property
+    def shape(self):
+        return (self.ctx.n,)
+
+    def to_numpy(self) -> np.ndarray:
+        return self.ctx.download(self.id)
+
+    def from_numpy(self, arr):
+        self.ctx.upload(self.id, arr)
+
+    def fill(self, value: float):
+        self.ctx._call("femcy_vec_fill", self.id, float(value))
+
+    def copy_from(self, other: "DeviceVector"):
+        self.ctx._call("femcy_vec_copy", self.id, other.id)
+
+    def __len__(self):
+        return self.ctx.n
+
+
+class GaussField:
+    """handle to a device Gauss-point field (dsdx, vol, F, cauchy stress)."""
+
+    def __init__(self, ctx: "Context", which: int, tail_shape):
+        self.ctx, self.which, self._tail = ctx, which, tuple(tail_shape)
+
+    @property
+    def shape(self):
+        return (self.ctx.ne, self.ctx.nGP)
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty((self.ctx.ne, self.ctx.nGP) + self._tail, dtype=np.float64)
+        self.ctx._call("femcy_get_gp_field", self.which, _ptr(out))
+        return out
+
+
+class Context:
+    """one HIP device + stream + all device state of one System_of_equations."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.femcy_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise FemcyError(f"femcy_ctx_create({device}) -> {rc}: {self.lib.femcy_last_error().decode()}")
+        self._h = h
+        self.device = device
+        self.n = self.nn = self.dm = self.ne = self.npe = self.nGP = 0
+
+    # ------------------------------------------------------------------------------- plumbing
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self._h, *args)
+        if rc != 0:
+            raise FemcyError(f"{name} -> {rc}: {self.lib.femcy_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.femcy_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt: int, value: int):
+        self._call("femcy_set_option", int(opt), int(value))
+
+    def sync(self):
+        self._call("femcy_sync")
+
+    # --------------------------------------------------------------------- problem definition
+    def set_mesh(self, nodes: np.ndarray, elements: np.ndarray):
+        nodes, elements = _f64(nodes), _i32(elements)
+        self.nn, self.dm = nodes.shape
+        self.ne, self.npe = elements.shape
+        self.n = self.nn * self.dm
+        self._call("femcy_set_mesh", self.nn, self.dm, _ptr(nodes), self.ne, self.npe, _ptr(elements))
+
+    def set_element(self, ELE):
+        """ELE: an element_zoo plugin (anything with .tables())."""
+        t = ELE.tables()
+        if t["npe"] != self.npe or t["dm"] != self.dm:
+            raise FemcyError(f"element plugin (npe={t['npe']}, dm={t['dm']}) does not match mesh "
+                             f"(npe={self.npe}, dm={self.dm})")
+        self.nGP = int(t["nGP"])
+        self._call("femcy_set_element", self.nGP, _ptr(_f64(t["dN"])), _ptr(_f64(t["w"])), int(t["voigt_kind"]))
+
+    def set_material(self, material):
+        params = _f64(material.params)
+        self._call("femcy_set_material", int(material.kind), _ptr(_f64(material.C)), _ptr(params), int(params.size))
+
+    def build_pattern(self) -> PatternInfo:
+        self._call("femcy_build_pattern")
+        return self.pattern_info()
+
+    def pattern_info(self) -> PatternInfo:
+        info = PatternInfo()
+        self._call("femcy_get_pattern_info", C.byref(info))
+        return info
+
+    # --------------------------------------------------------------------------------- vectors
+    def vector(self, vec_id: int) -> DeviceVector:
+        return DeviceVector(self, vec_id)
+
+    def upload(self, vec_id: int, arr):
+        a = _f64(arr).ravel()
+        self._call("femcy_vec_upload", int(vec_id), _ptr(a), a.size)
+
+    def download(self, vec_id: int) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        self._call("femcy_vec_download", int(vec_id), _ptr(out), out.size)
+        return out
+
+    def scatter(self, vec_id: int, idx, vals):
+        idx, vals = _i32(idx).ravel(), _f64(vals).ravel()
+        self._call("femcy_vec_scatter", int(vec_id), _ptr(idx), _ptr(vals), idx.size)
+
+    def vec_sub(self, c: int, a: int, b: int):
+        self._call("femcy_vec_sub", c, a, b)
+
+    def vec_axpy(self, a: int, b: int, c: float, d: int):
+        self._call("femcy_vec_axpy", a, b, float(c), d)
+
+    def vec_scale(self, v: int, s: float):
+        self._call("femcy_vec_scale", v, float(s))
+
+    def vec_norm(self, v: int) -> float:
+        out = C.c_double()
+        self._call("femcy_vec_norm", v, C.byref(out))
+        return out.value
+
+    def vec_absmax(self, v: int) -> float:
+        out = C.c_double()
+        self._call("femcy_vec_absmax", v, C.byref(out))
+        return out.value
+
+    # -------------------------------------------------------------------------------- hot path
+    def assemble_K(self, u_vec: int = VEC_DOF):
+        self._call("femcy_assemble_K", int(u_vec))
+
+    def internal_force(self, u_vec: int = VEC_DOF, f_vec: int = VEC_FORCE):
+        self._call("femcy_internal_force", int(u_vec), int(f_vec))
+
+    def dirichlet_linear(self, dofs, vals, rhs_vec: int = VEC_RHS):
+        dofs, vals = _i32(dofs).ravel(), _f64(vals).ravel()
+        self._call("femcy_apply_dirichlet_linear", _ptr(dofs), _ptr(vals), dofs.size, int(rhs_vec))
+
+    def dirichlet_newton(self, dofs, residual_vec: int = VEC_RESIDUAL):
+        dofs = _i32(dofs).ravel()
+        self._call("femcy_apply_dirichlet_newton", _ptr(dofs), dofs.size, int(residual_vec))
+
+    def spmv(self, x_vec: int, y_vec: int):
+        self._call("femcy_spmv", int(x_vec), int(y_vec))
+
+    def pcg(self, b_vec: int, x_vec: int = VEC_X, eps: float = 1.0e-3, maxit: int = 0):
+        it, r0, rm = C.c_int32(), C.c_double(), C.c_double()
+        self._call("femcy_pcg", int(b_vec), int(x_vec), float(eps), int(maxit), C.byref(it), C.byref(r0), C.byref(rm))
+        return it.value, r0.value, rm.value
+
+    # ------------------------------------------------------------------------------ inspection
+    def get_K_ell(self):
+        info = self.pattern_info()
+        W = info.ell_width
+        ij = np.empty((self.n, W + 1), dtype=np.int32)
+        A = np.empty((self.n, W), dtype=np.float64)
+        self._call("femcy_get_K_ell", _ptr(ij), _ptr(A))
+        return ij, A
+
+    def get_K_bsr(self):
+        """scipy.sparse.bsr_matrix of the device matrix (ascending block columns)."""
+        import scipy.sparse as sp
+        info = self.pattern_info()
+        rowptr = np.empty(self.nn + 1, dtype=np.int32)
+        col = np.empty(info.nnzb, dtype=np.int32)
+        vals = np.empty((info.nnzb, self.dm, self.dm), dtype=np.float64)
+        self._call("femcy_get_K_bsr", _ptr(rowptr), _ptr(col), _ptr(vals))
+        return sp.bsr_matrix((vals, col, rowptr), shape=(self.n, self.n))
+
+    def gauss_field(self, which: int) -> GaussField:
+        tail = {GP_DSDX: (self.npe, self.dm), GP_VOL: (), GP_F: (self.dm, self.dm), GP_SIGMA: (self.dm, self.dm)}[which]
+        return GaussField(self, which, tail)
+
+    def timing(self) -> dict:
+        t = Timing()
+        self._call("femcy_timing", C.byref(t))
+        return t.as_dict()
+
+    def timing_reset(self):
+        self._call("femcy_timing_reset")
+
+    # ------------------------------------------------------------------------------- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.femcy_comm_unique_id(buf)
+        if rc != 0:
+            raise FemcyError(f"femcy_comm_unique_id -> {rc}: {lib.femcy_last_error().decode()}")
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, uid: bytes, iface_local_dofs, iface_global_slot, niface_global: int,
+                  owner):
+        d, s = _i32(iface_local_dofs).ravel(), _i32(iface_global_slot).ravel()
+        ow = np.ascontiguousarray(owner, dtype=np.uint8).ravel()
+        if ow.size != self.n:
+            raise FemcyError("owner mask must have one entry per local DOF")
+        idbuf = C.create_string_buffer(uid, 128)
+        self._call("femcy_comm_init", int(rank), int(nranks), idbuf, d.size, _ptr(d), _ptr(s), int(niface_global),
+                   _ptr(ow))
+
+    def iface_sum(self, vec_id: int):
+        self._call("femcy_iface_sum", int(vec_id))

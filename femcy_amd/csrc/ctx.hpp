@@ -1,0 +1,158 @@
+// Internal state of one femcy context (one HIP device + one stream).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/femcy.h"
+
+namespace femcy {
+
+void set_error(const char* fmt, ...);
+
+#define FEMCY_HIP(call)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            femcy::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return FEMCY_EHIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+#define FEMCY_REQUIRE(cond, ...)                    \
+    do {                                            \
+        if (!(cond)) {                              \
+            femcy::set_error(__VA_ARGS__);          \
+            return FEMCY_EINVAL;                    \
+        }                                           \
+    } while (0)
+
+constexpr int SLICE = 64;           // nodes per SELL slice = one wavefront
+constexpr int MAX_PARTIALS = 4096;  // upper bound on per-launch reduction partials
+
+// device-side scalar state of a PCG solve (conjugateGradientSolver.py:103-127)
+struct PcgState {
+    double rMr[2];   // r.M.r, double-buffered by iteration parity
+    double r0;       // max|r0|
+    double rmax;     // max|r| after the last completed iteration
+    double dAd;      // multi-rank: reduced d.Ad
+    int32_t iters;   // completed iterations
+    int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // ---- mesh / element / material
+    int32_t nn = 0, dm = 0, ne = 0, npe = 0, nGP = 0, voigt = 0, s = 0;
+    int64_t n = 0;
+    std::vector<int32_t> h_elems;
+    double* d_nodes = nullptr;
+    int32_t* d_elems = nullptr;
+    double* d_dN = nullptr;
+    double* d_w = nullptr;
+    double* d_C = nullptr;
+    int32_t mat_kind = -1;
+    double mat_params[4] = {0, 0, 0, 0};
+    bool have_mesh = false, have_element = false, have_material = false, have_pattern = false;
+
+    // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
+    int32_t nslices = 0;
+    int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
+    int64_t nnzb = 0;
+    int32_t max_row_blocks = 0, max_node_elems = 0;
+    std::vector<int32_t> h_slice_len, h_rowlen, h_bcol;
+    std::vector<int64_t> h_slice_off;
+    int32_t* d_slice_len = nullptr;
+    int64_t* d_slice_off = nullptr;
+    int32_t* d_rowlen = nullptr;      // [nslices*64]
+    int32_t* d_bcol = nullptr;        // [stored_rows*64]
+    double* d_Kvals = nullptr;        // [stored_rows*dm*dm*64]
+    uint16_t* d_slotj = nullptr;      // [ne*npe*npe] element-local (a,b) -> slot j in row of node a
+    int32_t* d_ctr_ptr = nullptr;     // [stored_rows*64+1] contributions per stored block
+    int32_t* d_ctr = nullptr;         // [ne*npe*npe] packed (e*npe+la)*npe+lb
+    int32_t* d_ne_ptr = nullptr;      // [nn+1] node -> incident elements
+    int32_t* d_ne_idx = nullptr;      // [ne*npe] packed e*npe+la
+
+    // ---- Gauss-point fields
+    double* d_dsdx = nullptr;
+    double* d_vol = nullptr;
+    double* d_F = nullptr;
+    double* d_sigma = nullptr;
+
+    // ---- vectors
+    double* d_vec[FEMCY_VEC_COUNT] = {nullptr};
+    double *d_r = nullptr, *d_d = nullptr, *d_M = nullptr, *d_Ad = nullptr;
+    double* d_part1 = nullptr;        // [MAX_PARTIALS] d.Ad partials (SpMV launch)
+    double* d_part2 = nullptr;        // [2*MAX_PARTIALS] (r.M.r, max|r|) partials
+    PcgState* d_state = nullptr;
+    PcgState* h_state = nullptr;      // pinned
+    double* h_scalar = nullptr;       // pinned scratch for reductions
+    int32_t* d_idx_scratch = nullptr;
+    double* d_val_scratch = nullptr;
+    int64_t scratch_cap = 0;
+
+    // ---- options / timing
+    int opt_assembly = FEMCY_ASM_GATHER;
+    int opt_poll = 32;
+    int opt_timing = 0;
+    int opt_spmv_variant = 0;
+    femcy_timing_t timing{};
+    std::vector<EventPair> ev_pool;
+    struct Pending { int cls; size_t ev; };
+    std::vector<Pending> ev_pending;
+    size_t ev_next = 0;
+
+    // ---- multi-rank
+    int32_t rank = 0, nranks = 1;
+    void* comm = nullptr;             // ncclComm_t
+    int32_t niface_local = 0, niface_global = 0;
+    int32_t* d_iface_dof = nullptr;
+    int32_t* d_iface_slot = nullptr;
+    uint8_t* d_owner = nullptr;
+    double* d_commbuf = nullptr;      // [niface_global + 8]
+    double* d_gather = nullptr;       // [nranks*2]
+};
+
+// timing classes
+enum { T_GEOM = 0, T_ASM = 1, T_FORCE = 2, T_SPMV = 3, T_PCG = 4 };
+size_t timing_begin(Ctx* c, int cls);
+void timing_end(Ctx* c, size_t h);
+void timing_collect(Ctx* c);
+
+// pattern.cpp
+int build_pattern(Ctx* c);
+// kernels_*.hip (host launchers)
+int launch_geom(Ctx* c, const double* d_u, bool with_stress);
+int launch_assemble(Ctx* c);
+int launch_nodal_force(Ctx* c, double* d_f);
+int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out);
+int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
+int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
+              double* rmax);
+int vec_fill(Ctx* c, double* d, double v, int64_t n);
+int vec_sub(Ctx* c, double* dc, const double* da, const double* db);
+int vec_axpy(Ctx* c, double* da, const double* db, double cc, const double* dd);
+int vec_scale(Ctx* c, double* d, double s);
+int vec_sumsq(Ctx* c, const double* d, double* out);
+int vec_absmax(Ctx* c, const double* d, double* out);
+int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k);
+int ensure_scratch(Ctx* c, int64_t k);
+// comm.cpp
+int comm_unique_id(void* id128);
+int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
+int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
+int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
+int comm_destroy(Ctx* c);
+int iface_sum(Ctx* c, double* d_v);
+
+}  // namespace femcy
+
+struct femcy_ctx {
+    femcy::Ctx c;
+};

@@ -1,0 +1,649 @@
+// C ABI entry points of libfemcy_hip.so (declared in include/femcy.h).  Thin argument checking and
+// resource management around the launchers in kernels_*.hip / pattern.cpp / comm.cpp.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "ctx.hpp"
+
+namespace femcy {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t count, bool zero = true) {
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return FEMCY_ENOMEM;
+    }
+    if (zero) FEMCY_HIP(hipMemset(*p, 0, bytes));
+    return FEMCY_OK;
+}
+
+template <class T>
+static void dev_free(T** p) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+}
+
+int ensure_scratch(Ctx* c, int64_t k) {
+    if (k <= c->scratch_cap) return FEMCY_OK;
+    int64_t cap = std::max<int64_t>(k, 1024);
+    int rc;
+    if ((rc = dev_alloc(&c->d_idx_scratch, (size_t)cap, false))) return rc;
+    if ((rc = dev_alloc(&c->d_val_scratch, (size_t)cap, false))) return rc;
+    c->scratch_cap = cap;
+    return FEMCY_OK;
+}
+
+// ------------------------------------------------------------------------------------- timing
+size_t timing_begin(Ctx* c, int cls) {
+    if (!c->opt_timing) return (size_t)-1;
+    if (c->ev_next >= c->ev_pool.size()) {
+        EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return (size_t)-1;
+        c->ev_pool.push_back(p);
+    }
+    size_t h = c->ev_next++;
+    (void)hipEventRecord(c->ev_pool[h].a, c->stream);
+    c->ev_pending.push_back({cls, h});
+    return h;
+}
+void timing_end(Ctx* c, size_t h) {
+    if (h == (size_t)-1) return;
+    (void)hipEventRecord(c->ev_pool[h].b, c->stream);
+}
+void timing_collect(Ctx* c) {
+    if (c->ev_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[p.ev].a, c->ev_pool[p.ev].b) != hipSuccess) continue;
+        switch (p.cls) {
+            case T_GEOM: c->timing.geom_ms += ms; c->timing.geom_launches++; break;
+            case T_ASM: c->timing.assemble_ms += ms; c->timing.assemble_launches++; break;
+            case T_FORCE: c->timing.force_ms += ms; c->timing.force_launches++; break;
+            case T_SPMV: c->timing.spmv_ms += ms; c->timing.spmv_launches++; break;
+            case T_PCG: c->timing.pcg_ms += ms; break;
+        }
+    }
+    c->ev_pending.clear();
+    c->ev_next = 0;
+}
+
+static int check_vec(Ctx* c, int v) {
+    if (v < 0 || v >= FEMCY_VEC_COUNT) {
+        set_error("vector id %d out of range", v);
+        return FEMCY_EINVAL;
+    }
+    if (!c->d_vec[v]) {
+        set_error("vectors are allocated by femcy_set_mesh; call it first");
+        return FEMCY_EINVAL;
+    }
+    return FEMCY_OK;
+}
+
+}  // namespace femcy
+
+using namespace femcy;
+
+#define CTX_OR_FAIL(ctx)                            \
+    if (!(ctx)) {                                   \
+        femcy::set_error("null context");           \
+        return FEMCY_EINVAL;                        \
+    }                                               \
+    Ctx* c = &(ctx)->c;                             \
+    if (hipSetDevice(c->device) != hipSuccess) {    \
+        femcy::set_error("hipSetDevice(%d) failed", c->device); \
+        return FEMCY_EHIP;                          \
+    }
+
+#define VEC_OR_FAIL(v)                      \
+    {                                       \
+        int _rc = check_vec(c, (v));        \
+        if (_rc) return _rc;                \
+    }
+
+extern "C" {
+
+const char* femcy_last_error(void) { return g_err; }
+int femcy_version(void) { return 100; }
+
+int femcy_ctx_create(int device, femcy_ctx** out) {
+    if (!out) {
+        set_error("out is null");
+        return FEMCY_EINVAL;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libfemcy_hip has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return FEMCY_EHIP;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (have %d)", device, count);
+        return FEMCY_EINVAL;
+    }
+    FEMCY_HIP(hipSetDevice(device));
+    femcy_ctx* ctx = new (std::nothrow) femcy_ctx();
+    if (!ctx) return FEMCY_ENOMEM;
+    Ctx* c = &ctx->c;
+    c->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+        delete ctx;
+        return FEMCY_EHIP;
+    }
+    int rc = FEMCY_OK;
+    if ((rc = dev_alloc(&c->d_part1, (size_t)MAX_PARTIALS)) || (rc = dev_alloc(&c->d_part2, (size_t)2 * MAX_PARTIALS)) ||
+        (rc = dev_alloc(&c->d_state, 1))) {
+        delete ctx;
+        return rc;
+    }
+    if (hipHostMalloc((void**)&c->h_state, sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        delete ctx;
+        return FEMCY_ENOMEM;
+    }
+    *out = ctx;
+    return FEMCY_OK;
+}
+
+int femcy_ctx_destroy(femcy_ctx* ctx) {
+    if (!ctx) return FEMCY_OK;
+    Ctx* c = &ctx->c;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
+    dev_free(&c->d_nodes); dev_free(&c->d_elems); dev_free(&c->d_dN); dev_free(&c->d_w); dev_free(&c->d_C);
+    dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
+    dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr);
+    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx);
+    dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
+    for (auto& v : c->d_vec) dev_free(&v);
+    dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad);
+    dev_free(&c->d_part1); dev_free(&c->d_part2); dev_free(&c->d_state);
+    dev_free(&c->d_idx_scratch); dev_free(&c->d_val_scratch);
+    dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
+    dev_free(&c->d_gather);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    for (auto& p : c->ev_pool) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete ctx;
+    return FEMCY_OK;
+}
+
+int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
+    CTX_OR_FAIL(ctx);
+    switch (option) {
+        case FEMCY_OPT_ASSEMBLY:
+            FEMCY_REQUIRE(value == FEMCY_ASM_GATHER || value == FEMCY_ASM_ATOMIC, "bad assembly mode %lld", (long long)value);
+            c->opt_assembly = (int)value;
+            break;
+        case FEMCY_OPT_PCG_POLL:
+            FEMCY_REQUIRE(value >= 1, "poll interval must be >= 1");
+            c->opt_poll = (int)value;
+            break;
+        case FEMCY_OPT_TIMING:
+            if (!value) timing_collect(c);
+            c->opt_timing = value ? 1 : 0;
+            break;
+        case FEMCY_OPT_SPMV_VARIANT:
+            c->opt_spmv_variant = (int)value;
+            break;
+        default:
+            set_error("unknown option %d", option);
+            return FEMCY_EINVAL;
+    }
+    return FEMCY_OK;
+}
+
+int femcy_sync(femcy_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+
+// ------------------------------------------------------------------------- problem definition
+int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, int32_t ne, int32_t npe,
+                   const int32_t* elems) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(nodes && elems, "null mesh arrays");
+    FEMCY_REQUIRE(nn > 0 && ne > 0, "empty mesh (nn=%d, ne=%d)", nn, ne);
+    FEMCY_REQUIRE(dm == 2 || dm == 3, "dm must be 2 or 3, got %d", dm);
+    FEMCY_REQUIRE(npe >= 2 && npe <= 27, "npe out of range: %d", npe);
+    for (int64_t k = 0; k < (int64_t)ne * npe; ++k)
+        FEMCY_REQUIRE(elems[k] >= 0 && elems[k] < nn, "element %lld references node %d outside [0,%d)",
+                      (long long)(k / npe), elems[k], nn);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    c->nn = nn; c->dm = dm; c->ne = ne; c->npe = npe;
+    c->n = (int64_t)nn * dm;
+    c->h_elems.assign(elems, elems + (int64_t)ne * npe);
+    int rc;
+    if ((rc = dev_alloc(&c->d_nodes, (size_t)nn * dm, false))) return rc;
+    if ((rc = dev_alloc(&c->d_elems, (size_t)ne * npe, false))) return rc;
+    FEMCY_HIP(hipMemcpy(c->d_nodes, nodes, sizeof(double) * nn * dm, hipMemcpyHostToDevice));
+    FEMCY_HIP(hipMemcpy(c->d_elems, elems, sizeof(int32_t) * (size_t)ne * npe, hipMemcpyHostToDevice));
+    // vectors are padded (zero) so that double2 kernels may touch one element past n
+    const size_t nalloc = (size_t)((c->n + 63) / 64 * 64 + 64);
+    for (auto& v : c->d_vec)
+        if ((rc = dev_alloc(&v, nalloc))) return rc;
+    if ((rc = dev_alloc(&c->d_r, nalloc)) || (rc = dev_alloc(&c->d_d, nalloc)) || (rc = dev_alloc(&c->d_M, nalloc)) ||
+        (rc = dev_alloc(&c->d_Ad, nalloc)))
+        return rc;
+    c->have_mesh = true;
+    c->have_element = c->have_pattern = false;
+    return FEMCY_OK;
+}
+
+int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN, const double* w, int32_t voigt_kind) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
+    FEMCY_REQUIRE(dN && w && nGP >= 1 && nGP <= 64, "bad element tables (nGP=%d)", nGP);
+    FEMCY_REQUIRE((voigt_kind == FEMCY_VOIGT_2D && c->dm == 2) || (voigt_kind == FEMCY_VOIGT_3D && c->dm == 3),
+                  "voigt kind %d does not match dm=%d", voigt_kind, c->dm);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    c->nGP = nGP;
+    c->voigt = voigt_kind;
+    c->s = (c->dm == 2) ? 3 : 6;
+    int rc;
+    if ((rc = dev_alloc(&c->d_dN, (size_t)nGP * c->npe * c->dm, false))) return rc;
+    if ((rc = dev_alloc(&c->d_w, (size_t)nGP, false))) return rc;
+    FEMCY_HIP(hipMemcpy(c->d_dN, dN, sizeof(double) * nGP * c->npe * c->dm, hipMemcpyHostToDevice));
+    FEMCY_HIP(hipMemcpy(c->d_w, w, sizeof(double) * nGP, hipMemcpyHostToDevice));
+    const size_t ngp = (size_t)c->ne * nGP;
+    if ((rc = dev_alloc(&c->d_dsdx, ngp * c->npe * c->dm)) || (rc = dev_alloc(&c->d_vol, ngp)) ||
+        (rc = dev_alloc(&c->d_F, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_sigma, ngp * c->dm * c->dm)))
+        return rc;
+    c->have_element = true;
+    return FEMCY_OK;
+}
+
+int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C, const double* params, int32_t nparams) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
+    FEMCY_REQUIRE(C, "null C");
+    FEMCY_REQUIRE(kind >= FEMCY_MAT_LIN3D && kind <= FEMCY_MAT_NEOHOOKE, "unknown material kind %d", kind);
+    const bool is3d = (kind == FEMCY_MAT_LIN3D || kind == FEMCY_MAT_NEOHOOKE);
+    FEMCY_REQUIRE(is3d == (c->dm == 3), "material kind %d does not match dm=%d", kind, c->dm);
+    FEMCY_REQUIRE(nparams >= 2 && params, "material needs 2 parameters");
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    const int s = (c->dm == 2) ? 3 : 6;
+    int rc;
+    if ((rc = dev_alloc(&c->d_C, (size_t)s * s, false))) return rc;
+    FEMCY_HIP(hipMemcpy(c->d_C, C, sizeof(double) * s * s, hipMemcpyHostToDevice));
+    c->mat_kind = kind;
+    for (int i = 0; i < 4; ++i) c->mat_params[i] = (i < nparams) ? params[i] : 0.0;
+    c->have_material = true;
+    return FEMCY_OK;
+}
+
+int femcy_build_pattern(femcy_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    int rc = build_pattern(c);
+    if (rc) return rc;
+    c->have_pattern = true;
+    return FEMCY_OK;
+}
+
+int femcy_get_pattern_info(femcy_ctx* ctx, femcy_pattern_info* out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern && out, "pattern not built");
+    out->n = c->n;
+    out->nnzb = c->nnzb;
+    out->nnz = c->nnzb * c->dm * c->dm;
+    out->max_row_blocks = c->max_row_blocks;
+    out->ell_width = c->max_row_blocks * c->dm;
+    out->stored_blocks = c->stored_rows * SLICE;
+    out->nslices = c->nslices;
+    out->max_node_elems = c->max_node_elems;
+    return FEMCY_OK;
+}
+
+// ---------------------------------------------------------------------------- vector plumbing
+int femcy_vec_upload(femcy_ctx* ctx, int vec, const double* src, int64_t n) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    FEMCY_REQUIRE(src && n == c->n, "upload length %lld != n = %lld", (long long)n, (long long)c->n);
+    FEMCY_HIP(hipMemcpyAsync(c->d_vec[vec], src, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+int femcy_vec_download(femcy_ctx* ctx, int vec, double* dst, int64_t n) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    FEMCY_REQUIRE(dst && n == c->n, "download length %lld != n = %lld", (long long)n, (long long)c->n);
+    FEMCY_HIP(hipMemcpyAsync(dst, c->d_vec[vec], sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+int femcy_vec_fill(femcy_ctx* ctx, int vec, double value) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    return vec_fill(c, c->d_vec[vec], value, c->n);
+}
+int femcy_vec_copy(femcy_ctx* ctx, int dst, int src) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(dst);
+    VEC_OR_FAIL(src);
+    if (dst == src) return FEMCY_OK;
+    FEMCY_HIP(hipMemcpyAsync(c->d_vec[dst], c->d_vec[src], sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+    return FEMCY_OK;
+}
+int femcy_vec_scatter(femcy_ctx* ctx, int vec, const int32_t* idx, const double* vals, int32_t k) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    if (k == 0) return FEMCY_OK;
+    FEMCY_REQUIRE(idx && vals && k > 0, "bad scatter arguments");
+    for (int32_t i = 0; i < k; ++i) FEMCY_REQUIRE(idx[i] >= 0 && idx[i] < c->n, "scatter index %d out of range", idx[i]);
+    int rc = ensure_scratch(c, k);
+    if (rc) return rc;
+    FEMCY_HIP(hipMemcpyAsync(c->d_idx_scratch, idx, sizeof(int32_t) * k, hipMemcpyHostToDevice, c->stream));
+    FEMCY_HIP(hipMemcpyAsync(c->d_val_scratch, vals, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+    rc = vec_scatter(c, c->d_vec[vec], c->d_idx_scratch, c->d_val_scratch, k);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));   // host buffers are only borrowed for the call
+    return rc;
+}
+int femcy_vec_sub(femcy_ctx* ctx, int cv, int a, int b) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(cv); VEC_OR_FAIL(a); VEC_OR_FAIL(b);
+    return vec_sub(c, c->d_vec[cv], c->d_vec[a], c->d_vec[b]);
+}
+int femcy_vec_axpy(femcy_ctx* ctx, int a, int b, double cc, int d) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(a); VEC_OR_FAIL(b); VEC_OR_FAIL(d);
+    return vec_axpy(c, c->d_vec[a], c->d_vec[b], cc, c->d_vec[d]);
+}
+int femcy_vec_scale(femcy_ctx* ctx, int vec, double s) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    return vec_scale(c, c->d_vec[vec], s);
+}
+int femcy_vec_norm(femcy_ctx* ctx, int vec, double* rms) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    FEMCY_REQUIRE(rms, "null output");
+    double ss = 0.0;
+    int rc = vec_sumsq(c, c->d_vec[vec], &ss);
+    if (rc) return rc;
+    *rms = std::sqrt(ss / (double)c->n);
+    return FEMCY_OK;
+}
+int femcy_vec_absmax(femcy_ctx* ctx, int vec, double* out) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    FEMCY_REQUIRE(out, "null output");
+    return vec_absmax(c, c->d_vec[vec], out);
+}
+
+// -------------------------------------------------------------------------------- the hot path
+#define READY_OR_FAIL()                                                                                       \
+    FEMCY_REQUIRE(c->have_mesh&& c->have_element&& c->have_material&& c->have_pattern,                        \
+                  "context not fully defined (mesh=%d element=%d material=%d pattern=%d)", (int)c->have_mesh, \
+                  (int)c->have_element, (int)c->have_material, (int)c->have_pattern)
+
+int femcy_assemble_K(femcy_ctx* ctx, int u_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    const double* du = nullptr;
+    if (u_vec >= 0) {
+        VEC_OR_FAIL(u_vec);
+        du = c->d_vec[u_vec];
+    }
+    int rc = launch_geom(c, du, false);
+    if (rc) return rc;
+    return launch_assemble(c);
+}
+
+int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(u_vec);
+    VEC_OR_FAIL(f_vec);
+    int rc = launch_geom(c, c->d_vec[u_vec], true);
+    if (rc) return rc;
+    return launch_nodal_force(c, c->d_vec[f_vec]);
+}
+
+static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k, std::vector<int32_t>& uniq) {
+    uniq.assign(dofs, dofs + k);
+    for (int32_t d : uniq)
+        if (d < 0 || d >= c->n) {
+            set_error("constrained DOF %d out of range", d);
+            return FEMCY_EINVAL;
+        }
+    int rc = ensure_scratch(c, k);
+    if (rc) return rc;
+    FEMCY_HIP(hipMemcpyAsync(c->d_idx_scratch, dofs, sizeof(int32_t) * k, hipMemcpyHostToDevice, c->stream));
+    if (vals) FEMCY_HIP(hipMemcpyAsync(c->d_val_scratch, vals, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+    return FEMCY_OK;
+}
+
+int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const double* vals, int32_t k, int rhs_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(rhs_vec);
+    if (k == 0) return FEMCY_OK;
+    FEMCY_REQUIRE(dofs && vals && k > 0, "bad Dirichlet arguments");
+    FEMCY_REQUIRE(rhs_vec != FEMCY_VEC_TMP0 && rhs_vec != FEMCY_VEC_TMP1, "rhs may not alias the scratch vectors");
+    std::vector<int32_t> uniq;
+    int rc = stage_dofs(c, dofs, vals, k, uniq);
+    if (rc) return rc;
+    bool any = false;
+    for (int32_t i = 0; i < k; ++i) any = any || (vals[i] != 0.0);
+    if (any) {
+        // rhs -= K s  (s = prescribed values, 0 elsewhere): column-wise elimination through one SpMV with
+        // the not-yet-modified matrix, equal to the reference's per-entry rhs[j] -= s*K[j][i] by symmetry
+        double* s = c->d_vec[FEMCY_VEC_TMP0];
+        double* Ks = c->d_vec[FEMCY_VEC_TMP1];
+        if ((rc = vec_fill(c, s, 0.0, c->n))) return rc;
+        if ((rc = vec_scatter(c, s, c->d_idx_scratch, c->d_val_scratch, k))) return rc;
+        if ((rc = launch_spmv(c, s, Ks, nullptr, nullptr))) return rc;
+        if ((rc = vec_sub(c, c->d_vec[rhs_vec], c->d_vec[rhs_vec], Ks))) return rc;
+    }
+    if ((rc = vec_scatter(c, c->d_vec[rhs_vec], c->d_idx_scratch, c->d_val_scratch, k))) return rc;
+    if ((rc = launch_dirichlet_zero(c, c->d_idx_scratch, k, nullptr))) return rc;
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+
+int femcy_apply_dirichlet_newton(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int residual_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(residual_vec);
+    if (k == 0) return FEMCY_OK;
+    FEMCY_REQUIRE(dofs && k > 0, "bad Dirichlet arguments");
+    std::vector<int32_t> uniq;
+    int rc = stage_dofs(c, dofs, nullptr, k, uniq);
+    if (rc) return rc;
+    if ((rc = launch_dirichlet_zero(c, c->d_idx_scratch, k, c->d_vec[residual_vec]))) return rc;
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+
+int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "pattern not built");
+    VEC_OR_FAIL(x_vec);
+    VEC_OR_FAIL(y_vec);
+    FEMCY_REQUIRE(x_vec != y_vec, "spmv cannot run in place");
+    int rc = launch_spmv(c, c->d_vec[x_vec], c->d_vec[y_vec], nullptr, nullptr);
+    if (rc) return rc;
+    if (c->comm) return iface_sum(c, c->d_vec[y_vec]);
+    return FEMCY_OK;
+}
+
+int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, int32_t* iters, double* rmax0,
+              double* rmax) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "pattern not built");
+    VEC_OR_FAIL(b_vec);
+    VEC_OR_FAIL(x_vec);
+    FEMCY_REQUIRE(b_vec != x_vec, "pcg: b and x must be different vectors");
+    if (maxit <= 0) maxit = (int32_t)std::min<int64_t>(c->n, INT32_MAX);   // reference: at most n iterations
+    return pcg_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], eps, maxit, iters, rmax0, rmax);
+}
+
+// ---------------------------------------------------------------------------------- inspection
+static int download_K(Ctx* c, std::vector<double>& vals) {
+    vals.resize((size_t)c->stored_rows * c->dm * c->dm * SLICE);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    FEMCY_HIP(hipMemcpy(vals.data(), c->d_Kvals, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return FEMCY_OK;
+}
+
+int femcy_get_K_ell(femcy_ctx* ctx, int32_t* ij, double* A) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern && ij && A, "pattern not built or null outputs");
+    std::vector<double> vals;
+    int rc = download_K(c, vals);
+    if (rc) return rc;
+    const int dm = c->dm, W = c->max_row_blocks * dm;
+    for (int32_t a = 0; a < c->nn; ++a) {
+        const int64_t off = c->h_slice_off[a / SLICE];
+        const int lane = a % SLICE, L = c->h_rowlen[a];
+        for (int r = 0; r < dm; ++r) {
+            const int64_t i = (int64_t)a * dm + r;
+            int32_t* row_ij = ij + i * (W + 1);
+            double* row_A = A + i * W;
+            row_ij[0] = L * dm;
+            for (int t = 0; t < W; ++t) {
+                row_ij[t + 1] = -1;
+                row_A[t] = 0.0;
+            }
+            for (int j = 0; j < L; ++j)
+                for (int cc = 0; cc < dm; ++cc) {
+                    row_ij[1 + j * dm + cc] = c->h_bcol[(off + j) * SLICE + lane] * dm + cc;
+                    row_A[j * dm + cc] = vals[((off + j) * (dm * dm) + r * dm + cc) * SLICE + lane];
+                }
+        }
+    }
+    return FEMCY_OK;
+}
+
+int femcy_get_K_bsr(femcy_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern && rowptr && colidx && out, "pattern not built or null outputs");
+    std::vector<double> vals;
+    int rc = download_K(c, vals);
+    if (rc) return rc;
+    const int dm = c->dm, bb = dm * dm;
+    int64_t w = 0;
+    rowptr[0] = 0;
+    std::vector<std::pair<int32_t, int32_t>> order;
+    for (int32_t a = 0; a < c->nn; ++a) {
+        const int64_t off = c->h_slice_off[a / SLICE];
+        const int lane = a % SLICE, L = c->h_rowlen[a];
+        order.clear();
+        for (int j = 0; j < L; ++j) order.push_back({c->h_bcol[(off + j) * SLICE + lane], j});
+        std::sort(order.begin(), order.end());
+        for (auto& pr : order) {
+            colidx[w] = pr.first;
+            for (int k = 0; k < bb; ++k) out[w * bb + k] = vals[((off + pr.second) * bb + k) * SLICE + lane];
+            ++w;
+        }
+        rowptr[a + 1] = (int32_t)w;
+    }
+    return FEMCY_OK;
+}
+
+int femcy_get_gp_field(femcy_ctx* ctx, int which, double* out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_element && out, "element tables not set or null output");
+    const size_t ngp = (size_t)c->ne * c->nGP;
+    const double* src = nullptr;
+    size_t count = 0;
+    switch (which) {
+        case FEMCY_GP_DSDX: src = c->d_dsdx; count = ngp * c->npe * c->dm; break;
+        case FEMCY_GP_VOL: src = c->d_vol; count = ngp; break;
+        case FEMCY_GP_F: src = c->d_F; count = ngp * c->dm * c->dm; break;
+        case FEMCY_GP_SIGMA: src = c->d_sigma; count = ngp * c->dm * c->dm; break;
+        default: set_error("unknown Gauss-point field %d", which); return FEMCY_EINVAL;
+    }
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    FEMCY_HIP(hipMemcpy(out, src, count * sizeof(double), hipMemcpyDeviceToHost));
+    return FEMCY_OK;
+}
+
+int femcy_timing(femcy_ctx* ctx, femcy_timing_t* out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(out, "null output");
+    timing_collect(c);
+    *out = c->timing;
+    return FEMCY_OK;
+}
+int femcy_timing_reset(femcy_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    timing_collect(c);
+    c->timing = femcy_timing_t{};
+    return FEMCY_OK;
+}
+
+// ------------------------------------------------------------------------------------ multi-GPU
+int femcy_comm_unique_id(void* id128) {
+    if (!id128) {
+        set_error("null id buffer");
+        return FEMCY_EINVAL;
+    }
+    return comm_unique_id(id128);
+}
+
+int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id128, int32_t niface_local,
+                    const int32_t* iface_local_dofs, const int32_t* iface_global_slot, int32_t niface_global,
+                    const uint8_t* owner) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
+    FEMCY_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && id128, "bad rank/nranks");
+    FEMCY_REQUIRE(niface_local >= 0 && niface_global >= niface_local, "bad interface sizes");
+    FEMCY_REQUIRE(owner, "owner mask required");
+    for (int32_t i = 0; i < niface_local; ++i) {
+        FEMCY_REQUIRE(iface_local_dofs[i] >= 0 && iface_local_dofs[i] < c->n, "interface DOF out of range");
+        FEMCY_REQUIRE(iface_global_slot[i] >= 0 && iface_global_slot[i] < niface_global, "interface slot out of range");
+    }
+    int rc = comm_init(c, rank, nranks, id128);
+    if (rc) return rc;
+    c->niface_local = niface_local;
+    c->niface_global = niface_global;
+    if ((rc = dev_alloc(&c->d_iface_dof, (size_t)std::max(niface_local, 1), false))) return rc;
+    if ((rc = dev_alloc(&c->d_iface_slot, (size_t)std::max(niface_local, 1), false))) return rc;
+    if ((rc = dev_alloc(&c->d_owner, (size_t)c->n + 64))) return rc;
+    if ((rc = dev_alloc(&c->d_commbuf, (size_t)niface_global + 8))) return rc;
+    if ((rc = dev_alloc(&c->d_gather, (size_t)nranks * 2 + 2))) return rc;
+    if (niface_local > 0) {
+        FEMCY_HIP(hipMemcpy(c->d_iface_dof, iface_local_dofs, sizeof(int32_t) * niface_local, hipMemcpyHostToDevice));
+        FEMCY_HIP(hipMemcpy(c->d_iface_slot, iface_global_slot, sizeof(int32_t) * niface_local, hipMemcpyHostToDevice));
+    }
+    FEMCY_HIP(hipMemcpy(c->d_owner, owner, (size_t)c->n, hipMemcpyHostToDevice));
+    return FEMCY_OK;
+}
+
+int femcy_iface_sum(femcy_ctx* ctx, int vec) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    return iface_sum(c, c->d_vec[vec]);
+}
+
+}  // extern "C"

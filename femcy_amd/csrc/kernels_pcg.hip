@@ -1,0 +1,521 @@
+// Jacobi-preconditioned CG on the blocked SELL-64 matrix, plus the axpy-class vector helpers.
+//
+// Reference: conjugateGradientSolver.py:10-127 (ConjugateGradientSolver_rowMajor) and
+// tiGadgets.py:5-37,67-70.  The reference issues 8 kernels and 4 blocking device->host scalar reads
+// per iteration; here one iteration is 3 kernels and no host round trip:
+//
+//   k_spmv        Ad = K d, per-block partials of d.Ad                      (compute_Ad + dot_product)
+//   k_update_xr   alpha = rMr / sum(partials);  x += alpha d;  r -= alpha Ad;
+//                 per-block partials of r.M.r and max|r|                    (update_x, update_r,
+//                                                                            compute_rMr, rmax)
+//   k_update_d    beta = rMr_new / rMr;  d = M r + beta d;  block 0 publishes rMr_new, rmax, iters
+//                 and the converged flag                                    (update_d + stopping rule)
+//
+// Scalars never leave the device: every block of the consuming kernel re-reduces the producer's
+// partials in a fixed order (deterministic, no atomics, no extra launch); the kernel boundary is
+// the release/acquire.  The recurrence, the initial guess x0 = 0, M = 1/diag(K) and the stopping
+// rule max|r| < eps * max|r0| are the reference's.  Once `done` is set the remaining queued kernels
+// exit immediately, so x is exactly the iterate at which the reference would `break`; the host
+// polls the flag every `opt_poll` iterations through pinned memory.
+//
+// SpMV layout: lane = node (dm rows), slice = 64 nodes = one wavefront, values stored
+// [stored_row][k = r*dm+c][lane] so every load instruction of a wave is one contiguous 512-byte
+// segment; the block-column index is stored once per block ([stored_row][lane]); x is gathered
+// dm doubles at a time.  Workgroups are remapped so that each XCD (private 4 MiB L2) walks one
+// contiguous range of slices and the x-gathers of neighbouring slices hit the same L2.
+#include <cmath>
+#include "ctx.hpp"
+
+namespace femcy {
+
+constexpr int BS = 256;
+constexpr int NXCD = 8;
+
+// ------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// result broadcast to every thread; sm must hold BS/64 doubles; two calls need distinct sm
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) t += sm[i];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ double block_max(double v, double* sm) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = sm[0];
+#pragma unroll
+    for (int i = 1; i < BS / 64; ++i) t = fmax(t, sm[i]);
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ double reduce_partials_sum(const double* __restrict__ part, int np, double* sm) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += BS) v += part[i];
+    return block_sum(v, sm);
+}
+__device__ __forceinline__ double reduce_partials_max(const double* __restrict__ part, int np, double* sm) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += BS) v = fmax(v, part[i]);
+    return block_max(v, sm);
+}
+__device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops NaN; keep it visible
+    double a = fabs(r);
+    return (a != a) ? INFINITY : a;
+}
+
+// ------------------------------------------------------------------------------------------ SpMV
+template <int DM>
+__global__ void __launch_bounds__(BS) k_spmv(int32_t nn, int32_t nslices, const int32_t* __restrict__ slice_len,
+                                             const int64_t* __restrict__ slice_off,
+                                             const int32_t* __restrict__ bcol, const double* __restrict__ vals,
+                                             const double* __restrict__ x, double* __restrict__ y,
+                                             double* __restrict__ partials, const int32_t* __restrict__ done) {
+    __shared__ double sm[BS / 64];
+    if (done && *done) return;
+    // XCD-aware remap: physical block b runs on XCD b % 8; give each XCD a contiguous slice range
+    const int nb = gridDim.x;
+    const int per = (nb + NXCD - 1) / NXCD;
+    const int vb = (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
+    const int lane = threadIdx.x & 63;
+    const int s = vb * (BS / 64) + (threadIdx.x >> 6);
+    double dot = 0.0;
+    if (vb < nb && s < nslices) {
+        const int32_t L = slice_len[s];
+        const int64_t off = slice_off[s];
+        const int64_t a = (int64_t)s * SLICE + lane;
+        double acc[DM];
+#pragma unroll
+        for (int r = 0; r < DM; ++r) acc[r] = 0.0;
+        const int32_t* __restrict__ bc = bcol + off * SLICE + lane;
+        const double* __restrict__ v = vals + off * (DM * DM) * SLICE + lane;
+#pragma unroll 2
+        for (int32_t j = 0; j < L; ++j) {
+            const int64_t col = bc[(int64_t)j * SLICE];
+            double xv[DM];
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
+#pragma unroll
+            for (int r = 0; r < DM; ++r)
+#pragma unroll
+                for (int cc = 0; cc < DM; ++cc) acc[r] += v[((int64_t)j * (DM * DM) + r * DM + cc) * SLICE] * xv[cc];
+        }
+        if (a < nn) {
+#pragma unroll
+            for (int r = 0; r < DM; ++r) {
+                y[a * DM + r] = acc[r];
+                dot += x[a * DM + r] * acc[r];
+            }
+        }
+    }
+    if (partials) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+}
+
+// M = 1/diag(K) (M_init, conjugateGradientSolver.py:48-51): diagonal block is stored row 0 of the slice
+template <int DM>
+__global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int64_t* __restrict__ slice_off,
+                                               const double* __restrict__ vals, double* __restrict__ M, int invert) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nn) return;
+    const int64_t row = slice_off[a >> 6];
+    const int lane = (int)(a & 63);
+#pragma unroll
+    for (int r = 0; r < DM; ++r) {
+        const double dg = vals[(row * (DM * DM) + r * DM + r) * SLICE + lane];
+        M[a * DM + r] = invert ? 1.0 / dg : dg;
+    }
+}
+__global__ void __launch_bounds__(BS) k_recip(int64_t n, double* __restrict__ v) {
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) v[i] = 1.0 / v[i];
+}
+
+// x = 0, r = b, d = M r, partials of (r.M.r, max|r|)   (re_init + r_d_init, :32-38, :60-65)
+__global__ void __launch_bounds__(BS) k_pcg_init(int64_t n2, const double2* __restrict__ b, const double2* __restrict__ M,
+                                                 double2* __restrict__ x, double2* __restrict__ r,
+                                                 double2* __restrict__ d, const uint8_t* __restrict__ owner,
+                                                 double* __restrict__ part2) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64];
+    double rMr = 0.0, rm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 bv = b[i], mv = M[i];
+        x[i] = make_double2(0.0, 0.0);
+        r[i] = bv;
+        d[i] = make_double2(mv.x * bv.x, mv.y * bv.y);
+        double w0 = 1.0, w1 = 1.0;
+        if (owner) {
+            w0 = owner[2 * i];
+            w1 = owner[2 * i + 1];
+        }
+        rMr += w0 * (bv.x * mv.x * bv.x) + w1 * (bv.y * mv.y * bv.y);
+        rm = fmax(rm, fmax(nan_to_inf_abs(bv.x), nan_to_inf_abs(bv.y)));
+    }
+    const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
+    if (threadIdx.x == 0) {
+        part2[2 * blockIdx.x] = s;
+        part2[2 * blockIdx.x + 1] = m;
+    }
+}
+
+__global__ void __launch_bounds__(BS) k_pcg_init_final(int np, const double* __restrict__ part2, PcgState* st,
+                                                       const double* __restrict__ gathered, int nranks) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64];
+    double s = 0.0, m = 0.0;
+    if (gathered) {   // multi-rank: (sum, max) pairs already reduced per rank
+        for (int i = threadIdx.x; i < nranks; i += BS) {
+            s += gathered[2 * i];
+            m = fmax(m, gathered[2 * i + 1]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < np; i += BS) {
+            s += part2[2 * i];
+            m = fmax(m, part2[2 * i + 1]);
+        }
+    }
+    s = block_sum(s, sm1);
+    m = block_max(m, sm2);
+    if (threadIdx.x == 0) {
+        st->rMr[0] = s;
+        st->rMr[1] = 0.0;
+        st->r0 = m;
+        st->rmax = m;
+        st->dAd = 0.0;
+        st->iters = 0;
+        st->done = (m == 0.0) ? 1 : ((m != m || isinf(m)) ? 2 : 0);
+    }
+}
+
+// x += alpha d; r -= alpha Ad; partials (r.M.r, max|r|)
+__global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, const double* __restrict__ part1,
+                                                  const double* __restrict__ dAd_reduced, const PcgState* st,
+                                                  const double2* __restrict__ d, const double2* __restrict__ Ad,
+                                                  const double2* __restrict__ M, double2* __restrict__ x,
+                                                  double2* __restrict__ r, const uint8_t* __restrict__ owner,
+                                                  double* __restrict__ part2) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64];
+    if (st->done) return;
+    const double dAd = dAd_reduced ? *dAd_reduced : reduce_partials_sum(part1, np1, sm1);
+    const double alpha = st->rMr[it & 1] / dAd;
+    double rMr = 0.0, rm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 dv = d[i], av = Ad[i], mv = M[i];
+        double2 xv = x[i], rv = r[i];
+        xv.x = xv.x + alpha * dv.x;
+        xv.y = xv.y + alpha * dv.y;
+        rv.x = rv.x - alpha * av.x;
+        rv.y = rv.y - alpha * av.y;
+        x[i] = xv;
+        r[i] = rv;
+        double w0 = 1.0, w1 = 1.0;
+        if (owner) {
+            w0 = owner[2 * i];
+            w1 = owner[2 * i + 1];
+        }
+        rMr += w0 * (rv.x * mv.x * rv.x) + w1 * (rv.y * mv.y * rv.y);
+        rm = fmax(rm, fmax(nan_to_inf_abs(rv.x), nan_to_inf_abs(rv.y)));
+    }
+    const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
+    if (threadIdx.x == 0) {
+        part2[2 * blockIdx.x] = s;
+        part2[2 * blockIdx.x + 1] = m;
+    }
+}
+
+// d = M r + beta d; publish scalars and the stopping decision
+__global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int it, int np2, const double* __restrict__ part2,
+                                                 const double* __restrict__ gathered, int nranks, double eps,
+                                                 PcgState* st, const double2* __restrict__ r,
+                                                 const double2* __restrict__ M, double2* __restrict__ d) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64];
+    if (st->done) return;
+    double s = 0.0, m = 0.0;
+    if (gathered) {
+        for (int i = threadIdx.x; i < nranks; i += BS) {
+            s += gathered[2 * i];
+            m = fmax(m, gathered[2 * i + 1]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < np2; i += BS) {
+            s += part2[2 * i];
+            m = fmax(m, part2[2 * i + 1]);
+        }
+    }
+    const double rMr_new = block_sum(s, sm1);
+    const double rmax = block_max(m, sm2);
+    const double rMr_old = st->rMr[it & 1];
+    const double r0 = st->r0;
+    const double beta = rMr_new / rMr_old;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
+        const double2 rv = r[i], mv = M[i];
+        double2 dv = d[i];
+        dv.x = mv.x * rv.x + beta * dv.x;
+        dv.y = mv.y * rv.y + beta * dv.y;
+        d[i] = dv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rMr[(it + 1) & 1] = rMr_new;
+        st->rmax = rmax;
+        st->iters = it + 1;
+        if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new)
+            st->done = 2;
+        else if (rmax < eps * r0)
+            st->done = 1;
+    }
+}
+
+// single-block sum of SpMV partials into one slot (multi-rank path)
+__global__ void __launch_bounds__(BS) k_sum_partials(int np, const double* __restrict__ part, double* out) {
+    __shared__ double sm[BS / 64];
+    const double t = reduce_partials_sum(part, np, sm);
+    if (threadIdx.x == 0) *out = t;
+}
+__global__ void __launch_bounds__(BS) k_sum_partials2(int np, const double* __restrict__ part2, double* out2) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64];
+    double s = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < np; i += BS) {
+        s += part2[2 * i];
+        m = fmax(m, part2[2 * i + 1]);
+    }
+    s = block_sum(s, sm1);
+    m = block_max(m, sm2);
+    if (threadIdx.x == 0) {
+        out2[0] = s;
+        out2[1] = m;
+    }
+}
+__global__ void k_iface_pack(int32_t k, const int32_t* __restrict__ dof, const int32_t* __restrict__ slot,
+                             const double* __restrict__ v, double* __restrict__ buf) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) buf[slot[i]] = v[dof[i]];
+}
+__global__ void k_iface_unpack(int32_t k, const int32_t* __restrict__ dof, const int32_t* __restrict__ slot,
+                               const double* __restrict__ buf, double* __restrict__ v) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) v[dof[i]] = buf[slot[i]];
+}
+
+// ------------------------------------------------------------------------------- vector helpers
+__global__ void __launch_bounds__(BS) k_fill(int64_t n, double* __restrict__ v, double val) {
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) v[i] = val;
+}
+__global__ void __launch_bounds__(BS) k_sub(int64_t n, double* __restrict__ c, const double* __restrict__ a,
+                                            const double* __restrict__ b) {
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) c[i] = a[i] - b[i];
+}
+__global__ void __launch_bounds__(BS) k_axpy(int64_t n, double* __restrict__ a, const double* __restrict__ b, double cc,
+                                             const double* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS)
+        a[i] = b[i] + cc * d[i];
+}
+__global__ void __launch_bounds__(BS) k_scale(int64_t n, double* __restrict__ v, double s) {
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) v[i] *= s;
+}
+__global__ void k_scatter(int32_t k, const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                          double* __restrict__ v) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) v[idx[i]] = vals[i];
+}
+// mode 0: sum of squares, mode 1: max |.|; partials then a single-block finish into *out
+__global__ void __launch_bounds__(BS) k_reduce(int64_t n, const double* __restrict__ v, int mode,
+                                               double* __restrict__ part) {
+    __shared__ double sm[BS / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        const double t = v[i];
+        acc = mode ? fmax(acc, nan_to_inf_abs(t)) : acc + t * t;
+    }
+    const double t = mode ? block_max(acc, sm) : block_sum(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(BS) k_reduce_final(int np, const double* __restrict__ part, int mode, double* out) {
+    __shared__ double sm[BS / 64];
+    const double t = mode ? reduce_partials_max(part, np, sm) : reduce_partials_sum(part, np, sm);
+    if (threadIdx.x == 0) *out = t;
+}
+
+static inline int ew_grid(int64_t n) {
+    int64_t g = (n + BS - 1) / BS;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
+}
+
+int vec_fill(Ctx* c, double* d, double v, int64_t n) {
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(BS), 0, c->stream, n, d, v);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+int vec_sub(Ctx* c, double* dc, const double* da, const double* db) {
+    hipLaunchKernelGGL(k_sub, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, dc, da, db);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+int vec_axpy(Ctx* c, double* da, const double* db, double cc, const double* dd) {
+    hipLaunchKernelGGL(k_axpy, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, da, db, cc, dd);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+int vec_scale(Ctx* c, double* d, double s) {
+    hipLaunchKernelGGL(k_scale, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, d, s);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k) {
+    if (k <= 0) return FEMCY_OK;
+    hipLaunchKernelGGL(k_scatter, dim3((k + BS - 1) / BS), dim3(BS), 0, c->stream, k, d_idx, d_vals, d);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+static int vec_reduce(Ctx* c, const double* d, int mode, double* out) {
+    const int g = ew_grid(c->n);
+    hipLaunchKernelGGL(k_reduce, dim3(g), dim3(BS), 0, c->stream, c->n, d, mode, c->d_part1);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part1, mode, c->d_part2);
+    FEMCY_HIP(hipGetLastError());
+    FEMCY_HIP(hipMemcpyAsync(c->h_scalar, c->d_part2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    *out = c->h_scalar[0];
+    return FEMCY_OK;
+}
+int vec_sumsq(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 0, out); }
+int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1, out); }
+
+// ---------------------------------------------------------------------------------------- SpMV
+int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
+    const int grid = (c->nslices + (BS / 64) - 1) / (BS / 64);
+    if (grid > MAX_PARTIALS) {
+        // more slices than partial slots: fall back to a coarser partial count is not needed for the
+        // sizes this path is built for (4096 blocks = 1M nodes); report instead of silently truncating
+        set_error("SpMV grid %d exceeds MAX_PARTIALS %d", grid, MAX_PARTIALS);
+        return FEMCY_EINVAL;
+    }
+    const int32_t* done = d_partials ? &c->d_state->done : nullptr;
+    size_t th = timing_begin(c, T_SPMV);
+    if (c->dm == 3)
+        hipLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->nslices, c->d_slice_len,
+                           c->d_slice_off, c->d_bcol, c->d_Kvals, d_x, d_y, d_partials, done);
+    else
+        hipLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->nslices, c->d_slice_len,
+                           c->d_slice_off, c->d_bcol, c->d_Kvals, d_x, d_y, d_partials, done);
+    timing_end(c, th);
+    FEMCY_HIP(hipGetLastError());
+    if (nblocks_out) *nblocks_out = grid;
+    return FEMCY_OK;
+}
+
+// sum a sub-assembled vector over the ranks that share each interface DOF
+int iface_sum(Ctx* c, double* d_v) {
+    if (!c->comm) return FEMCY_OK;
+    FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
+    if (c->niface_local > 0)
+        hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream, c->niface_local,
+                           c->d_iface_dof, c->d_iface_slot, d_v, c->d_commbuf);
+    int rc = comm_allreduce_sum(c, c->d_commbuf, c->niface_global);
+    if (rc) return rc;
+    if (c->niface_local > 0)
+        hipLaunchKernelGGL(k_iface_unpack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
+                           c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, d_v);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
+// ----------------------------------------------------------------------------------------- PCG
+int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
+              double* rmax) {
+    const int64_t n2 = (c->n + 1) / 2;
+    const int g = ew_grid(n2);
+    const bool multi = c->comm != nullptr;   // a 1-rank communicator still runs the exchange path (testable on one GPU)
+    size_t th = timing_begin(c, T_PCG);
+
+    // M = 1 / diag(K) (M_init).  Multi-rank: K is sub-assembled, so diag is summed over the interface first.
+    const int jg = (c->nn + BS - 1) / BS;
+    if (c->dm == 3)
+        hipLaunchKernelGGL((k_jacobi<3>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_slice_off, c->d_Kvals,
+                           c->d_M, multi ? 0 : 1);
+    else
+        hipLaunchKernelGGL((k_jacobi<2>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_slice_off, c->d_Kvals,
+                           c->d_M, multi ? 0 : 1);
+    if (multi) {
+        int rc = iface_sum(c, c->d_M);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_recip, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
+    }
+    hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)d_b, (const double2*)c->d_M,
+                       (double2*)d_x, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),
+                       c->d_part2);
+    if (multi) {
+        hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, c->d_commbuf);
+        int rc = comm_allgather(c, c->d_commbuf, c->d_gather, 2);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, c->d_state,
+                       (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks);
+    FEMCY_HIP(hipGetLastError());
+
+    int np1 = 0;
+    int32_t it = 0;
+    bool finished = false;
+    while (!finished) {
+        const int32_t burst_end = (int32_t)std::min<int64_t>((int64_t)it + c->opt_poll, maxit);
+        for (; it < burst_end; ++it) {
+            int rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1);
+            if (rc) return rc;
+            const double* dAd_red = nullptr;
+            if (multi) {
+                // interface rows of Ad hold partial sums: pack them + the local d.Ad, all-reduce, unpack
+                double* slot = c->d_commbuf + c->niface_global;
+                FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, c->stream, np1, c->d_part1, slot);
+                if (c->niface_local > 0)
+                    hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
+                                       c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_Ad, c->d_commbuf);
+                if ((rc = comm_allreduce_sum(c, c->d_commbuf, (int64_t)c->niface_global + 1))) return rc;
+                if (c->niface_local > 0)
+                    hipLaunchKernelGGL(k_iface_unpack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
+                                       c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
+                dAd_red = slot;
+            }
+            hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(BS), 0, c->stream, n2, (int)it, np1, c->d_part1, dAd_red,
+                               c->d_state, (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M,
+                               (double2*)d_x, (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr),
+                               c->d_part2);
+            if (multi) {
+                double* pair = c->d_commbuf + c->niface_global + 2;
+                hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, pair);
+                if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
+            }
+            hipLaunchKernelGGL(k_update_d, dim3(g), dim3(BS), 0, c->stream, n2, (int)it, g, c->d_part2,
+                               (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, eps, c->d_state,
+                               (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d);
+        }
+        FEMCY_HIP(hipGetLastError());
+        FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_state->done || it >= maxit) finished = true;
+    }
+    timing_end(c, th);
+    if (iters) *iters = c->h_state->iters;
+    if (r0) *r0 = c->h_state->r0;
+    if (rmax) *rmax = c->h_state->rmax;
+    c->timing.pcg_iters += c->h_state->iters;
+    if (c->h_state->done == 2) {
+        set_error("PCG breakdown: NaN/Inf residual after %d iterations (r0 = %g)", c->h_state->iters, c->h_state->r0);
+        return FEMCY_ENUMERIC;
+    }
+    return FEMCY_OK;
+}
+
+}  // namespace femcy

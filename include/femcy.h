@@ -1,0 +1,182 @@
+/*
+ * femcy.h -- C ABI of libfemcy_hip.so, the MI355X (gfx950) solve path behind FEMcy's Python surface.
+ *
+ * The reference (mo-hanxuan/FEMcy) has no FFI: its "operator API" is Python duck typing over Taichi
+ * kernels.  Every entry point below names the reference kernel(s)/method(s) it replaces
+ * (file:line relative to the reference checkout) -- this is exactly the set a ctypes binding of
+ * `System_of_equations` / `ConjugateGradientSolver_rowMajor` needs (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FEMCY_E* code otherwise; the message is
+ *     available from femcy_last_error() (thread-local).  The library never aborts or throws.
+ *   - host pointers are caller-owned and only borrowed for the duration of the call.
+ *   - device memory is library-owned inside the opaque femcy_ctx: one ctx = one HIP device + one
+ *     stream.  A ctx is not thread-safe; different ctxs are independent.
+ *   - all floating point is f64, all indices i32 (reference: main.py:11 default_fp=ti.f64).
+ *   - DOF numbering: i = node*dm + component (stiffnessMtrx.py:179-180).
+ *   - solver vectors (the reference's ti.fields rhs/dof/residual/...) live in HBM inside the ctx and
+ *     are addressed by the femcy_vec ids below; femcy_vec_upload/_download move them across PCIe.
+ */
+#ifndef FEMCY_H
+#define FEMCY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct femcy_ctx femcy_ctx;
+
+enum femcy_status {
+    FEMCY_OK = 0,
+    FEMCY_EINVAL = -1,     /* bad argument / call order */
+    FEMCY_EHIP = -2,       /* a HIP runtime call failed */
+    FEMCY_ENOKERNEL = -3,  /* no kernel instantiation for this (npe, dm, nGP) / material */
+    FEMCY_ENUMERIC = -4,   /* NaN/breakdown detected by a solver */
+    FEMCY_ECOMM = -5,      /* RCCL failure */
+    FEMCY_ENOMEM = -6
+};
+
+/* device-resident solver vectors, each of length n = nn*dm (stiffnessMtrx.py:33-34,55-56,95,113;
+ * conjugateGradientSolver.py:20-29) */
+enum femcy_vec {
+    FEMCY_VEC_DOF = 0,       /* System_of_equations.dof                 */
+    FEMCY_VEC_RHS = 1,       /* .rhs                                    */
+    FEMCY_VEC_RESIDUAL = 2,  /* .residual_nodal_force                   */
+    FEMCY_VEC_FORCE = 3,     /* .nodal_force                            */
+    FEMCY_VEC_DU = 4,        /* .du                                     */
+    FEMCY_VEC_DOF_OLD = 5,   /* .dof_old                                */
+    FEMCY_VEC_X = 6,         /* ConjugateGradientSolver_rowMajor.x      */
+    FEMCY_VEC_TMP0 = 7,
+    FEMCY_VEC_TMP1 = 8,
+    FEMCY_VEC_COUNT = 9
+};
+
+/* Voigt pattern of the strain matrix B (element_zoo: strainMtrx) */
+enum femcy_voigt { FEMCY_VOIGT_2D = 0 /* xx,yy,xy */, FEMCY_VOIGT_3D = 1 /* xx,yy,zz,xy,zx,yz */ };
+
+/* material_zoo classes (reader/inp_info.py:294-316) */
+enum femcy_material {
+    FEMCY_MAT_LIN3D = 0,    /* linear_isotropic.py            params = {E, nu}  */
+    FEMCY_MAT_PSTRAIN = 1,  /* linear_isotropic_plane_strain  params = {E, nu}  */
+    FEMCY_MAT_PSTRESS = 2,  /* linear_isotropic_plane_stress  params = {E, nu}  */
+    FEMCY_MAT_NEOHOOKE = 3  /* neo_hookean.py                 params = {C1, D1} */
+};
+
+/* Gauss-point fields that can be downloaded for checking (stiffnessMtrx.py:40-61) */
+enum femcy_gpfield {
+    FEMCY_GP_DSDX = 0,   /* f64[ne][nGP][npe][dm] */
+    FEMCY_GP_VOL = 1,    /* f64[ne][nGP]          */
+    FEMCY_GP_F = 2,      /* f64[ne][nGP][dm][dm]  */
+    FEMCY_GP_SIGMA = 3   /* f64[ne][nGP][dm][dm]  */
+};
+
+/* assembly strategy (femcy_set_option FEMCY_OPT_ASSEMBLY) */
+enum femcy_assembly { FEMCY_ASM_GATHER = 0 /* owner-computes, deterministic */, FEMCY_ASM_ATOMIC = 1 /* f64 HW atomics */ };
+
+enum femcy_option {
+    FEMCY_OPT_ASSEMBLY = 0,     /* enum femcy_assembly, default GATHER                         */
+    FEMCY_OPT_PCG_POLL = 1,     /* iterations between host polls of the device "done" flag      */
+    FEMCY_OPT_TIMING = 2,       /* 1 = bracket kernel classes with hipEvents (femcy_timing)     */
+    FEMCY_OPT_SPMV_VARIANT = 3  /* 0 = 8-byte loads, 1 = 16-byte paired loads                   */
+};
+
+typedef struct femcy_pattern_info {
+    int64_t n;           /* scalar DOFs                                                */
+    int64_t nnzb;        /* structural dm x dm blocks (node adjacency incl. diagonal)   */
+    int64_t nnz;         /* nnzb*dm*dm                                                  */
+    int32_t max_row_blocks;   /* max neighbours per node (reference: maxLen, stiffnessMtrx.py:80) */
+    int32_t ell_width;        /* reference W = max_row_blocks*dm                          */
+    int64_t stored_blocks;    /* blocks stored incl. SELL padding                         */
+    int32_t nslices;
+    int32_t max_node_elems;   /* reference nodeEles width (stiffnessMtrx.py:71)           */
+} femcy_pattern_info;
+
+typedef struct femcy_timing_t {
+    /* accumulated since the last femcy_timing_reset; *_ms from hipEvents on the ctx stream */
+    double geom_ms;      int64_t geom_launches;      /* get_dsdx_and_vol / F / sigma kernels  */
+    double assemble_ms;  int64_t assemble_launches;  /* K assembly kernel                     */
+    double force_ms;     int64_t force_launches;     /* nodal-force gather                    */
+    double spmv_ms;      int64_t spmv_launches;      /* compute_Ad                            */
+    double pcg_ms;       int64_t pcg_iters;          /* whole PCG solves (all kernels)        */
+} femcy_timing_t;
+
+/* ------------------------------------------------------------------ life cycle / diagnostics */
+int femcy_ctx_create(int device, femcy_ctx** out);
+int femcy_ctx_destroy(femcy_ctx* ctx);
+const char* femcy_last_error(void);
+int femcy_version(void);
+int femcy_set_option(femcy_ctx* ctx, int option, int64_t value);
+int femcy_sync(femcy_ctx* ctx);                                   /* hipStreamSynchronize */
+
+/* ----------------------------------------------------------------------- problem definition */
+/* Body + System_of_equations.__init__ state (body.py:13-17, stiffnessMtrx.py:26-121) */
+int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes /*[nn*dm]*/,
+                   int32_t ne, int32_t npe, const int32_t* elems /*[ne*npe]*/);
+/* table-driven element plugin: ELE.gaussPoints/gaussWeights/dshape_dnat (element_zoo modules) */
+int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN /*[nGP*npe*dm]*/,
+                      const double* w /*[nGP]*/, int32_t voigt_kind);
+/* material.C copied to every Gauss point by ddsdde_init (stiffnessMtrx.py:124-129) + sigma(F) kind */
+int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C /*[s*s]*/, const double* params,
+                       int32_t nparams);
+/* body.get_nodeEles/get_coElement_nodes + sparseIJ (body.py:165-194, stiffnessMtrx.py:70-89):
+ * node adjacency -> blocked sliced-ELL matrix, element->slot map, node->element lists */
+int femcy_build_pattern(femcy_ctx* ctx);
+int femcy_get_pattern_info(femcy_ctx* ctx, femcy_pattern_info* out);
+
+/* ------------------------------------------------------------------------- vector plumbing */
+int femcy_vec_upload(femcy_ctx* ctx, int vec, const double* src, int64_t n);
+int femcy_vec_download(femcy_ctx* ctx, int vec, double* dst, int64_t n);
+int femcy_vec_fill(femcy_ctx* ctx, int vec, double value);                 /* field.fill()          */
+int femcy_vec_copy(femcy_ctx* ctx, int dst, int src);                      /* field.copy_from()     */
+int femcy_vec_scatter(femcy_ctx* ctx, int vec, const int32_t* idx, const double* vals, int32_t k);
+                                                      /* dirichletBC_val, stiffnessMtrx.py:357-366 */
+int femcy_vec_sub(femcy_ctx* ctx, int c, int a, int b);                    /* tiGadgets.py:5-9      */
+int femcy_vec_axpy(femcy_ctx* ctx, int a, int b, double c, int d);         /* a = b + c*d, :12-16   */
+int femcy_vec_scale(femcy_ctx* ctx, int vec, double s);                    /* tiGadgets.py:67-70    */
+int femcy_vec_norm(femcy_ctx* ctx, int vec, double* rms);                  /* tiGadgets.py:28-37    */
+int femcy_vec_absmax(femcy_ctx* ctx, int vec, double* out);                /* tiGadgets.py:19-25    */
+
+/* --------------------------------------------------------------------------- the hot path */
+/* get_dsdx_and_vol + assemble_stiffnessMtrx (stiffnessMtrx.py:132-150, 161-186) at x = X + vec[u] */
+int femcy_assemble_K(femcy_ctx* ctx, int u_vec);
+/* assemble_nodal_force_GN (stiffnessMtrx.py:609-644): F (ref. config), sigma(F), dsdx/vol (current
+ * config), node-parallel gather of dsdx . sigma * vol */
+int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec);
+/* dirichletBC_linearEquations (stiffnessMtrx.py:279-307) for one *Boundary block, race-free */
+int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const double* vals, int32_t k, int rhs_vec);
+/* dirichletBC_forNewtonMethod_kernel (stiffnessMtrx.py:317-341) */
+int femcy_apply_dirichlet_newton(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int residual_vec);
+/* compute_Ad (conjugateGradientSolver.py:53-58): vec[y] = K vec[x] */
+int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec);
+/* ConjugateGradientSolver_rowMajor.re_init + solve (conjugateGradientSolver.py:32-51, 103-127):
+ * Jacobi-PCG, x0 = 0, stop when max|r| < eps*max|r0|, at most maxit iterations (reference: n). */
+int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, int32_t* iters,
+              double* rmax0, double* rmax);
+
+/* --------------------------------------------------------------------- inspection (tests) */
+/* the reference's sparseIJ / sparseMtrx_rowMajor layouts (stiffnessMtrx.py:78-94) */
+int femcy_get_K_ell(femcy_ctx* ctx, int32_t* ij /*[n*(W+1)]*/, double* A /*[n*W]*/);
+/* block-CSR with ascending columns: rowptr[nn+1], colidx[nnzb], vals[nnzb*dm*dm] */
+int femcy_get_K_bsr(femcy_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* vals);
+int femcy_get_gp_field(femcy_ctx* ctx, int which, double* out);
+int femcy_timing(femcy_ctx* ctx, femcy_timing_t* out);
+int femcy_timing_reset(femcy_ctx* ctx);
+
+/* ------------------------------------------------------------------- multi-GPU (new work) */
+/* 128-byte ncclUniqueId produced on rank 0 and broadcast by the host program */
+int femcy_comm_unique_id(void* id128);
+/* element partition: this ctx holds one sub-mesh; iface_local_dofs[k] is the local scalar DOF that is
+ * entry iface_global_slot[k] of the packed global interface vector (length niface_global), owner[i] = 1
+ * if this rank counts local DOF i in dot products (exactly one rank per shared DOF). */
+int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id128,
+                    int32_t niface_local, const int32_t* iface_local_dofs, const int32_t* iface_global_slot,
+                    int32_t niface_global, const uint8_t* owner /*[n]*/);
+/* sum a sub-assembled vector over the ranks sharing each interface DOF (forces, diag(K)) */
+int femcy_iface_sum(femcy_ctx* ctx, int vec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMCY_H */

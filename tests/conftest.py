@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory():
+    """creates femcy_amd Contexts; a -m gpu run on a box without a GPU must fail, not skip."""
+    from femcy_amd.backend import Context
+    made = []
+
+    def make(device=0):
+        c = Context(device)
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()

@@ -1,0 +1,227 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the reference's own decks.
+
+Tolerances: everything is f64; the HIP kernels evaluate the same sums as the reference in a
+different association order (FMA contraction, element accumulation order), so agreement is to
+rounding: 1e-12 relative on matrix entries / fields, looser on solver iterates after O(100) CG
+iterations (tolerances stated per test).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import deck, oracle_material
+from oracle import femcy_oracle as orc
+from oracle.elements import elem_def
+
+pytestmark = pytest.mark.gpu
+
+DECKS = [  # one per element type x material class
+    "ellip_membrane_linEle_localVeryFine.inp",      # CPS3  plane stress
+    "cookMembrane_2d_linearEl_smallDef.inp",        # CPE3  plane strain
+    "ellip_CPS4.inp",                               # CPS4
+    "ellip_membrane_quadritic_trig_neumann.inp",    # CPS6
+    "ellip_CPS8.inp",                               # CPS8
+    "twist_plate_C3D4.inp",                         # C3D4  lin3d
+    "cook_3d_linearEl_largeDef.inp",                # C3D4  neo-Hookean
+    "twist_C3D10_coarse.inp",                       # C3D10
+]
+
+
+def load(name):
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    mat = list(inp.materials.values())[0]
+    return inp, et, inp.eSets[et], mat
+
+
+def make_ctx(factory, inp, el, mat):
+    ctx = factory()
+    ctx.set_mesh(inp.nodes, el)
+    ctx.set_element(inp.ELE)
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    return ctx
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def smooth_disp(nodes, scale):
+    """a smooth, non-trivial displacement field (no RNG): ~scale * characteristic length."""
+    L = np.ptp(nodes, axis=0).max()
+    x = nodes / L
+    u = np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]),
+                  0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0],
+                  0.3 * np.sin(x.sum(axis=1))][:nodes.shape[1]], axis=1)
+    return (scale * L * u).ravel()
+
+
+@pytest.mark.parametrize("name", DECKS)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_assemble_K(gpu_ctx_factory, name, mode):
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.set_option(be.OPT_ASSEMBLY, mode)
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    for scale in (0.0, 0.02):
+        u = smooth_disp(inp.nodes, scale)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.assemble_K(be.VEC_DOF)
+        K = ctx.get_K_bsr().tocsr()
+        Ko = orc.assemble_K(topo, u, oracle_material(mat).C)
+        assert abs(K - Ko).max() / abs(Ko).max() < 1e-12          # entry-wise, relative to max|K|
+        dsdx, vol = orc.dsdx_and_vol(topo.nodes, topo.elements, u, topo.ed)
+        assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy(), dsdx) < 1e-12
+        assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), vol) < 1e-12
+    # the reference-layout export (sparseIJ / sparseMtrx_rowMajor) is the same matrix
+    ij, A = ctx.get_K_ell()
+    n = ctx.n
+    rows = np.repeat(np.arange(n), ij[:, 0])
+    mask = np.arange(ij.shape[1] - 1)[None, :] < ij[:, :1]
+    Kell = sp.coo_matrix((A[mask], (rows, ij[:, 1:][mask])), shape=(n, n)).tocsr()
+    assert abs(Kell - K).max() == 0.0
+    info = ctx.pattern_info()
+    assert info.nnzb == topo.adj_idx.size and info.max_row_blocks == np.diff(topo.adj_ptr).max()
+
+
+@pytest.mark.parametrize("name", DECKS)
+def test_spmv_and_vectors(gpu_ctx_factory, name):
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)
+    K = ctx.get_K_bsr().tocsr()
+    x = np.random.default_rng(0).standard_normal(ctx.n)
+    ctx.upload(be.VEC_TMP0, x)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    y = ctx.download(be.VEC_TMP1)
+    assert rel(y, K @ x) < 1e-13
+    # tiGadgets
+    ctx.upload(be.VEC_RHS, 2.0 * x)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_TMP0, be.VEC_RHS)
+    assert np.array_equal(ctx.download(be.VEC_RESIDUAL), x - 2.0 * x)
+    ctx.vec_axpy(be.VEC_DU, be.VEC_TMP0, -0.25, be.VEC_RHS)
+    assert np.allclose(ctx.download(be.VEC_DU), x - 0.25 * 2.0 * x, rtol=1e-15, atol=0)
+    ctx.vec_scale(be.VEC_DU, 0.5)
+    assert np.allclose(ctx.download(be.VEC_DU), 0.5 * (x - 0.5 * x), rtol=1e-15, atol=0)
+    assert abs(ctx.vec_norm(be.VEC_TMP0) - orc.field_norm(x)) < 1e-13 * orc.field_norm(x)
+    assert ctx.vec_absmax(be.VEC_TMP0) == np.abs(x).max()
+    ctx.vector(be.VEC_DU).fill(3.5)
+    assert (ctx.download(be.VEC_DU) == 3.5).all()
+    ctx.vector(be.VEC_DOF_OLD).copy_from(ctx.vector(be.VEC_TMP0))
+    assert np.array_equal(ctx.download(be.VEC_DOF_OLD), x)
+
+
+@pytest.mark.parametrize("name", DECKS)
+def test_internal_force(gpu_ctx_factory, name):
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    u = smooth_disp(inp.nodes, 0.03)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f, sig, F, dsdx, vol = orc.internal_force(topo, u, oracle_material(mat))
+    assert rel(ctx.gauss_field(be.GP_F).to_numpy(), F) < 1e-13
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), sig) < 1e-11
+    assert rel(ctx.download(be.VEC_FORCE), f) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["ellip_membrane_localFine_dirichlet.inp", "twist_plate_C3D4.inp", "ellip_CPS8.inp"])
+def test_dirichlet(gpu_ctx_factory, name):
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    dm = topo.dm
+    Ko = orc.assemble_K(topo, np.zeros(ctx.n), oracle_material(mat).C)
+    rhs0 = np.cos(np.arange(ctx.n) * 0.37)
+    bcs = [dict(b, val=(b["val"] if b["val"] != 0 else 0.125 * (k + 1))) for k, b in enumerate(inp.dirichlet_bc_info)]
+    # linear variant, block by block as the reference does
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RHS, rhs0)
+    for b in bcs:
+        dofs = np.asarray(b["node_set"]) * dm + b["dof"]
+        ctx.dirichlet_linear(dofs, np.full(dofs.size, b["val"]), be.VEC_RHS)
+    K1, rhs1 = orc.dirichlet_linear(Ko, rhs0, bcs, dm)
+    assert abs(ctx.get_K_bsr().tocsr() - K1).max() / abs(Ko).max() < 1e-12
+    assert rel(ctx.download(be.VEC_RHS), rhs1) < 1e-12
+    # Newton variant
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, rhs0)
+    for b in bcs:
+        ctx.dirichlet_newton(np.asarray(b["node_set"]) * dm + b["dof"], be.VEC_RESIDUAL)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in bcs]))
+    K2 = orc._zero_rows_cols_unit_diag(Ko, cons)
+    r2 = rhs0.copy()
+    r2[cons] = 0.0
+    assert abs(ctx.get_K_bsr().tocsr() - K2).max() / abs(Ko).max() < 1e-12
+    assert np.array_equal(ctx.download(be.VEC_RESIDUAL), r2)
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "ellip_membrane_quadritic_trig_neumann.inp",
+                                  "twist_C3D10_coarse.inp"])
+def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
+    """same recurrence, same stopping rule: iteration counts equal and iterates agree."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    dm = ctx.dm
+    ctx.assemble_K(-1)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in inp.dirichlet_bc_info]))
+    b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    K = ctx.get_K_bsr().tocsr()
+    bb = ctx.download(be.VEC_RESIDUAL)
+    for eps, tol in ((1e-3, 1e-6), (1e-10, 1e-6)):   # CG rounding differences grow with cond(K)
+        it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=eps)
+        x = ctx.download(be.VEC_X)
+        xo, ito, r0o, rmaxo = orc.pcg_reference(K, bb, eps=eps)
+        assert r0 == r0o
+        assert abs(it - ito) <= max(1, ito // 100), (it, ito)
+        assert rmax < eps * r0
+        if it == ito:
+            assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < tol
+        assert np.abs(K @ x - bb).max() < 2 * eps * r0 + 1e-9 * r0     # it solves the system
+    # maxit honoured, poll interval irrelevant to the result
+    ctx.set_option(be.OPT_PCG_POLL, 3)
+    it5, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=5)
+    x5 = ctx.download(be.VEC_X)
+    xo5, ito5, _, _ = orc.pcg_reference(K, bb, eps=0.0, maxit=5)
+    assert it5 == 5 and np.linalg.norm(x5 - xo5) / np.linalg.norm(xo5) < 1e-12
+
+
+def test_pcg_single_rank_communicator(gpu_ctx_factory):
+    """the multi-rank exchange path (pack / all-reduce / all-gather) with a 1-rank RCCL communicator."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load("twist_plate_C3D4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in inp.dirichlet_bc_info]))
+    b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    it0, r00, rm0 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+    x0 = ctx.download(be.VEC_X)
+    iface = np.arange(0, ctx.n, 7, dtype=np.int32)          # pretend these DOFs are shared
+    ctx.comm_init(0, 1, be.Context.comm_unique_id(), iface, np.arange(iface.size, dtype=np.int32), iface.size,
+                  np.ones(ctx.n, dtype=np.uint8))
+    it1, r01, rm1 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+    x1 = ctx.download(be.VEC_X)
+    assert it0 == it1 and r00 == r01
+    assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-12
+
+
+def test_errors_are_reported_not_fatal(gpu_ctx_factory):
+    from femcy_amd import backend as be
+    ctx = gpu_ctx_factory()
+    with pytest.raises(be.FemcyError):
+        ctx.assemble_K(-1)                      # nothing defined yet
+    with pytest.raises(be.FemcyError):
+        ctx.set_mesh(np.zeros((3, 3)), np.array([[0, 1, 2, 7]]))    # node id out of range
+    with pytest.raises(be.FemcyError):
+        be.Context(99)
