@@ -1,0 +1,54 @@
+"""entry point, compatible with the reference's main.py (/root/reference/main.py:10-82):
+prompt for an Abaqus .inp file, solve, print displacements.  The Taichi GGUI windows of the
+reference are not available headless; results are printed (and optionally saved with --save).
+
+    python -m femcy_amd.main                 # interactive prompt, as the reference
+    python -m femcy_amd.main path/to/deck.inp [--save result.npz] [--device 0] [--quiet]
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from .body import Body
+from .reader.inp_info import InpInfo
+from .stiffnessMtrx import System_of_equations
+from .tiGadgets import field_abs_max
+
+
+def run(fileName: str, device: int = 0, verbose: bool = True):
+    inp = InpInfo(fileName)
+    nodes, eSets = inp.nodes, inp.eSets
+    body = Body(nodes=nodes, elements=list(eSets.values())[0], ELE=inp.ELE)
+    material = list(inp.materials.values())[0]
+    system = System_of_equations(body, material, inp.geometric_nonlinear, device=device, verbose=verbose)
+    time0 = time.time()
+    system.solve(inp, show_newton_steps=True, save2path=None)
+    system.ctx.sync()
+    time1 = time.time()
+    print(f"\033[40;33;1m system.dof = \n{system.dof.to_numpy()}, "
+          f"time for finite element computing is {time1 - time0} s \033[0m")
+    print(f"\033[40;33;1m max dof (disp) = {field_abs_max(system.dof)} \033[0m")
+    print(f" solver statistics: {system.stats}")
+    return inp, system
+
+
+def main(argv=None):
+    os.system("")
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("inp", nargs="?", default=None)
+    ap.add_argument("--save", default=None, help="write nodes / dof / Cauchy stress to this .npz")
+    ap.add_argument("--device", type=int, default=int(os.environ.get("FEMCY_DEVICE", "0")))
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+    fileName = args.inp or input("\033[32;1m please give the .inp format's input file path and name: \033[0m")
+    inp, system = run(fileName, device=args.device, verbose=not args.quiet)
+    if args.save:
+        np.savez(args.save, nodes=inp.nodes, dof=system.dof.to_numpy(),
+                 cauchy_stress=system.cauchy_stress.to_numpy() if inp.geometric_nonlinear else np.zeros(0))
+        print(f" saved {args.save}")
+
+
+if __name__ == "__main__":
+    main()

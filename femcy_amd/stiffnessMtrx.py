@@ -1,0 +1,305 @@
+"""`System_of_equations`: the host driver of the MI355X solve path, call-compatible with the
+reference class (/root/reference/stiffnessMtrx.py:19-822).
+
+Same constructor, same public attributes (`dof`, `rhs`, `nodal_force`, `residual_nodal_force`,
+`du`, `dof_old`, `F`, `cauchy_stress`, `dsdx`, `vol`, `ELE`, `body`, `dm`, ...) and the same
+control flow for the increment / modified-Newton / line-search drivers (`solve`, `advance_inc`),
+but every kernel is a call into libfemcy_hip.so and every field is a handle to HBM-resident data
+(`.to_numpy()` downloads it).  Nothing numerical runs on the CPU except the consistent Neumann
+loads (a per-facet loop in the reference too, stiffnessMtrx.py:369-411) and the user Dirichlet hook.
+
+Deliberate deviations, all outside the arithmetic of the path:
+  * `solve_dof`: the reference switches to scipy's direct `spsolve` below 1e5 DOF
+    (stiffnessMtrx.py:272-276).  There is no CPU solver in this package: small systems run the
+    same device PCG with a tight tolerance (`direct_eps`, default 1e-12 on max|r|/max|r0|), which
+    reproduces the direct-solve control flow of every shipped deck to ~1e-11; at >= 1e5 DOF the
+    reference's own CG settings (eps = 1e-3) apply.
+  * windows / PNG output are not produced (`show_newton_steps`, `save2path` are accepted and ignored).
+  * the reference raises UnboundLocalError when the very first residual is < 1e-9
+    (`newton_loop` unbound, :767-822); here that case returns (True, 0).
+"""
+import copy
+import time
+from typing import Tuple
+
+import numpy as np
+
+from . import backend as be
+from . import tiGadgets as tg
+from . import user_defined as ud
+from .body import Body
+from .conjugateGradientSolver import ConjugateGradientSolver_rowMajor as CG
+from .fields import HostField
+
+
+class System_of_equations:
+    """K(dof) . du = rhs / residual on one MI355X."""
+
+    def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
+                 direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None):
+        self.dm = body.dm
+        self.geometric_nonlinear = geometric_nonlinear
+        self.body = body
+        self.elements, self.nodes = body.elements, body.nodes
+        self.ELE = body.ELE
+        self.material = material
+        self.C = material.C
+        self.verbose = verbose
+        self.direct_eps, self.cg_eps = direct_eps, cg_eps
+
+        # ---- device state: mesh, element tables, material, sparsity pattern
+        self.ctx = ctx if ctx is not None else be.Context(device)
+        t0 = time.time()
+        self.ctx.set_mesh(body.np_nodes, body.np_elements)
+        self.ctx.set_element(self.ELE)
+        self.ctx.set_material(material)
+        self.pattern = self.ctx.build_pattern()
+        self._say("\033[32;1m pattern: {} DOF, {} blocks of {}x{}, ELL width {} ({:.3f} s) \033[0m".format(
+            self.pattern.n, self.pattern.nnzb, self.dm, self.dm, self.pattern.ell_width, time.time() - t0))
+
+        # ---- the reference's fields, as handles to HBM
+        v = self.ctx.vector
+        self.rhs, self.dof = v(be.VEC_RHS), v(be.VEC_DOF)
+        self.nodal_force, self.residual_nodal_force = v(be.VEC_FORCE), v(be.VEC_RESIDUAL)
+        self.du, self.dof_old = v(be.VEC_DU), v(be.VEC_DOF_OLD)
+        g = self.ctx.gauss_field
+        self.F, self.cauchy_stress = g(be.GP_F), g(be.GP_SIGMA)
+        self.dsdx, self.vol = g(be.GP_DSDX), g(be.GP_VOL)
+        self.sparseMtrx_rowMajor = self          # what the reference hands to the CG class
+        self.sparseIJ = None
+
+        self.time0 = 0.
+        self.time1 = 0.
+        self.dt = 0.
+        self.compiled = False
+        self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0}
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # ----------------------------------------------------------------------------- kernels
+    def get_dsdx_and_vol(self):
+        """geometry is fused into the assembly / internal-force launches (same dof, same result);
+        kept as a method because the reference's drivers call it."""
+
+    def assemble_stiffnessMtrx(self):
+        self.ctx.assemble_K(be.VEC_DOF)
+        self.stats["assemblies"] += 1
+
+    assemble_sparseMtrx = assemble_stiffnessMtrx
+    assemble_stiffnessMtrx_faster = assemble_stiffnessMtrx
+
+    def assemble_nodal_force_GN(self):
+        """F (reference configuration) -> sigma(F) -> current-configuration grad N, vol -> nodal gather."""
+        self.ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        self.stats["force_evals"] += 1
+
+    def get_deformation_gradient(self):
+        self.ctx.internal_force(be.VEC_DOF, be.VEC_TMP0)      # F and sigma are by-products of the element pass
+
+    # ------------------------------------------------------------------------ linear solve
+    def solve_by_CG(self, eps=None):
+        if not hasattr(self, "PCG"):
+            b = self.rhs if not self.geometric_nonlinear else self.residual_nodal_force
+            self.PCG = CG(spm=self.sparseMtrx_rowMajor, sparseIJ=self.sparseIJ, b=b, eps=self.cg_eps)
+        self.PCG.eps = self.cg_eps if eps is None else eps
+        self.PCG.re_init()
+        it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps, maxit=self.PCG.maxit)
+        self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
+        self.stats["linear_solves"] += 1
+        self.stats["cg_iterations"] += it
+        self.du.copy_from(self.PCG.x)
+        if not self.geometric_nonlinear:
+            self.dof.copy_from(self.PCG.x)
+        else:
+            tg.c_equals_a_minus_b(self.dof, self.dof, self.PCG.x)      # Newton: dof -= x
+        return self.du
+
+    def solve_by_scipy(self):
+        """name kept for compatibility: the "direct" branch is a tight device PCG (module docstring)."""
+        return self.solve_by_CG(eps=self.direct_eps)
+
+    def solve_dof(self):
+        if self.dof.shape[0] < 1e5:
+            return self.solve_by_scipy()
+        return self.solve_by_CG()
+
+    # ----------------------------------------------------------------- boundary conditions
+    @staticmethod
+    def _node_ids(nodeSet):
+        return np.asarray(nodeSet.to_numpy() if hasattr(nodeSet, "to_numpy") else nodeSet, dtype=np.int64)
+
+    def dirichletBC_linearEquations(self, nodeSet, dm_specified: int, sval: float):
+        dofs = self._node_ids(nodeSet) * self.dm + dm_specified
+        self.ctx.dirichlet_linear(dofs, np.full(dofs.size, sval), be.VEC_RHS)
+
+    def dirichletBC_forNewtonMethod_kernel(self, nodeSet, dm_specified: int, sval: float):
+        self.ctx.dirichlet_newton(self._node_ids(nodeSet) * self.dm + dm_specified, be.VEC_RESIDUAL)
+
+    def dirichletBC_forNewtonMethod(self, dirichletBCs):
+        for bc in dirichletBCs:
+            self.dirichletBC_dof(bc["node_set"], bc["dof"], bc["val"], bc["user"], self.time1)
+            self.dirichletBC_forNewtonMethod_kernel(nodeSet=bc["node_set"], dm_specified=bc["dof"], sval=bc["val"])
+
+    def dirichletBC_dof(self, nodeSet, dm_specified: int, sval: float, user: bool, time: float):
+        if not user:
+            self.dirichletBC_val(nodeSet, dm_specified, sval)
+        else:
+            ud.user_dirichletBC(self.dof, nodeSet, self.dm, dm_specified, self.nodes, time)
+
+    def dirichletBC_val(self, nodeSet, dm_specified: int, sval: float):
+        dofs = self._node_ids(nodeSet) * self.dm + dm_specified
+        self.ctx.scatter(be.VEC_DOF, dofs, np.full(dofs.size, sval))
+
+    def neumannBC(self, load_facets, load_val: float, load_dir=np.array([])):
+        """consistent nodal loads of a surface traction (dead load on the undeformed geometry).
+        rhs is refreshed on every call, as in the reference (:384)."""
+        body, ELE, dm = self.body, self.ELE, self.dm
+        boundary = body.get_boundary()
+        rhs = np.zeros(self.dof.shape[0])
+        for facet in load_facets:
+            ele = boundary[facet]
+            conn = body.np_elements[ele].tolist()
+            localNodes = body.np_nodes[body.np_elements[ele]]
+            localFacet = [conn.index(i) for i in facet]
+            key = tuple(sorted(localFacet))
+            for integId in range(ELE.integPointNum_eachFacet):
+                normal, area_x_weight = ELE.globalNormal(nodes=localNodes, facet=localFacet, integPointId=integId)
+                direction = normal if len(load_dir) == 0 else np.asarray(load_dir)
+                flux = load_val * direction * area_x_weight
+                shape = ELE.shapeFunc_pyscope(np.asarray(ELE.facet_natural_coos[key][integId], dtype=np.float64))
+                for node0, lid in zip(facet, localFacet):
+                    rhs[node0 * dm:node0 * dm + dm] += flux[:dm] * shape[lid]
+        self.rhs.from_numpy(rhs)
+
+    def impose_boundary_condition(self, boundary_conditions: dict):
+        for nb in boundary_conditions["neumannBCs"]:
+            self.neumannBC(nb["face_set"], load_val=nb["traction"], load_dir=nb.get("direction", np.array([])))
+        for bc in boundary_conditions["dirichletBCs"]:
+            if not self.geometric_nonlinear:
+                self.dirichletBC_linearEquations(bc["node_set"], bc["dof"], bc["val"])
+            else:   # Newton: prescribed values go into dof now, K / residual are treated later
+                self.dirichletBC_dof(bc["node_set"], bc["dof"], bc["val"], bc["user"], self.time1)
+
+    # --------------------------------------------------------------------- time stepping
+    def solve(self, inp, show_newton_steps: bool = False, save2path: str = None):
+        """multiple time increments with automatic cut-back (reference :647-711)."""
+        max_inc, min_inc = inp.time_incs["max_inc"], inp.time_incs["min_inc"]
+        max_time = inp.time_incs["max_time"]
+        self.dt = inp.time_incs["ini_inc"]
+        neumannBCs = copy.deepcopy(inp.neumann_bc_info)
+        dirichletBCs = copy.deepcopy(inp.dirichlet_bc_info)
+        for bc in dirichletBCs:
+            bc["node_set"] = HostField(np.array([*bc["node_set"]]), dtype=np.int32)
+        boundary_conditions = {"neumannBCs": neumannBCs, "dirichletBCs": dirichletBCs}
+        self.increments = []
+        kinc = -1
+        while self.time1 < max_time:
+            kinc += 1
+            self.time1 = min(self.time0 + self.dt, max_time)
+            self._say("\033[40;33;1m >>>>> kinc = {}, time0 = {}, dt = {} \033[0m".format(kinc, self.time0, self.dt))
+            load_ratio = self.time1 / max_time
+            for i, nb in enumerate(neumannBCs):
+                nb["traction"] = inp.neumann_bc_info[i]["traction"] * load_ratio
+            for i, bc in enumerate(dirichletBCs):
+                bc["val"] = inp.dirichlet_bc_info[i]["val"] * load_ratio
+            converged, newton_loop = self.advance_inc(inp, boundary_conditions, show_newton_steps, save2path)
+            self.increments.append({"kinc": kinc, "time1": self.time1, "dt": self.dt, "converged": converged,
+                                    "newton_loop": newton_loop})
+            if not converged:
+                self.time1 = self.time0
+                self.dt /= 4.
+                self.dof.copy_from(self.dof_old)
+                kinc -= 1
+                if self.dt < min_inc:
+                    print("\033[31;1m allowable minimum dt is reached, "
+                          "Newton's method not converges, solution is not found. \033[0m")
+                    break
+                continue
+            if newton_loop <= 8:
+                self.dt = min(self.dt * 1.5, max_inc)
+            self.dof_old.copy_from(self.dof)
+            self.time0 = self.time1
+
+    def _residual(self, dirichletBCs):
+        """nodal force + K at the current dof, residual = f_int - rhs, Newton Dirichlet treatment,
+        RMS norm (the block the reference repeats at :756-759, :779-783 and in inside_relaxation)."""
+        self.assemble_nodal_force_GN()
+        self.assemble_stiffnessMtrx()
+        tg.c_equals_a_minus_b(self.residual_nodal_force, self.nodal_force, self.rhs)
+        self.dirichletBC_forNewtonMethod(dirichletBCs)
+        return tg.field_norm(self.residual_nodal_force)
+
+    def advance_inc(self, inp, boundary_conditions: dict, show_newton_steps: bool = False, save2path: str = None,
+                    window=None) -> Tuple[bool, int]:
+        """one time increment: linear solve, or modified Newton with the reference's "boost" and
+        "damp" line searches (reference :714-822)."""
+        t0 = time.time()
+        self.get_dsdx_and_vol()
+        self.assemble_stiffnessMtrx()
+        if not self.compiled:
+            self.compiled = True
+            self.ctx.sync()
+            self._say("\033[35;1m first assembly took {:.4f} s\033[0m".format(time.time() - t0))
+        self.impose_boundary_condition(boundary_conditions)
+
+        if not inp.geometric_nonlinear:
+            self.solve_dof()
+            return True, 0
+
+        dirichletBCs = boundary_conditions["dirichletBCs"]
+        pre_residual = self._residual(dirichletBCs)
+        if not hasattr(self, "ini_residual"):
+            self.ini_residual = pre_residual          # latched once for the whole run
+        self._say("\033[40;33;1m initial residual_nodal_force = {} \033[0m".format(self.ini_residual))
+        if self.ini_residual < 1.e-9:
+            return True, 0
+
+        newton_loop = -1
+        while pre_residual / (self.ini_residual + 1.e-30) >= 0.01:
+            newton_loop += 1
+            if newton_loop >= 24:
+                return False, newton_loop
+            du = self.solve_dof()                     # dof -= K^-1 residual
+            residual = self._residual(dirichletBCs)
+            if np.isnan(residual):
+                self._say("NaN occurs, automatically recompute with smaller time step")
+                return False, newton_loop
+            self._say("\033[40;33;1m newton_loop = {}, residual_nodal_force = {} \033[0m".format(newton_loop, residual))
+
+            # boost: keep going along du while the residual declines (but not by 10x)
+            relax_loop, relaxation = -1, 1.
+            while 0.1 * pre_residual < residual < pre_residual:
+                new_residual = residual
+                relax_loop += 1
+                if relax_loop >= 10:
+                    break
+                tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, -relaxation, du)
+                residual = self._residual(dirichletBCs)
+                if residual > new_residual:
+                    tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, +relaxation, du)
+                    residual = self._residual(dirichletBCs)
+                    relaxation *= 0.5
+
+            # damp: the residual grew -> take back half of the step (at most twice)
+            relax_loop, relaxation = -1, 0.5
+            while residual > pre_residual:
+                relax_loop += 1
+                if relax_loop >= 2:
+                    break
+                tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, (1. - relaxation), du)
+                tg.field_multiply(du, relaxation)
+                residual = self._residual(dirichletBCs)
+
+            pre_residual = residual
+        return True, newton_loop
+
+    # -------------------------------------------------------------------- post-processing
+    def compute_strain_stress(self):
+        raise NotImplementedError("device post-processing (strain / stress / Mises) is SURVEY.md 8(f) 'next'; "
+                                  "F and the Cauchy stress of the last force evaluation are available as "
+                                  "system.F.to_numpy() / system.cauchy_stress.to_numpy()")
+
+    def get_elasEng(self):
+        raise NotImplementedError("elastic energy is SURVEY.md 8(f) 'next'")

@@ -1,0 +1,67 @@
+"""Generate the committed golden vectors under tests/golden/ from the CPU oracle.
+
+The reference itself cannot run here (Taichi is not installable), so these are NOT
+outputs of the reference: they are outputs of the oracle restatement, which is pinned against the
+reference's published known answers (tests/test_oracle_pins.py).  They freeze the oracle's results
+so that (a) the -m gpu suite can compare the HIP path without re-running 40 s Newton solves on the
+CPU and (b) any later change to the oracle that moves a result is caught by the CPU suite.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+from helpers import deck, oracle_system_from_inp, oracle_material  # noqa: E402
+from femcy_amd.reader import InpInfo  # noqa: E402
+from oracle import femcy_oracle as orc  # noqa: E402
+from oracle.elements import elem_def  # noqa: E402
+
+SOLVE_DECKS = [
+    "ellip_membrane_linEle_localVeryFine.inp", "ellip_membrane_quadritic_trig_neumann.inp", "ellip_CPS4.inp",
+    "ellip_CPS8.inp", "ellip_membrane_3d_linearEl.inp", "ellip_membrane_3d.inp",
+    "ellip_membrane_localFine_dirichlet.inp", "ellip_localVeryFine_directional_force.inp",
+    "cookMembrane_2d_linearEl_smallDef.inp", "beam_CPS3_disp_meshSize5.inp", "cook_3d_linearEl_largeDef.inp",
+    "beamDeflec_quadPSE_largeD_load800.inp", "twist_plate_C3D4.inp", "twist_C3D10_coarse.inp",
+    "cookMembrane_2d_linearEl_largeDef.inp",
+]
+
+
+def main():
+    out = {}
+    for name in SOLVE_DECKS:
+        inp = InpInfo(deck(name))
+        s = oracle_system_from_inp(inp)
+        t = time.time()
+        u = s.solve(inp.time_incs, inp.dirichlet_bc_info, inp.neumann_bc_info)
+        key = name[:-4]
+        out[key + "/dof"] = u
+        out[key + "/meta"] = np.array([len(s.increments), s.n_solves, s.n_assemblies,
+                                       getattr(s, "ini_residual", 0.0)], dtype=np.float64)
+        print(f"{name}: |u|={np.linalg.norm(u):.10g} incs={len(s.increments)} solves={s.n_solves} "
+              f"({time.time()-t:.1f}s)")
+    np.savez_compressed(os.path.join(HERE, "oracle_solutions.npz"), **out)
+
+    # element-level vectors: one Ke per element type (first element of a deck, u = 0)
+    ke = {}
+    for name in ["ellip_membrane_linEle_localVeryFine.inp", "ellip_CPS4.inp",
+                 "ellip_membrane_quadritic_trig_neumann.inp", "ellip_CPS8.inp", "twist_plate_C3D4.inp",
+                 "twist_C3D10_coarse.inp"]:
+        inp = InpInfo(deck(name))
+        et = list(inp.eSets)[0]
+        el = inp.eSets[et][:1]
+        ed = elem_def(et)
+        mat = oracle_material(list(inp.materials.values())[0])
+        dsdx, vol = orc.dsdx_and_vol(inp.nodes, el, np.zeros(inp.nodes.size), ed)
+        ke[et] = orc.element_stiffness(dsdx, vol, mat.C)[0]
+        ke[et + "/dsdx"] = dsdx[0]
+        ke[et + "/vol"] = vol[0]
+    np.savez_compressed(os.path.join(HERE, "oracle_element_vectors.npz"), **ke)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""-m gpu: whole decks through `System_of_equations.solve` (host driver + C ABI + HIP kernels)
+against the committed golden displacements of the oracle.  north_star tolerance: <= 1e-6 relative L2
+on the nodal displacements, with the same increment / Newton control flow."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, deck
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (deck, tolerance)
+    ("ellip_membrane_linEle_localVeryFine", 1e-6),        # BASELINE config 1 (plumbing): linear CPS3
+    ("ellip_membrane_quadritic_trig_neumann", 1e-6),      # CPS6
+    ("ellip_CPS4", 1e-6), ("ellip_CPS8", 1e-6),
+    ("ellip_membrane_3d_linearEl", 1e-6), ("ellip_membrane_3d", 1e-6),          # C3D4 / C3D10 linear
+    ("ellip_membrane_localFine_dirichlet", 1e-6),         # non-zero Dirichlet values, 4 increments
+    ("ellip_localVeryFine_directional_force", 1e-6),      # TRVEC load
+    ("cookMembrane_2d_linearEl_smallDef", 1e-6),          # CPE3 plane strain
+    ("beam_CPS3_disp_meshSize5", 1e-6),                   # CPS3 large deformation (StVK), 43 Newton solves
+    ("cook_3d_linearEl_largeDef", 1e-6),                  # C3D4 Neo-Hookean large deformation
+    ("beamDeflec_quadPSE_largeD_load800", 1e-6),          # CPS6 large deformation, traction load
+    ("twist_plate_C3D4", 1e-6),                           # 180 degree twist, user Dirichlet BC, 186 solves
+]
+
+
+def run(name):
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    inp = InpInfo(deck(name + ".inp"))
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    system.solve(inp)
+    u = system.dof.to_numpy()
+    system.ctx.close()
+    return system, u
+
+
+@pytest.mark.parametrize("name,tol", CASES)
+def test_deck_displacements(name, tol):
+    g = np.load(os.path.join(GOLDEN, "oracle_solutions.npz"))
+    system, u = run(name)
+    ref = g[name + "/dof"]
+    err = np.linalg.norm(u - ref) / np.linalg.norm(ref)
+    print(f"{name}: rel L2 = {err:.3e}, stats = {system.stats}, increments = {len(system.increments)}")
+    assert err <= tol
+    incs, solves = g[name + "/meta"][:2]
+    assert len(system.increments) == incs and system.stats["linear_solves"] == solves
+
+
+def test_twist_prescribed_rotation():
+    system, u = run("twist_plate_C3D4")
+    assert abs(np.abs(u).max() - 80.0) < 1e-9               # 180 degrees about (40, 5): max |u| = plate width
