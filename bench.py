@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's headline metric on MI355X:
+    "CG iters/sec + element-stiffness assemblies/sec, 1M C3D4 elems, 1/2/4/8 GPU".
+
+One *step* = one pass of the hot path over the synthetic twist plate at state S1 (prescribed twist
+of t = 0.05 on the z=0 face), exactly what one residual evaluation + linear solve of
+the reference's Newton loop does on the device:
+    femcy_assemble_K            get_dsdx_and_vol + assemble_stiffnessMtrx   (995 328 C3D4 per GPU)
+    femcy_apply_dirichlet_newton  0/1 treatment of K, residual rows zeroed
+    femcy_pcg(eps=0, maxit=ITERS) ITERS Jacobi-PCG iterations, reference recurrence + stopping test
+All inputs are resident in HBM when the timed region starts.  N GPUs: the plate is cut into N z-slabs
+of 995 328 elements each (weak scaling; N=1 is BASELINE's 1M mesh k=12, N=8 is its 8M mesh k=24) with
+one RCCL interface all-reduce + one all-gather per CG iteration.
+
+`value` = CG iterations of all steps / wall time of the whole timed region (assembly included), times
+global_elements/995328 (= N) so that it is a whole-job aggregate; `cg_iters_per_s` (PCG only) and
+`assemblies_per_s` (elements/s, geometry + assembly kernels) come from HIP events on the ctx stream.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--iters ITERS] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
+ELEMS_PER_GPU = 995328
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=500, help="PCG iterations per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from femcy_amd import backend as be, meshgen, partition
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit(f"--gpus {N} needs {N} ranks: launch with python -m torch.distributed.run "
+                             f"--nnodes=1 --nproc-per-node {N} --master-addr 127.0.0.1 bench.py --gpus {N}")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {N}")
+    torch.cuda.set_device(local_rank)
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ problem (deterministic)
+    t0 = time.time()
+    nx, ny, nz = (tuple(int(v) for v in args.cells.split(",")) if args.cells else meshgen.scaling_cells(N))
+    mesh = meshgen.twist_plate(nx, ny, nz)
+    nodes_g, el_g = mesh["nodes"], mesh["elements"]
+    ne_global, n_global = el_g.shape[0], nodes_g.size
+    if N > 1:
+        part = partition.build_part(nodes_g, el_g, N, rank)
+        nodes, el = part.nodes, part.elements
+        localize = part.localize_nodes
+    else:
+        part, nodes, el = None, nodes_g, el_g
+        localize = lambda ids: np.asarray(ids, dtype=np.int64)
+    ctx = be.Context(local_rank)
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(Element_linear_tetrahedral())
+    ctx.set_material(LinearIsotropic(*mesh["elastic"]))
+    info = ctx.build_pattern()
+    if N > 1:
+        uid = [be.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
+    n, ne = ctx.n, ctx.ne
+    if rank == 0:
+        log(f"[bench] cells {nx}x{ny}x{nz}: {ne_global} elements / {n_global} DOF global, {ne} elements / {n} DOF "
+            f"per rank, nnzb {info.nnzb}, setup {time.time()-t0:.1f}s")
+
+    # state S1: prescribed values of the first increment (t = 0.05) written into dof, zero elsewhere
+    u = np.zeros(n)
+    cons = []
+    for bc in mesh["dirichlet_bc_info"]:
+        ids = localize(bc["node_set"])
+        cons.append(ids * 3 + bc["dof"])
+        if bc["user"] and ids.size:
+            user_dirichletBC_values(u, ids, 3, bc["dof"], nodes, 0.05)
+    cons = np.unique(np.concatenate(cons)).astype(np.int32)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    if N > 1:
+        ctx.iface_sum(be.VEC_FORCE)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)           # Newton residual = f_int - rhs
+
+    def step():
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
+
+    ctx.set_option(be.OPT_TIMING, 1)
+    for _ in range(args.warmup):
+        step()
+    ctx.timing_reset()
+
+    barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    total_iters = 0
+    for _ in range(args.steps):
+        it, r0, rmax = step()
+        total_iters += it
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if N > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = ctx.timing()
+    ctx.set_option(be.OPT_TIMING, 0)
+
+    # ------------------------------------------------------------------ roofline of the dominant kernel
+    # algorithmic bytes of one SpMV: 8*nnz + 4*nnz/dm^2 + 4*(nn+1) + 16*n, padding never counted
+    spmv_bytes = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * n
+    spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
+    achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9 if spmv_us > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    cg_only = total_iters / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0
+    asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
+    scale = ne_global / ELEMS_PER_GPU
+
+    result = {
+        "metric": "CG iters/sec + element-stiffness assemblies/sec, 1M C3D4 elems, 1/2/4/8 GPU",
+        "value": total_iters / elapsed * scale,
+        "unit": "CG iters/s x (global elements / 995328)",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"twist plate C3D4 {nx}x{ny}x{nz} cells, {ne_global} elements, {n_global} DOF "
+                               f"(BASELINE configs[2] at N=1, configs[3] at N=8), state S1 (t=0.05), "
+                               f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
+                   "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters,
+                   "parallelism": f"element z-slabs x{N}" if N > 1 else "single GPU"},
+        "cg_iters_per_s": cg_only * scale,
+        "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
+        "assembly_ms": asm_ms,
+        "pcg_us_per_iter": tm["pcg_ms"] * 1e3 / max(total_iters, 1),
+        "roofline": {"kernel": "k_spmv<3> (compute_Ad)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us,
+                     "launches_timed": int(tm["spmv_launches"]),
+                     "pcg_iteration_gbs": (spmv_bytes + 88 * n) * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9
+                     if tm["pcg_ms"] > 0 else 0.0},
+    }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(nodes, el, mesh, u, cons)
+        except Exception as e:   # the checker must never take the GPU number down with it
+            log(f"[bench] cpu_baseline failed: {e!r}")
+            result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if N > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(nodes, el, mesh, u, cons):
+    """oracle/femcy_oracle.c (the reference's algorithm as written: ELL n x W, per-entry linear search +
+    atomic adds, thread-per-row SpMV, 8 vector passes + 4 reductions per CG iteration) with OpenMP on all
+    host cores, on a bounded sample of the same workload: 1 assembly + ~10 s of CG iterations."""
+    from oracle.c_oracle import COracle
+    from oracle.elements import elem_def
+    from oracle.femcy_oracle import Material
+    ed = elem_def("C3D4")
+    t0 = time.time()
+    co = COracle(nodes, el, ed.dN_table(), ed.gauss_weights, Material("lin3d", mesh["elastic"]).C)
+    setup = time.time() - t0
+    co.get_dsdx_and_vol(u)
+    co.assemble()                                    # warm (page faults of the 200 MB ELL array)
+    t = time.perf_counter()
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    t_asm = time.perf_counter() - t
+    co.zero_rows_cols_unit_diag(cons)
+    f = co.internal_force(u, 0, *mesh["elastic"])
+    f[cons] = 0.0
+    co.cg(f, eps=0.0, maxit=3)
+    t = time.perf_counter()
+    co.cg(f, eps=0.0, maxit=10)
+    per_it = (time.perf_counter() - t) / 10
+    its = int(max(20, min(2000, 10.0 / per_it)))
+    t = time.perf_counter()
+    _, it, _, _ = co.cg(f, eps=0.0, maxit=its)
+    dt = time.perf_counter() - t
+    return {"value": it / dt, "unit": "CG iters/s", "cores": co.threads(), "kind": "port",
+            "assemblies_per_s": co.ne / t_asm, "assembly_ms": t_asm * 1e3,
+            "sample": f"same 1M-element mesh and state: 1 as-written assembly ({t_asm:.2f} s) + {it} CG iterations "
+                      f"({dt:.1f} s) of oracle/femcy_oracle.c, OpenMP x{co.threads()} threads; setup {setup:.0f} s untimed"}
+
+
+if __name__ == "__main__":
+    main()

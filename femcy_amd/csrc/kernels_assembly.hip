@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
                                                         const int64_t* __restrict__ slice_off,
                                                         const int32_t* __restrict__ rowlen,
                                                         const int32_t* __restrict__ bcol, double* __restrict__ Kvals,
-                                                        double* __restrict__ resid) {
+                                                        double* __restrict__ resid,
+                                                        const uint8_t* __restrict__ owner) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)k * maxL) return;
     const int32_t q = (int32_t)(t / maxL), j = (int32_t)(t % maxL);
@@ -437,7 +438,8 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
         for (int cc = 0; cc < DM; ++cc) Kvals[(rowb * (DM * DM) + cc * DM + r) * SLICE + laneb] = 0.0;
     }
     if (j == 0) {
-        Kvals[(rowa * (DM * DM) + r * DM + r) * SLICE + lanea] = 1.0;
+        // multi-rank: K is sub-assembled, so only the owning rank contributes the unit diagonal
+        Kvals[(rowa * (DM * DM) + r * DM + r) * SLICE + lanea] = owner ? (double)owner[dof] : 1.0;
         if (resid) resid[dof] = 0.0;
     }
 }
@@ -527,12 +529,13 @@ int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_re
     const int bs = 256;
     const int64_t total = (int64_t)k * c->max_row_blocks;
     const int grid = (int)((total + bs - 1) / bs);
+    const uint8_t* owner = c->comm ? c->d_owner : nullptr;
     if (c->dm == 3)
         hipLaunchKernelGGL((k_dirichlet_zero<3>), dim3(grid), dim3(bs), 0, c->stream, k, c->max_row_blocks, d_dofs,
-                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid);
+                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid, owner);
     else
         hipLaunchKernelGGL((k_dirichlet_zero<2>), dim3(grid), dim3(bs), 0, c->stream, k, c->max_row_blocks, d_dofs,
-                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid);
+                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid, owner);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }

@@ -1,0 +1,111 @@
+"""Element partition of a mesh over the GPUs of one node (new work: the reference is single-device).
+
+The mesh is cut into `nranks` slabs of (nearly) equal element count along one axis (z, the long
+axis of the twist plate: 144 or 288 cell layers, <= 2 neighbours per rank).  Each rank owns its
+elements and keeps every node they touch; nodes on a cut are replicated.  The rank-local stiffness
+matrix is sub-assembled (interface rows hold partial sums), so per CG iteration the interface
+entries of y = K_loc d are summed across ranks through one packed "global interface vector"
+all-reduce; dot products count every shared DOF once through the `owner` mask (lowest sharing rank).
+
+`Part` carries exactly what femcy_comm_init() needs:
+  iface_local_dofs[k]   local scalar DOF that is entry iface_global_slot[k] of the packed vector
+  niface_global         length of the packed vector (all cuts, all ranks)
+  owner[i]              1 if this rank counts local DOF i in reductions
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+
+@dataclass
+class Part:
+    rank: int
+    nranks: int
+    elem_ids: np.ndarray           # global element ids owned by this rank
+    l2g: np.ndarray                # local node -> global node (ascending)
+    nodes: np.ndarray              # local coordinates
+    elements: np.ndarray           # local connectivity (int32)
+    iface_local_dofs: np.ndarray   # int32
+    iface_global_slot: np.ndarray  # int32
+    niface_global: int
+    owner: np.ndarray              # uint8[n_local]
+    dm: int
+
+    @property
+    def n_local(self):
+        return self.nodes.shape[0] * self.dm
+
+    def localize_nodes(self, global_node_ids) -> np.ndarray:
+        """global node ids -> local ids, dropping nodes this rank does not hold."""
+        g = np.asarray(global_node_ids, dtype=np.int64)
+        pos = np.searchsorted(self.l2g, g)
+        pos = np.clip(pos, 0, self.l2g.size - 1)
+        return pos[self.l2g[pos] == g]
+
+    def scatter_global(self, v_global: np.ndarray) -> np.ndarray:
+        """restrict a global DOF vector to this rank's nodes."""
+        return v_global.reshape(-1, self.dm)[self.l2g].ravel()
+
+
+def element_ranks(nodes: np.ndarray, elements: np.ndarray, nranks: int, axis: int = 2) -> np.ndarray:
+    """rank of every element: equal-count slabs ordered by centroid coordinate along `axis`
+    (stable, so structured meshes split exactly on cell layers)."""
+    ne = elements.shape[0]
+    cen = nodes[elements[:, :4] if elements.shape[1] > 4 else elements][:, :, axis].mean(axis=1)
+    order = np.argsort(np.round(cen, 9), kind="stable")
+    rank_of = np.empty(ne, dtype=np.int32)
+    rank_of[order] = (np.arange(ne, dtype=np.int64) * nranks // ne).astype(np.int32)
+    return rank_of
+
+
+def _sharing(elements: np.ndarray, rank_of: np.ndarray, nn: int, nranks: int):
+    """boolean [nn, nranks]: node touched by rank."""
+    touched = np.zeros((nn, nranks), dtype=bool)
+    touched[elements.ravel(), np.repeat(rank_of, elements.shape[1])] = True
+    return touched
+
+
+def build_part(nodes: np.ndarray, elements: np.ndarray, nranks: int, rank: int, axis: int = 2,
+               rank_of: np.ndarray = None) -> Part:
+    nn, dm = nodes.shape
+    elements = np.asarray(elements)
+    if rank_of is None:
+        rank_of = element_ranks(nodes, elements, nranks, axis)
+    touched = _sharing(elements, rank_of, nn, nranks)
+    mult = touched.sum(axis=1)
+    iface_nodes = np.nonzero(mult >= 2)[0]                       # global ids, ascending -> slot order
+    slot_of_node = np.full(nn, -1, dtype=np.int64)
+    slot_of_node[iface_nodes] = np.arange(iface_nodes.size)
+    owner_rank = np.argmax(touched, axis=1)                      # lowest rank touching the node
+
+    mine = np.nonzero(rank_of == rank)[0]
+    l2g = np.nonzero(touched[:, rank])[0]
+    g2l = np.full(nn, -1, dtype=np.int64)
+    g2l[l2g] = np.arange(l2g.size)
+    loc_el = g2l[elements[mine]].astype(np.int32)
+    loc_iface = np.nonzero(slot_of_node[l2g] >= 0)[0]            # local node ids on a cut
+    comp = np.arange(dm)
+    iface_local_dofs = (loc_iface[:, None] * dm + comp[None, :]).ravel().astype(np.int32)
+    iface_global_slot = (slot_of_node[l2g[loc_iface]][:, None] * dm + comp[None, :]).ravel().astype(np.int32)
+    owner = np.repeat((owner_rank[l2g] == rank).astype(np.uint8), dm)
+    return Part(rank=rank, nranks=nranks, elem_ids=mine, l2g=l2g, nodes=np.ascontiguousarray(nodes[l2g]),
+                elements=loc_el, iface_local_dofs=iface_local_dofs, iface_global_slot=iface_global_slot,
+                niface_global=int(iface_nodes.size * dm), owner=owner, dm=dm)
+
+
+def build_all_parts(nodes, elements, nranks, axis=2) -> List[Part]:
+    rank_of = element_ranks(nodes, elements, nranks, axis)
+    return [build_part(nodes, elements, nranks, r, axis, rank_of) for r in range(nranks)]
+
+
+def gather_owned(parts: List[Part], local_vectors: List[np.ndarray], n_global: int) -> np.ndarray:
+    """assemble a global vector from per-rank vectors, taking each shared DOF from its owner."""
+    out = np.zeros(n_global)
+    for p, v in zip(parts, local_vectors):
+        gd = (p.l2g[:, None] * p.dm + np.arange(p.dm)[None, :]).ravel()
+        sel = p.owner.astype(bool)
+        out[gd[sel]] = np.asarray(v)[sel]
+    return out

@@ -1,0 +1,125 @@
+"""CPU suite: the N>1 path.  Partition invariants in-process, and a world_size-2 gloo run of the
+distributed PCG mirror (tests/dist_reference.py) against the single-rank oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from femcy_amd import meshgen, partition
+from oracle import femcy_oracle as orc
+from oracle.elements import elem_def
+
+
+def small_problem():
+    m = meshgen.twist_plate(4, 2, 6)
+    ed = elem_def("C3D4")
+    mat = orc.Material("lin3d", m["elastic"])
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in m["dirichlet_bc_info"]]))
+    return m, ed, mat, cons
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_partition_invariants(nranks):
+    m, ed, mat, cons = small_problem()
+    nodes, el = m["nodes"], m["elements"]
+    parts = partition.build_all_parts(nodes, el, nranks)
+    assert sorted(np.concatenate([p.elem_ids for p in parts]).tolist()) == list(range(el.shape[0]))
+    sizes = [p.elem_ids.size for p in parts]
+    assert max(sizes) - min(sizes) <= 1
+    n = nodes.size
+    owners = np.zeros(n, dtype=int)
+    slot_to_gdof = {}
+    for p in parts:
+        assert np.array_equal(nodes[p.l2g], p.nodes)
+        assert np.array_equal(p.l2g[p.elements], el[p.elem_ids])
+        gd = (p.l2g[:, None] * 3 + np.arange(3)).ravel()
+        owners[gd] += p.owner
+        for ld, sl in zip(p.iface_local_dofs, p.iface_global_slot):
+            assert slot_to_gdof.setdefault(int(sl), int(gd[ld])) == int(gd[ld])     # same slot <-> same global DOF
+        assert p.niface_global == parts[0].niface_global
+    assert (owners == 1).all()                                   # every DOF counted exactly once
+    assert len(slot_to_gdof) == parts[0].niface_global
+    # sub-assembly identity: sum_r R_r^T K_r R_r = K
+    K = orc.assemble_K(orc.Topology(nodes, el, ed), np.zeros(n), mat.C)
+    acc = sp.csr_matrix((n, n))
+    for p in parts:
+        Kl = orc.assemble_K(orc.Topology(p.nodes, p.elements, ed), np.zeros(p.n_local), mat.C).tocoo()
+        gd = (p.l2g[:, None] * 3 + np.arange(3)).ravel()
+        acc = acc + sp.coo_matrix((Kl.data, (gd[Kl.row], gd[Kl.col])), shape=(n, n)).tocsr()
+    assert abs(acc - K).max() < 1e-12 * abs(K).max()
+    # slab partition of the structured plate cuts on cell layers: <= 2 neighbours per rank
+    for p in parts if 6 % nranks == 0 else []:
+        zs = np.unique(np.round(p.nodes[p.iface_local_dofs[::3] // 3][:, 2], 6))
+        assert zs.size <= 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from dist_reference import distributed_pcg, iface_sum
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, ed, mat, cons = small_problem()
+        nodes, el = m["nodes"], m["elements"]
+        part = partition.build_part(nodes, el, world, rank)
+        topo = orc.Topology(part.nodes, part.elements, ed)
+        # state S1 of the benchmark: prescribed twist at t = 0.05, residual = f_int with Dirichlet rows zeroed
+        u = np.zeros(nodes.size)
+        for b in m["dirichlet_bc_info"]:
+            if b["user"]:
+                orc.user_dirichletBC(u, np.asarray(b["node_set"]), 3, b["dof"], nodes, 0.05)
+        ul = part.scatter_global(u)
+        f_loc = iface_sum(part, orc.internal_force(topo, ul, mat)[0])          # consistent after the interface sum
+        K_loc = orc.assemble_K(topo, ul, mat.C)
+        gd = (part.l2g[:, None] * 3 + np.arange(3)).ravel()
+        is_cons = np.isin(gd, cons)
+        lc = np.nonzero(is_cons)[0]
+        K_loc = orc._zero_rows_cols_unit_diag(K_loc, lc).tolil()
+        for i in lc:                                                           # unit diagonal from the owner only
+            K_loc[i, i] = float(part.owner[i])
+        K_loc = K_loc.tocsr()
+        f_loc[lc] = 0.0
+        x, it, r0, rmax = distributed_pcg(part, K_loc, f_loc, eps=1e-9)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, it=it, r0=r0, rmax=rmax, f=f_loc)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_pcg_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m, ed, mat, cons = small_problem()
+    nodes, el = m["nodes"], m["elements"]
+    n = nodes.size
+    topo = orc.Topology(nodes, el, ed)
+    u = np.zeros(n)
+    for b in m["dirichlet_bc_info"]:
+        if b["user"]:
+            orc.user_dirichletBC(u, np.asarray(b["node_set"]), 3, b["dof"], nodes, 0.05)
+    f = orc.internal_force(topo, u, mat)[0]
+    K = orc._zero_rows_cols_unit_diag(orc.assemble_K(topo, u, mat.C), cons)
+    f[cons] = 0.0
+    xo, ito, r0o, rmaxo = orc.pcg_reference(K, f, eps=1e-9)
+    parts = partition.build_all_parts(nodes, el, world)
+    res = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    assert np.abs(partition.gather_owned(parts, [r["f"] for r in res], n) - f).max() < 1e-9 * np.abs(f).max()
+    assert all(int(r["it"]) == int(res[0]["it"]) for r in res)
+    assert abs(int(res[0]["it"]) - ito) <= max(2, ito // 50)      # summation order differs (sub-assembly)
+    assert abs(float(res[0]["r0"]) - r0o) < 1e-9 * r0o
+    x = partition.gather_owned(parts, [r["x"] for r in res], n)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-5
+    # replicated interface values agree across ranks
+    for p, r in zip(parts, res):
+        gd = (p.l2g[:, None] * 3 + np.arange(3)).ravel()
+        assert np.abs(r["x"] - x[gd]).max() < 1e-9 * np.abs(x).max()
