@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--iters", type=int, default=500, help="PCG iterations per step")
+    ap.add_argument("--sample", type=int, default=16, help="time every k-th SpMV launch with HIP events (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
     args = ap.parse_args()
 
@@ -78,7 +80,8 @@ def main():
     mesh = meshgen.twist_plate(nx, ny, nz)
     nodes_g, el_g = mesh["nodes"], mesh["elements"]
     ne_global, n_global = el_g.shape[0], nodes_g.size
-    if N > 1:
+    use_comm = N > 1 or args.force_comm
+    if use_comm:
         part = partition.build_part(nodes_g, el_g, N, rank)
         nodes, el = part.nodes, part.elements
         localize = part.localize_nodes
@@ -90,9 +93,10 @@ def main():
     ctx.set_element(Element_linear_tetrahedral())
     ctx.set_material(LinearIsotropic(*mesh["elastic"]))
     info = ctx.build_pattern()
-    if N > 1:
+    if use_comm:
         uid = [be.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if N > 1:
+            dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
     n, ne = ctx.n, ctx.ne
     if rank == 0:
@@ -111,7 +115,7 @@ def main():
     ctx.upload(be.VEC_DOF, u)
     ctx.vector(be.VEC_RHS).fill(0.0)
     ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
-    if N > 1:
+    if use_comm:
         ctx.iface_sum(be.VEC_FORCE)
     ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)           # Newton residual = f_int - rhs
 
@@ -120,7 +124,7 @@ def main():
         ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
         return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
 
-    ctx.set_option(be.OPT_TIMING, 1)
+    ctx.set_option(be.OPT_TIMING, args.sample)    # HIP events on the ctx stream; every k-th SpMV launch is sampled
     for _ in range(args.warmup):
         step()
     ctx.timing_reset()

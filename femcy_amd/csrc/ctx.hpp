@@ -100,7 +100,8 @@ struct Ctx {
     // ---- options / timing
     int opt_assembly = FEMCY_ASM_GATHER;
     int opt_poll = 32;
-    int opt_timing = 0;
+    int opt_timing = 0;               // 0 off, 1 every launch, k > 1: every k-th SpMV launch
+    int64_t spmv_count = 0;
     int opt_spmv_variant = 0;
     femcy_timing_t timing{};
     std::vector<EventPair> ev_pool;
@@ -122,6 +123,7 @@ struct Ctx {
 // timing classes
 enum { T_GEOM = 0, T_ASM = 1, T_FORCE = 2, T_SPMV = 3, T_PCG = 4 };
 size_t timing_begin(Ctx* c, int cls);
+EventPair* timing_acquire(Ctx* c, int cls);   // registers a pair without recording (hipExtLaunchKernel fills it)
 void timing_end(Ctx* c, size_t h);
 void timing_collect(Ctx* c);
 

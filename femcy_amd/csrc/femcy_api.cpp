@@ -51,7 +51,7 @@ int ensure_scratch(Ctx* c, int64_t k) {
 }
 
 // ------------------------------------------------------------------------------------- timing
-size_t timing_begin(Ctx* c, int cls) {
+static size_t timing_slot(Ctx* c, int cls) {
     if (!c->opt_timing) return (size_t)-1;
     if (c->ev_next >= c->ev_pool.size()) {
         EventPair p;
@@ -59,9 +59,17 @@ size_t timing_begin(Ctx* c, int cls) {
         c->ev_pool.push_back(p);
     }
     size_t h = c->ev_next++;
-    (void)hipEventRecord(c->ev_pool[h].a, c->stream);
     c->ev_pending.push_back({cls, h});
     return h;
+}
+size_t timing_begin(Ctx* c, int cls) {
+    size_t h = timing_slot(c, cls);
+    if (h != (size_t)-1) (void)hipEventRecord(c->ev_pool[h].a, c->stream);
+    return h;
+}
+EventPair* timing_acquire(Ctx* c, int cls) {
+    size_t h = timing_slot(c, cls);
+    return h == (size_t)-1 ? nullptr : &c->ev_pool[h];
 }
 void timing_end(Ctx* c, size_t h) {
     if (h == (size_t)-1) return;
@@ -207,7 +215,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             break;
         case FEMCY_OPT_TIMING:
             if (!value) timing_collect(c);
-            c->opt_timing = value ? 1 : 0;
+            c->opt_timing = value < 0 ? 0 : (int)value;
             break;
         case FEMCY_OPT_SPMV_VARIANT:
             c->opt_spmv_variant = (int)value;

@@ -24,6 +24,7 @@
 // dm doubles at a time.  Workgroups are remapped so that each XCD (private 4 MiB L2) walks one
 // contiguous range of slices and the x-gathers of neighbouring slices hit the same L2.
 #include <cmath>
+#include <hip/hip_ext.h>
 #include "ctx.hpp"
 
 namespace femcy {
@@ -403,14 +404,21 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
         return FEMCY_EINVAL;
     }
     const int32_t* done = d_partials ? &c->d_state->done : nullptr;
-    size_t th = timing_begin(c, T_SPMV);
+    // timing: start/stop events attached to the dispatch itself (hipExtLaunchKernel), i.e. the kernel's own
+    // begin/end timestamps -- no marker packets between the PCG kernels, agrees with rocprofv3's kernel trace
+    // FEMCY_OPT_TIMING = k > 1 samples every k-th SpMV launch: a profiled dispatch costs ~5 us of pipeline
+    // drain, which would otherwise inflate every CG iteration of a timed run by ~10 %
+    const bool sample = c->opt_timing == 1 || (c->opt_timing > 1 && (c->spmv_count++ % c->opt_timing) == 0);
+    EventPair* ev = sample ? timing_acquire(c, T_SPMV) : nullptr;
+    hipEvent_t ea = ev ? ev->a : nullptr, eb = ev ? ev->b : nullptr;
     if (c->dm == 3)
-        hipLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->nslices, c->d_slice_len,
-                           c->d_slice_off, c->d_bcol, c->d_Kvals, d_x, d_y, d_partials, done);
+        hipExtLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->nslices,
+                              (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
+                              (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
     else
-        hipLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->nslices, c->d_slice_len,
-                           c->d_slice_off, c->d_bcol, c->d_Kvals, d_x, d_y, d_partials, done);
-    timing_end(c, th);
+        hipExtLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->nslices,
+                              (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
+                              (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
     FEMCY_HIP(hipGetLastError());
     if (nblocks_out) *nblocks_out = grid;
     return FEMCY_OK;

@@ -78,7 +78,8 @@ enum femcy_assembly { FEMCY_ASM_GATHER = 0 /* owner-computes, deterministic */, 
 enum femcy_option {
     FEMCY_OPT_ASSEMBLY = 0,     /* enum femcy_assembly, default GATHER                         */
     FEMCY_OPT_PCG_POLL = 1,     /* iterations between host polls of the device "done" flag      */
-    FEMCY_OPT_TIMING = 2,       /* 1 = bracket kernel classes with hipEvents (femcy_timing)     */
+    FEMCY_OPT_TIMING = 2,       /* 1 = time kernel classes with hipEvents (femcy_timing);       */
+                                /* k > 1 = same, but only every k-th SpMV launch is sampled     */
     FEMCY_OPT_SPMV_VARIANT = 3  /* 0 = 8-byte loads, 1 = 16-byte paired loads                   */
 };
 
