@@ -40,6 +40,11 @@ struct PcgState {
     int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown
 };
 
+// contiguous slice range of each XCD for the SpMV (balanced by stored blocks), passed by value
+struct XcdRanges {
+    int32_t start[9];
+};
+
 struct EventPair {
     hipEvent_t a, b;
 };
@@ -63,6 +68,8 @@ struct Ctx {
 
     // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
     int32_t nslices = 0;
+    XcdRanges xcd{};                  // SpMV: slice range per XCD
+    int32_t spmv_grid = 0;            // 8 * max blocks per XCD
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
     int64_t nnzb = 0;
     int32_t max_row_blocks = 0, max_node_elems = 0;

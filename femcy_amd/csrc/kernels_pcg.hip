@@ -81,21 +81,22 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
 
 // ------------------------------------------------------------------------------------------ SpMV
 template <int DM>
-__global__ void __launch_bounds__(BS) k_spmv(int32_t nn, int32_t nslices, const int32_t* __restrict__ slice_len,
+__global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
                                              const int32_t* __restrict__ bcol, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done) {
     __shared__ double sm[BS / 64];
     if (done && *done) return;
-    // XCD-aware remap: physical block b runs on XCD b % 8; give each XCD a contiguous slice range
-    const int nb = gridDim.x;
-    const int per = (nb + NXCD - 1) / NXCD;
-    const int vb = (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
+    // XCD-aware mapping: physical block b runs on XCD b % 8 (observed dispatch order; speed only).  XCD k
+    // walks the contiguous slice range [xr.start[k], xr.start[k+1]), ranges balanced by stored work, so the
+    // x-gathers of neighbouring slices share one private L2.  gridDim.x = 8 * blocks-per-XCD; blocks past
+    // the end of their range only contribute a zero partial.
+    const int k = blockIdx.x % NXCD;
     const int lane = threadIdx.x & 63;
-    const int s = vb * (BS / 64) + (threadIdx.x >> 6);
+    const int s = xr.start[k] + (blockIdx.x / NXCD) * (BS / 64) + (threadIdx.x >> 6);
     double dot = 0.0;
-    if (vb < nb && s < nslices) {
+    if (s < xr.start[k + 1]) {
         const int32_t L = slice_len[s];
         const int64_t off = slice_off[s];
         const int64_t a = (int64_t)s * SLICE + lane;
@@ -211,12 +212,22 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, c
                                                   double* __restrict__ part2) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->done) return;
+    // issue the first tile's loads before the scalar prologue so the partial reduction hides under them
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2 z2 = make_double2(0.0, 0.0);
+    double2 dv = z2, av = z2, mv = z2, xv = z2, rv = z2;
+    if (i < n2) {
+        dv = d[i];
+        av = Ad[i];
+        mv = M[i];
+        xv = x[i];
+        rv = r[i];
+    }
     const double dAd = dAd_reduced ? *dAd_reduced : reduce_partials_sum(part1, np1, sm1);
     const double alpha = st->rMr[it & 1] / dAd;
     double rMr = 0.0, rm = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 dv = d[i], av = Ad[i], mv = M[i];
-        double2 xv = x[i], rv = r[i];
+    while (i < n2) {
         xv.x = xv.x + alpha * dv.x;
         xv.y = xv.y + alpha * dv.y;
         rv.x = rv.x - alpha * av.x;
@@ -230,6 +241,14 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, c
         }
         rMr += w0 * (rv.x * mv.x * rv.x) + w1 * (rv.y * mv.y * rv.y);
         rm = fmax(rm, fmax(nan_to_inf_abs(rv.x), nan_to_inf_abs(rv.y)));
+        i += stride;
+        if (i < n2) {
+            dv = d[i];
+            av = Ad[i];
+            mv = M[i];
+            xv = x[i];
+            rv = r[i];
+        }
     }
     const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
     if (threadIdx.x == 0) {
@@ -245,16 +264,25 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int it, int np2, co
                                                  const double2* __restrict__ M, double2* __restrict__ d) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->done) return;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2 z2 = make_double2(0.0, 0.0);
+    double2 rv = z2, mv = z2, dv = z2;
+    if (i < n2) {           // first tile in flight while the scalars are reduced
+        rv = r[i];
+        mv = M[i];
+        dv = d[i];
+    }
     double s = 0.0, m = 0.0;
     if (gathered) {
-        for (int i = threadIdx.x; i < nranks; i += BS) {
-            s += gathered[2 * i];
-            m = fmax(m, gathered[2 * i + 1]);
+        for (int k = threadIdx.x; k < nranks; k += BS) {
+            s += gathered[2 * k];
+            m = fmax(m, gathered[2 * k + 1]);
         }
     } else {
-        for (int i = threadIdx.x; i < np2; i += BS) {
-            s += part2[2 * i];
-            m = fmax(m, part2[2 * i + 1]);
+        for (int k = threadIdx.x; k < np2; k += BS) {
+            s += part2[2 * k];
+            m = fmax(m, part2[2 * k + 1]);
         }
     }
     const double rMr_new = block_sum(s, sm1);
@@ -262,12 +290,16 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int it, int np2, co
     const double rMr_old = st->rMr[it & 1];
     const double r0 = st->r0;
     const double beta = rMr_new / rMr_old;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BS) {
-        const double2 rv = r[i], mv = M[i];
-        double2 dv = d[i];
+    while (i < n2) {
         dv.x = mv.x * rv.x + beta * dv.x;
         dv.y = mv.y * rv.y + beta * dv.y;
         d[i] = dv;
+        i += stride;
+        if (i < n2) {
+            rv = r[i];
+            mv = M[i];
+            dv = d[i];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->rMr[(it + 1) & 1] = rMr_new;
@@ -396,10 +428,8 @@ int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1
 
 // ---------------------------------------------------------------------------------------- SpMV
 int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
-    const int grid = (c->nslices + (BS / 64) - 1) / (BS / 64);
+    const int grid = c->spmv_grid;
     if (grid > MAX_PARTIALS) {
-        // more slices than partial slots: fall back to a coarser partial count is not needed for the
-        // sizes this path is built for (4096 blocks = 1M nodes); report instead of silently truncating
         set_error("SpMV grid %d exceeds MAX_PARTIALS %d", grid, MAX_PARTIALS);
         return FEMCY_EINVAL;
     }
@@ -412,11 +442,11 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     EventPair* ev = sample ? timing_acquire(c, T_SPMV) : nullptr;
     hipEvent_t ea = ev ? ev->a : nullptr, eb = ev ? ev->b : nullptr;
     if (c->dm == 3)
-        hipExtLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->nslices,
+        hipExtLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->xcd,
                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
     else
-        hipExtLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->nslices,
+        hipExtLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->xcd,
                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
     FEMCY_HIP(hipGetLastError());

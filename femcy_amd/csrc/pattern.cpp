@@ -170,6 +170,22 @@ int build_pattern(Ctx* c) {
         }
     }
 
+    // ---- SpMV work split: XCD k gets the contiguous slice range holding the k-th eighth of the stored blocks
+    {
+        constexpr int NX = 8, WPB = 4;   // XCDs, waves (= slices) per workgroup
+        int32_t s = 0;
+        c->xcd.start[0] = 0;
+        for (int k = 1; k < NX; ++k) {
+            const int64_t target = stored_rows * k / NX;
+            while (s < nslices && slice_off[s] < target) ++s;
+            c->xcd.start[k] = s;
+        }
+        c->xcd.start[NX] = nslices;
+        int32_t per = 1;
+        for (int k = 0; k < NX; ++k) per = std::max(per, (c->xcd.start[k + 1] - c->xcd.start[k] + WPB - 1) / WPB);
+        c->spmv_grid = per * NX;
+    }
+
     // ---- commit to the context
     c->nslices = nslices;
     c->stored_rows = stored_rows;

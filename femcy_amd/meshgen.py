@@ -103,15 +103,47 @@ def scaling_cells(n_gpus: int) -> Tuple[int, int, int]:
     return (96, 12, 144 * n_gpus)
 
 
+def beam_quad8(nx: int = 40, ny: int = 4, length: float = 40.0, height: float = 4.0, plane: str = "CPE8",
+               tip_disp: float = 20.0) -> Dict:
+    """BASELINE configs[1] stand-in (no CPE8 beam deck is shipped): the 40 x 4 beam of
+    tests/beam_deflection (E = 2e5, nu = 0.3, nlgeom=YES, left face clamped, right side u_x = 0 and
+    u_y = tip_disp) meshed with nx x ny serendipity quadrilaterals (corner order 0-3 counter-clockwise,
+    mid-sides 4:(0,1) 5:(1,2) 6:(2,3) 7:(3,0), element_quadratic_quadrilateral.py:7-14)."""
+    gx, gy = 2 * nx + 1, 2 * ny + 1
+    I, J = np.meshgrid(np.arange(gx), np.arange(gy), indexing="xy")          # [gy, gx]
+    used = ~((I % 2 == 1) & (J % 2 == 1))
+    ids = -np.ones((gy, gx), dtype=np.int64)
+    ids[used] = np.arange(used.sum())
+    nodes = np.stack([I[used] * (length / (2 * nx)), J[used] * (height / (2 * ny))], axis=1).astype(np.float64)
+    ex, ey = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    i0, j0 = 2 * ex.ravel(), 2 * ey.ravel()
+    loc = [(0, 0), (2, 0), (2, 2), (0, 2), (1, 0), (2, 1), (1, 2), (0, 1)]
+    el = np.stack([ids[j0 + dj, i0 + di] for di, dj in loc], axis=1).astype(np.int32)
+    left = np.nonzero(nodes[:, 0] < 1e-9)[0]
+    right = np.nonzero(nodes[:, 0] > length - 1e-9)[0]
+    dirichlet = [{"node_set": right, "dof": 0, "val": 0.0, "user": False},
+                 {"node_set": left, "dof": 0, "val": 0.0, "user": False},
+                 {"node_set": left, "dof": 1, "val": 0.0, "user": False},
+                 {"node_set": right, "dof": 1, "val": tip_disp, "user": False}]
+    return {"nodes": nodes, "elements": el, "etype": plane, "node_sets": {"left_face": left, "right_side": right},
+            "dirichlet_bc_info": dirichlet, "neumann_bc_info": [], "elastic": (2.0e5, 0.3),
+            "geometric_nonlinear": True,
+            "time_incs": {"ini_inc": 0.25, "max_time": 1.0, "min_inc": 1e-5, "max_inc": 0.25},
+            "bc_blocks": [(False, ["right_side, 1, 1"]), (False, ["left_face, 1, 1", "left_face, 2, 2"]),
+                          (False, ["right_side, 2, 2, %.17g" % tip_disp])]}
+
+
 def write_inp(path: str, mesh: Dict, part: str = "Part-1"):
-    """write a reader-compatible Abaqus deck (same keyword layout as the shipped twist decks)."""
+    """write a reader-compatible Abaqus deck (same keyword layout as the shipped decks)."""
     nodes, el = mesh["nodes"], mesh["elements"]
     inst = f"{part}-1"
+    blocks = mesh.get("bc_blocks", [(False, ["Set-10, %d, %d" % (d, d) for d in (1, 2, 3)]),
+                                    (True, ["fit_right_z, %d, %d" % (d, d) for d in (1, 2, 3)])])
     with open(path, "w") as f:
         f.write("*Heading\n** generated by femcy_amd.meshgen\n*Part, name=%s\n*End Part\n" % part)
         f.write("*Assembly, name=Assembly\n*Instance, name=%s, part=%s\n*Node\n" % (inst, part))
         for i, p in enumerate(nodes):
-            f.write("%d, %.17g, %.17g, %.17g\n" % (i + 1, p[0], p[1], p[2]))
+            f.write(", ".join(["%d" % (i + 1)] + ["%.17g" % v for v in p]) + "\n")
         f.write("*Element, type=%s\n" % mesh["etype"])
         for i, e in enumerate(el):
             f.write(", ".join(str(v) for v in [i + 1] + (e + 1).tolist()) + "\n")
@@ -125,6 +157,7 @@ def write_inp(path: str, mesh: Dict, part: str = "Part-1"):
         f.write("*Step, name=Step-1, nlgeom=%s\n*Static\n" % ("YES" if mesh["geometric_nonlinear"] else "NO"))
         t = mesh["time_incs"]
         f.write("%.17g, %.17g, %.17g, %.17g\n" % (t["ini_inc"], t["max_time"], t["min_inc"], t["max_inc"]))
-        f.write("*Boundary\n" + "".join("Set-10, %d, %d\n" % (d, d) for d in (1, 2, 3)))
-        f.write("*Boundary, user\n" + "".join("fit_right_z, %d, %d\n" % (d, d) for d in (1, 2, 3)))
+        for user, lines in blocks:
+            f.write("*Boundary, user\n" if user else "*Boundary\n")
+            f.write("".join(l + "\n" for l in lines))
         f.write("*End Step\n")

@@ -28,10 +28,21 @@ SOLVE_DECKS = [
     "cookMembrane_2d_linearEl_smallDef.inp", "beam_CPS3_disp_meshSize5.inp", "cook_3d_linearEl_largeDef.inp",
     "beamDeflec_quadPSE_largeD_load800.inp", "twist_plate_C3D4.inp", "twist_C3D10_coarse.inp",
     "cookMembrane_2d_linearEl_largeDef.inp",
+    # generated decks (femcy_amd.meshgen.beam_quad8, written by write_generated_decks() below):
+    # BASELINE configs[1] asks for a CPE8 large-deformation beam, which the reference does not ship
+    "gen_beam_CPE8_tip4.inp",       # plane strain StVK, 20 x 2 quad8, converges in 4 increments
+    "gen_beam_CPS8_tip8.inp",       # plane stress, 3 increment cut-backs (dt/4 + dof_old restore path)
 ]
 
 
+def write_generated_decks():
+    from femcy_amd import meshgen
+    meshgen.write_inp(deck("gen_beam_CPE8_tip4.inp"), meshgen.beam_quad8(20, 2, plane="CPE8", tip_disp=4.0))
+    meshgen.write_inp(deck("gen_beam_CPS8_tip8.inp"), meshgen.beam_quad8(20, 2, plane="CPS8", tip_disp=8.0))
+
+
 def main():
+    write_generated_decks()
     out = {}
     for name in SOLVE_DECKS:
         inp = InpInfo(deck(name))

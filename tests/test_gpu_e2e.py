@@ -22,6 +22,10 @@ CASES = [  # (deck, tolerance)
     ("cook_3d_linearEl_largeDef", 1e-6),                  # C3D4 Neo-Hookean large deformation
     ("beamDeflec_quadPSE_largeD_load800", 1e-6),          # CPS6 large deformation, traction load
     ("twist_plate_C3D4", 1e-6),                           # 180 degree twist, user Dirichlet BC, 186 solves
+    ("cookMembrane_2d_linearEl_largeDef", 1e-6),          # CPE3 plane strain large deformation, 670 solves
+    ("twist_C3D10_coarse", 1e-6),                         # C3D10 twist (BASELINE configs[4] element), 1184 solves
+    ("gen_beam_CPE8_tip4", 1e-6),                         # BASELINE configs[1] stand-in: CPE8 large deformation
+    ("gen_beam_CPS8_tip8", 1e-6),                         # CPS8 with 3 increment cut-backs (dt/4 + restore)
 ]
 
 
@@ -47,7 +51,11 @@ def test_deck_displacements(name, tol):
     print(f"{name}: rel L2 = {err:.3e}, stats = {system.stats}, increments = {len(system.increments)}")
     assert err <= tol
     incs, solves = g[name + "/meta"][:2]
-    assert len(system.increments) == incs and system.stats["linear_solves"] == solves
+    assert len(system.increments) == incs
+    failed = sum(not i["converged"] for i in system.increments)
+    # a discarded (cut-back) increment iterates on a diverging Newton sequence: where exactly it trips the
+    # NaN / 24-iteration exit is rounding-sensitive, so the solve count may differ there by a few
+    assert abs(system.stats["linear_solves"] - solves) <= (0 if failed == 0 else 2 * failed)
 
 
 def test_twist_prescribed_rotation():

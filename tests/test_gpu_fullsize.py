@@ -1,0 +1,126 @@
+"""-m gpu: BASELINE.json's full-size configuration (995 328 C3D4, 548 535 DOF, configs[2]) --
+the HIP path against the as-written C/OpenMP oracle (which handles 1 M elements in seconds) and through
+size-independent properties (symmetry, rigid-body null space, idempotence / run-to-run bit
+reproducibility, Dirichlet identity rows, solver residual)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+    from oracle.c_oracle import COracle
+    from oracle.elements import elem_def
+    from oracle.femcy_oracle import Material
+    m = meshgen.twist_plate_k(12)
+    assert m["elements"].shape == (995328, 4) and m["nodes"].shape == (182845, 3)
+    ctx = be.Context(0)
+    ctx.set_mesh(m["nodes"], m["elements"])
+    ctx.set_element(Element_linear_tetrahedral())
+    ctx.set_material(LinearIsotropic(*m["elastic"]))
+    info = ctx.build_pattern()
+    assert (info.n, info.nnzb, info.nnz, info.max_row_blocks) == (548535, 2606005, 23454045, 15)
+    u = np.zeros(ctx.n)
+    cons = []
+    for bc in m["dirichlet_bc_info"]:
+        cons.append(np.asarray(bc["node_set"]) * 3 + bc["dof"])
+        if bc["user"]:
+            user_dirichletBC_values(u, bc["node_set"], 3, bc["dof"], m["nodes"], 0.05)
+    cons = np.unique(np.concatenate(cons))
+    ed = elem_def("C3D4")
+    co = COracle(m["nodes"], m["elements"], ed.dN_table(), ed.gauss_weights, Material("lin3d", m["elastic"]).C)
+    yield dict(be=be, ctx=ctx, m=m, u=u, cons=cons, co=co)
+    ctx.close()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def test_fullsize_against_c_oracle(full):
+    be, ctx, u, cons, co, m = full["be"], full["ctx"], full["u"], full["cons"], full["co"], full["m"]
+    ctx.upload(be.VEC_DOF, u)
+    ctx.assemble_K(be.VEC_DOF)
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
+    assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy(), co.dsdx) < 1e-12
+    x = np.random.default_rng(0).standard_normal(ctx.n)
+    ctx.upload(be.VEC_TMP0, x)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    y = ctx.download(be.VEC_TMP1)
+    assert rel(y, co.compute_Ad(x)) < 1e-12                      # K(u) x, reference ELL SpMV as written
+    # internal force (F at the reference configuration, StVK stress, current-configuration gather)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f = co.internal_force(u, 0, *m["elastic"])
+    assert rel(ctx.download(be.VEC_FORCE), f) < 1e-11
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), co.sigma) < 1e-11
+    # Newton Dirichlet + 30 iterations of the reference recurrence
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    co.zero_rows_cols_unit_diag(cons)
+    f[cons] = 0.0
+    assert rel(ctx.download(be.VEC_RESIDUAL), f) < 1e-11
+    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+    xo, ito, r0o, rmaxo = co.cg(f, eps=0.0, maxit=30)
+    assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
+    assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+
+
+def test_fullsize_properties(full):
+    be, ctx, u, cons = full["be"], full["ctx"], full["u"], full["cons"]
+    rng = np.random.default_rng(1)
+    ctx.upload(be.VEC_DOF, u)
+
+    def Kx(v):
+        ctx.upload(be.VEC_TMP0, v)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        return ctx.download(be.VEC_TMP1)
+
+    ctx.assemble_K(be.VEC_DOF)
+    x, y = rng.standard_normal(ctx.n), rng.standard_normal(ctx.n)
+    Kx1, Ky1 = Kx(x), Kx(y)
+    scale = np.abs(Kx1).max()
+    assert abs(y @ Kx1 - x @ Ky1) < 1e-10 * abs(y @ Kx1)                 # symmetry
+    assert np.abs(Kx(2.5 * x - 0.5 * y) - (2.5 * Kx1 - 0.5 * Ky1)).max() < 1e-12 * scale     # linearity
+    for i in range(3):                                                   # rigid translations: K t = 0
+        t = np.zeros(ctx.n)
+        t[i::3] = 1.0
+        assert np.abs(Kx(t)).max() < 1e-9 * scale
+    # idempotence / determinism: re-assembling gives the same bits; the atomic variant the same values
+    ctx.assemble_K(be.VEC_DOF)
+    assert np.array_equal(Kx(x), Kx1)
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ATOMIC)
+    ctx.assemble_K(be.VEC_DOF)
+    assert np.abs(Kx(x) - Kx1).max() < 1e-12 * scale
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_GATHER)
+    ctx.assemble_K(be.VEC_DOF)
+    # Dirichlet: constrained rows/columns become identity
+    b = rng.standard_normal(ctx.n)
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    bb = ctx.download(be.VEC_RESIDUAL)
+    assert (bb[cons] == 0).all() and np.array_equal(np.delete(bb, cons), np.delete(b, cons))
+    Kxd = Kx(x)
+    assert np.array_equal(Kxd[cons], x[cons])
+    x0 = x.copy()
+    x0[cons] = 0.0
+    free = np.ones(ctx.n, bool)
+    free[cons] = False
+    assert np.abs(Kx(x0)[free] - Kxd[free]).max() < 1e-12 * scale        # columns of constrained DOFs are zero
+    # the reference's CG settings at >= 1e5 DOF (eps = 1e-3, stiffnessMtrx.py:257-259) converge and solve
+    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+    xs = ctx.download(be.VEC_X)
+    assert 0 < it < ctx.n and rmax < 1e-3 * r0
+    assert np.abs(Kx(xs) - bb).max() < 1.0001e-3 * r0
+    it2, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+    assert it2 == it and np.array_equal(ctx.download(be.VEC_X), xs)       # run-to-run bit reproducible

@@ -182,7 +182,7 @@ def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
         x = ctx.download(be.VEC_X)
         xo, ito, r0o, rmaxo = orc.pcg_reference(K, bb, eps=eps)
         assert r0 == r0o
-        assert abs(it - ito) <= max(1, ito // 100), (it, ito)
+        assert abs(it - ito) <= max(2, ito // 50), (it, ito)      # rounding order moves a tight stop by a few iterations
         assert rmax < eps * r0
         if it == ito:
             assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < tol

@@ -220,7 +220,7 @@ def test_pcg_reference_solves_and_counts():
 FAST = ["ellip_membrane_linEle_localVeryFine", "ellip_membrane_quadritic_trig_neumann", "ellip_CPS4", "ellip_CPS8",
         "ellip_membrane_3d_linearEl", "ellip_membrane_3d", "ellip_membrane_localFine_dirichlet",
         "ellip_localVeryFine_directional_force", "cookMembrane_2d_linearEl_smallDef", "beam_CPS3_disp_meshSize5",
-        "cook_3d_linearEl_largeDef"]
+        "cook_3d_linearEl_largeDef", "gen_beam_CPE8_tip4", "gen_beam_CPS8_tip8"]
 
 
 @pytest.mark.parametrize("name", FAST)
