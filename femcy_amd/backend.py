@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libfemcy_hip.so")
 # enum femcy_vec
 VEC_DOF, VEC_RHS, VEC_RESIDUAL, VEC_FORCE, VEC_DU, VEC_DOF_OLD, VEC_X, VEC_TMP0, VEC_TMP1 = range(9)
 # enum femcy_gpfield
-GP_DSDX, GP_VOL, GP_F, GP_SIGMA = range(4)
+GP_DSDX, GP_VOL, GP_F, GP_SIGMA, GP_STRAIN, GP_MISES, GP_ENERGY = range(7)
 # enum femcy_option
 OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT = range(4)
 ASM_GATHER, ASM_ATOMIC = 0, 1
@@ -34,7 +34,8 @@ EXPORTS = [
     "femcy_vec_upload", "femcy_vec_download", "femcy_vec_fill", "femcy_vec_copy", "femcy_vec_scatter",
     "femcy_vec_sub", "femcy_vec_axpy", "femcy_vec_scale", "femcy_vec_norm", "femcy_vec_absmax",
     "femcy_assemble_K", "femcy_internal_force", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
-    "femcy_spmv", "femcy_pcg", "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
+    "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
+    "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
     "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_init", "femcy_iface_sum",
 ]
 
@@ -91,6 +92,8 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_apply_dirichlet_linear": [p, p, p, i32, cint], "femcy_apply_dirichlet_newton": [p, p, i32, cint],
         "femcy_spmv": [p, cint, cint],
         "femcy_pcg": [p, cint, cint, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)],
+        "femcy_compute_strain_stress": [p, cint, cint], "femcy_elastic_energy": [p, cint, C.POINTER(f64)],
+        "femcy_extrapolate": [p, cint, cint, p, p],
         "femcy_get_K_ell": [p, p, p], "femcy_get_K_bsr": [p, p, p, p], "femcy_get_gp_field": [p, cint, p],
         "femcy_timing": [p, C.POINTER(Timing)], "femcy_timing_reset": [p],
         "femcy_comm_unique_id": [p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
@@ -286,6 +289,24 @@ class Context:
         self._call("femcy_pcg", int(b_vec), int(x_vec), float(eps), int(maxit), C.byref(it), C.byref(r0), C.byref(rm))
         return it.value, r0.value, rm.value
 
+    # -------------------------------------------------------------------------- post-processing
+    def compute_strain_stress(self, u_vec: int = VEC_DOF, large: bool = False):
+        self._call("femcy_compute_strain_stress", int(u_vec), int(bool(large)))
+
+    def elastic_energy(self, u_vec: int = VEC_DOF) -> float:
+        out = C.c_double()
+        self._call("femcy_elastic_energy", int(u_vec), C.byref(out))
+        return out.value
+
+    def extrapolate(self, gp_field: int, E: np.ndarray, comp: int = 0) -> np.ndarray:
+        """Gauss-point field (component `comp`) -> patch-wise nodal values [ne, npe]; E is npe x nGP."""
+        E = _f64(E)
+        if E.shape != (self.npe, self.nGP):
+            raise FemcyError(f"extrapolation matrix must be {self.npe} x {self.nGP}, got {E.shape}")
+        out = np.empty((self.ne, self.npe), dtype=np.float64)
+        self._call("femcy_extrapolate", int(gp_field), int(comp), _ptr(E), _ptr(out))
+        return out
+
     # ------------------------------------------------------------------------------ inspection
     def get_K_ell(self):
         info = self.pattern_info()
@@ -306,7 +327,9 @@ class Context:
         return sp.bsr_matrix((vals, col, rowptr), shape=(self.n, self.n))
 
     def gauss_field(self, which: int) -> GaussField:
-        tail = {GP_DSDX: (self.npe, self.dm), GP_VOL: (), GP_F: (self.dm, self.dm), GP_SIGMA: (self.dm, self.dm)}[which]
+        mat = (self.dm, self.dm)
+        tail = {GP_DSDX: (self.npe, self.dm), GP_VOL: (), GP_F: mat, GP_SIGMA: mat, GP_STRAIN: mat, GP_MISES: (),
+                GP_ENERGY: ()}[which]
         return GaussField(self, which, tail)
 
     def timing(self) -> dict:

@@ -91,6 +91,9 @@ struct Ctx {
     double* d_vol = nullptr;
     double* d_F = nullptr;
     double* d_sigma = nullptr;
+    double* d_strain = nullptr;
+    double* d_mises = nullptr;
+    double* d_energy = nullptr;
 
     // ---- vectors
     double* d_vec[FEMCY_VEC_COUNT] = {nullptr};
@@ -137,7 +140,11 @@ void timing_collect(Ctx* c);
 // pattern.cpp
 int build_pattern(Ctx* c);
 // kernels_*.hip (host launchers)
-int launch_geom(Ctx* c, const double* d_u, bool with_stress);
+int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom = true, bool write_sigma = true);
+int launch_post(Ctx* c, int large);
+int launch_energy(Ctx* c);
+int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int width, int comp, double* d_out);
+int launch_energy_sum(Ctx* c, double* total);
 int launch_assemble(Ctx* c);
 int launch_nodal_force(Ctx* c, double* d_f);
 int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out);

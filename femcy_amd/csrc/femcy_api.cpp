@@ -185,6 +185,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr);
     dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
+    dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy);
     for (auto& v : c->d_vec) dev_free(&v);
     dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad);
     dev_free(&c->d_part1); dev_free(&c->d_part2); dev_free(&c->d_state);
@@ -282,7 +283,9 @@ int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN, const doubl
     FEMCY_HIP(hipMemcpy(c->d_w, w, sizeof(double) * nGP, hipMemcpyHostToDevice));
     const size_t ngp = (size_t)c->ne * nGP;
     if ((rc = dev_alloc(&c->d_dsdx, ngp * c->npe * c->dm)) || (rc = dev_alloc(&c->d_vol, ngp)) ||
-        (rc = dev_alloc(&c->d_F, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_sigma, ngp * c->dm * c->dm)))
+        (rc = dev_alloc(&c->d_F, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_sigma, ngp * c->dm * c->dm)) ||
+        (rc = dev_alloc(&c->d_strain, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_mises, ngp)) ||
+        (rc = dev_alloc(&c->d_energy, ngp)))
         return rc;
     c->have_element = true;
     return FEMCY_OK;
@@ -515,6 +518,56 @@ int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, i
     return pcg_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], eps, maxit, iters, rmax0, rmax);
 }
 
+// ------------------------------------------------------------------------------ post-processing
+int femcy_compute_strain_stress(femcy_ctx* ctx, int u_vec, int large) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh && c->have_element && c->have_material, "context not fully defined");
+    VEC_OR_FAIL(u_vec);
+    // get_deformation_gradient: F only -- dsdx, vol and (for nlgeom) the Cauchy stress of the last
+    // constitutiveOfLargeDeform stay as they are, exactly as in the reference
+    int rc = launch_geom(c, c->d_vec[u_vec], true, false, false);
+    if (rc) return rc;
+    return launch_post(c, large ? 1 : 0);
+}
+
+int femcy_elastic_energy(femcy_ctx* ctx, int u_vec, double* total) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh && c->have_element && c->have_material && total, "context not fully defined");
+    VEC_OR_FAIL(u_vec);
+    int rc = launch_geom(c, c->d_vec[u_vec], true, false, false);
+    if (rc) return rc;
+    if ((rc = launch_energy(c))) return rc;
+    return launch_energy_sum(c, total);
+}
+
+int femcy_extrapolate(femcy_ctx* ctx, int gp_field, int comp, const double* E, double* out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_element && E && out, "element tables not set or null arguments");
+    const double* field = nullptr;
+    int width = 1;
+    switch (gp_field) {
+        case FEMCY_GP_VOL: field = c->d_vol; break;
+        case FEMCY_GP_MISES: field = c->d_mises; break;
+        case FEMCY_GP_ENERGY: field = c->d_energy; break;
+        case FEMCY_GP_F: field = c->d_F; width = c->dm * c->dm; break;
+        case FEMCY_GP_SIGMA: field = c->d_sigma; width = c->dm * c->dm; break;
+        case FEMCY_GP_STRAIN: field = c->d_strain; width = c->dm * c->dm; break;
+        default: set_error("field %d cannot be extrapolated", gp_field); return FEMCY_EINVAL;
+    }
+    FEMCY_REQUIRE(comp >= 0 && comp < width, "component %d out of range for field %d", comp, gp_field);
+    double *d_E = nullptr, *d_out = nullptr;
+    const size_t nE = (size_t)c->npe * c->nGP, nout = (size_t)c->ne * c->npe;
+    FEMCY_HIP(hipMalloc((void**)&d_E, nE * sizeof(double)));
+    FEMCY_HIP(hipMalloc((void**)&d_out, nout * sizeof(double)));
+    FEMCY_HIP(hipMemcpyAsync(d_E, E, nE * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = launch_extrapolate(c, d_E, field, width, comp, d_out);
+    if (!rc) FEMCY_HIP(hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_E);
+    (void)hipFree(d_out);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------- inspection
 static int download_K(Ctx* c, std::vector<double>& vals) {
     vals.resize((size_t)c->stored_rows * c->dm * c->dm * SLICE);
@@ -589,6 +642,9 @@ int femcy_get_gp_field(femcy_ctx* ctx, int which, double* out) {
         case FEMCY_GP_VOL: src = c->d_vol; count = ngp; break;
         case FEMCY_GP_F: src = c->d_F; count = ngp * c->dm * c->dm; break;
         case FEMCY_GP_SIGMA: src = c->d_sigma; count = ngp * c->dm * c->dm; break;
+        case FEMCY_GP_STRAIN: src = c->d_strain; count = ngp * c->dm * c->dm; break;
+        case FEMCY_GP_MISES: src = c->d_mises; count = ngp; break;
+        case FEMCY_GP_ENERGY: src = c->d_energy; count = ngp; break;
         default: set_error("unknown Gauss-point field %d", which); return FEMCY_EINVAL;
     }
     FEMCY_HIP(hipStreamSynchronize(c->stream));

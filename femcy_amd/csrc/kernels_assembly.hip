@@ -20,6 +20,8 @@
 //   * B has 3 (3-D) / 2 (2-D) non-zeros per column; B^T C B is evaluated on those only, in the same
 //     ascending Voigt order as the reference's dense products, so the only rounding differences are
 //     FMA contraction and the (order-free in the reference) accumulation order over elements.
+#include <algorithm>
+#include <vector>
 #include "ctx.hpp"
 
 namespace femcy {
@@ -207,17 +209,19 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                 J[i][j] = acc;
             }
         const double det = det_inv<DM>(J, inv);
-        double* out = dsdx + ((int64_t)e * nGP + g) * NPE * DM;
+        if (dsdx) {   // post-processing recomputes F / sigma without touching the stored geometry
+            double* out = dsdx + ((int64_t)e * nGP + g) * NPE * DM;
 #pragma unroll
-        for (int a = 0; a < NPE; ++a)
+            for (int a = 0; a < NPE; ++a)
 #pragma unroll
-            for (int j = 0; j < DM; ++j) {
-                double acc = 0.0;
+                for (int j = 0; j < DM; ++j) {
+                    double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < DM; ++k) acc += dNg[a * DM + k] * inv[k][j];
-                out[a * DM + j] = acc;
-            }
-        vol[(int64_t)e * nGP + g] = det * w[g];
+                    for (int k = 0; k < DM; ++k) acc += dNg[a * DM + k] * inv[k][j];
+                    out[a * DM + j] = acc;
+                }
+            vol[(int64_t)e * nGP + g] = det * w[g];
+        }
 
         if (STRESS) {
             double J0[DM][DM], inv0[DM][DM], F[DM][DM], sig[DM][DM];
@@ -252,16 +256,19 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
             }
 #pragma unroll
             for (int i = 0; i < DM; ++i) F[i][i] += 1.0;
-            cauchy_large<DM>(mat_kind, C, p0, p1, F, sig);
             double* fo = Fout + ((int64_t)e * nGP + g) * DM * DM;
-            double* so = Sout + ((int64_t)e * nGP + g) * DM * DM;
 #pragma unroll
             for (int i = 0; i < DM; ++i)
 #pragma unroll
-                for (int j = 0; j < DM; ++j) {
-                    fo[i * DM + j] = F[i][j];
-                    so[i * DM + j] = sig[i][j];
-                }
+                for (int j = 0; j < DM; ++j) fo[i * DM + j] = F[i][j];
+            if (Sout) {   // get_deformation_gradient alone (post-processing) leaves the stored stress untouched
+                cauchy_large<DM>(mat_kind, C, p0, p1, F, sig);
+                double* so = Sout + ((int64_t)e * nGP + g) * DM * DM;
+#pragma unroll
+                for (int i = 0; i < DM; ++i)
+#pragma unroll
+                    for (int j = 0; j < DM; ++j) so[i * DM + j] = sig[i][j];
+            }
         }
     }
 }
@@ -447,6 +454,264 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
     }
 }
 
+// ------------------------------------------------------------------------------ post-processing
+// compute_strain_stress (stiffnessMtrx.py:436-501), constitutiveOfSmallDeform x4, the three Mises kernels,
+// elasticEnergyDensity x4 (material_zoo/*.py), get_elasEng_kernel (:597-606).  One thread per Gauss point.
+template <int DM>
+__device__ __forceinline__ void cauchy_small(int kind, const double* __restrict__ C, double p0, double p1,
+                                             const double (&F)[DM][DM], double (&sig)[DM][DM]);
+
+template <>
+__device__ __forceinline__ void cauchy_small<3>(int kind, const double* __restrict__ C, double p0, double p1,
+                                                const double (&F)[3][3], double (&sig)[3][3]) {
+    if (kind == FEMCY_MAT_NEOHOOKE) {
+        cauchy_large<3>(kind, C, p0, p1, F, sig);   // neo_hookean.py:44-60: same expression
+        return;
+    }
+    double E[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E[i][j] = (F[i][j] + F[j][i]) / 2.0 - (i == j ? 1.0 : 0.0);
+    const double ev[6] = {E[0][0], E[1][1], E[2][2], 2.0 * E[0][1], 2.0 * E[2][0], 2.0 * E[1][2]};
+    double sv[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a += C[p * 6 + q] * ev[q];
+        sv[p] = a;
+    }
+    sig[0][0] = sv[0]; sig[1][1] = sv[1]; sig[2][2] = sv[2];
+    sig[0][1] = sig[1][0] = sv[3];
+    sig[0][2] = sig[2][0] = sv[4];
+    sig[1][2] = sig[2][1] = sv[5];
+}
+
+template <>
+__device__ __forceinline__ void cauchy_small<2>(int kind, const double* __restrict__ C, double p0, double p1,
+                                                const double (&F)[2][2], double (&sig)[2][2]) {
+    if (kind == FEMCY_MAT_PSTRESS) {
+        const double E_ = p0, nu = p1;
+        const double F33 = -nu / (1.0 - nu) * (F[0][0] + F[1][1] - 2.0) + 1.0;   // E33 = F33 - 1 multiplies zeros of C_6x6
+        (void)F33;
+        const double e00 = F[0][0] - 1.0, e11 = F[1][1] - 1.0, g01 = 2.0 * ((F[0][1] + F[1][0]) / 2.0);
+        const double G = E_ / 2.0 / (1.0 + nu), c00 = E_ / (1.0 - nu * nu), c01 = c00 * nu;
+        sig[0][0] = c00 * e00 + c01 * e11;
+        sig[1][1] = c01 * e00 + c00 * e11;
+        sig[0][1] = sig[1][0] = G * g01;
+    } else {
+        const double e00 = F[0][0] - 1.0, e11 = F[1][1] - 1.0;
+        const double e01 = (F[0][1] + F[1][0]) / 2.0;
+        const double ev[3] = {e00, e11, e01 + e01};
+        double v[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) v[p] = C[p * 3 + 0] * ev[0] + C[p * 3 + 1] * ev[1] + C[p * 3 + 2] * ev[2];
+        sig[0][0] = v[0];
+        sig[1][1] = v[1];
+        sig[0][1] = sig[1][0] = v[2];
+    }
+}
+
+__device__ __forceinline__ double energy_voigt3(const double (&F3)[3][3], const double (&C6)[6][6]) {
+    double ev[6];
+    green_voigt3(F3, ev);
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a += C6[p][q] * ev[q];
+        acc += ev[p] * a;
+    }
+    return acc / 2.0;
+}
+
+template <int DM>
+__device__ __forceinline__ double energy_density(int kind, const double* __restrict__ C, double p0, double p1,
+                                                 const double (&F)[DM][DM]) {
+    double F3[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, C6[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) C6[i][j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) F3[i][j] = F[i][j];
+    if (kind == FEMCY_MAT_NEOHOOKE) {
+        const double J = det3(F3);
+        double trB = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) trB += F3[i][j] * F3[i][j];
+        return p0 * (trB - 3.0 - 2.0 * log(J)) + p1 * (J - 1.0) * (J - 1.0);
+    }
+    if (kind == FEMCY_MAT_LIN3D) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) C6[i][j] = C[i * 6 + j];
+    } else if (kind == FEMCY_MAT_PSTRESS) {       // linear_isotropic_plane_stress.py:22-31, 98-114
+        const double E_ = p0, nu = p1, c00 = E_ / (1.0 - nu * nu);
+        F3[2][2] = -nu / (1.0 - nu) * (F[0][0] + F[1][1] - 2.0) + 1.0;
+        C6[0][0] = C6[1][1] = c00;
+        C6[0][1] = C6[1][0] = c00 * nu;
+        C6[3][3] = E_ / 2.0 / (1.0 + nu);
+    } else {                                      // plane strain: linear_isotropic_plane_strain.py:31-40, 88-100
+        F3[2][2] = 1.0;
+        const double c00 = C[0], c01 = C[1];
+        C6[0][0] = C6[1][1] = c00;
+        C6[0][1] = C6[1][0] = C6[0][2] = C6[2][0] = C6[1][2] = C6[2][1] = c01;
+        C6[3][3] = C[8];
+    }
+    return energy_voigt3(F3, C6);
+}
+
+template <int DM>
+__global__ void __launch_bounds__(256) k_post(int64_t ngp, int large, int kind, const double* __restrict__ C, double p0,
+                                              double p1, const double* __restrict__ Fin, double* __restrict__ sigma,
+                                              double* __restrict__ strain, double* __restrict__ mises) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ngp) return;
+    double F[DM][DM], sig[DM][DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) F[i][j] = Fin[t * DM * DM + i * DM + j];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+            double e;
+            if (large) {
+                e = 0.0;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) e += F[k][i] * F[k][j];
+                e = (e - (i == j ? 1.0 : 0.0)) / 2.0;       // Green strain (:575-589)
+            } else {
+                e = (F[i][j] + F[j][i]) / 2.0 - (i == j ? 1.0 : 0.0);   // infinitesimal strain (:559-572)
+            }
+            strain[t * DM * DM + i * DM + j] = e;
+        }
+    if (!large) {
+        cauchy_small<DM>(kind, C, p0, p1, F, sig);
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int j = 0; j < DM; ++j) sigma[t * DM * DM + i * DM + j] = sig[i][j];
+    } else {   // "stress has been computed for geometric nonlinear case" (:446-447)
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int j = 0; j < DM; ++j) sig[i][j] = sigma[t * DM * DM + i * DM + j];
+    }
+    double s3[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) s3[i][j] = sig[i][j];
+    if (kind == FEMCY_MAT_PSTRAIN) s3[2][2] = p1 * (sig[0][0] + sig[1][1]);   // nu (s_xx + s_yy) (:475-489)
+    const double tr = (s3[0][0] + s3[1][1] + s3[2][2]) / 3.0;
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double dv = s3[i][j] - (i == j ? tr : 0.0);
+            ss += dv * dv;
+        }
+    mises[t] = sqrt(1.5 * ss);
+}
+
+template <int DM>
+__global__ void __launch_bounds__(256) k_energy(int64_t ngp, int kind, const double* __restrict__ C, double p0, double p1,
+                                                const double* __restrict__ Fin, double* __restrict__ energy) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ngp) return;
+    double F[DM][DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) F[i][j] = Fin[t * DM * DM + i * DM + j];
+    energy[t] = energy_density<DM>(kind, C, p0, p1, F);
+}
+
+// ELE.extrapolate (element_zoo/*.py): nodal_vals[e][a] = sum_g E[a][g] * field[e][g][comp]
+__global__ void __launch_bounds__(256) k_extrapolate(int64_t ne, int npe, int nGP, int width, int comp,
+                                                     const double* __restrict__ E, const double* __restrict__ field,
+                                                     double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ne * npe) return;
+    const int64_t e = t / npe;
+    const int a = (int)(t % npe);
+    double acc = 0.0;
+    for (int g = 0; g < nGP; ++g) acc += E[a * nGP + g] * field[(e * nGP + g) * width + comp];
+    out[t] = acc;
+}
+
+// sum_i a[i] * b[i] partials (elastic energy = sum density * vol)
+__global__ void __launch_bounds__(256) k_dot_partial(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                     double* __restrict__ part) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += a[i] * b[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+int launch_post(Ctx* c, int large) {
+    const int64_t ngp = (int64_t)c->ne * c->nGP;
+    const int bs = 256, grid = (int)((ngp + bs - 1) / bs);
+    if (c->dm == 3)
+        hipLaunchKernelGGL((k_post<3>), dim3(grid), dim3(bs), 0, c->stream, ngp, large, c->mat_kind, c->d_C,
+                           c->mat_params[0], c->mat_params[1], c->d_F, c->d_sigma, c->d_strain, c->d_mises);
+    else
+        hipLaunchKernelGGL((k_post<2>), dim3(grid), dim3(bs), 0, c->stream, ngp, large, c->mat_kind, c->d_C,
+                           c->mat_params[0], c->mat_params[1], c->d_F, c->d_sigma, c->d_strain, c->d_mises);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
+int launch_energy(Ctx* c) {
+    const int64_t ngp = (int64_t)c->ne * c->nGP;
+    const int bs = 256, grid = (int)((ngp + bs - 1) / bs);
+    if (c->dm == 3)
+        hipLaunchKernelGGL((k_energy<3>), dim3(grid), dim3(bs), 0, c->stream, ngp, c->mat_kind, c->d_C,
+                           c->mat_params[0], c->mat_params[1], c->d_F, c->d_energy);
+    else
+        hipLaunchKernelGGL((k_energy<2>), dim3(grid), dim3(bs), 0, c->stream, ngp, c->mat_kind, c->d_C,
+                           c->mat_params[0], c->mat_params[1], c->d_F, c->d_energy);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
+int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int width, int comp, double* d_out) {
+    const int64_t total = (int64_t)c->ne * c->npe;
+    hipLaunchKernelGGL(k_extrapolate, dim3((int)((total + 255) / 256)), dim3(256), 0, c->stream, (int64_t)c->ne, c->npe,
+                       c->nGP, width, comp, d_E, d_field, d_out);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
+int launch_energy_sum(Ctx* c, double* total) {
+    const int64_t ngp = (int64_t)c->ne * c->nGP;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ngp + 255) / 256, 1024));
+    hipLaunchKernelGGL(k_dot_partial, dim3(grid), dim3(256), 0, c->stream, ngp, c->d_energy, c->d_vol, c->d_part2);
+    FEMCY_HIP(hipGetLastError());
+    std::vector<double> h(grid);
+    FEMCY_HIP(hipMemcpyAsync(h.data(), c->d_part2, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *total = s;
+    return FEMCY_OK;
+}
+
 // ------------------------------------------------------------------------------- host launchers
 #define FEMCY_DISPATCH_ELEMENT(NPE_, DM_, CALL)                          \
     if (c->npe == NPE_ && c->dm == DM_) {                                \
@@ -455,7 +720,7 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
         launched = true;                                                 \
     }
 
-int launch_geom(Ctx* c, const double* d_u, bool with_stress) {
+int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bool write_sigma) {
     const int bs = 256, grid = (c->ne + bs - 1) / bs;
     bool launched = false;
     size_t th = timing_begin(c, T_GEOM);
@@ -463,7 +728,8 @@ int launch_geom(Ctx* c, const double* d_u, bool with_stress) {
     if (with_stress)                                                                                                \
         hipLaunchKernelGGL((k_geom<NPE, DM, true>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes,  \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \
-                           c->mat_params[1], c->d_dsdx, c->d_vol, c->d_F, c->d_sigma);                             \
+                           c->mat_params[1], write_geom ? c->d_dsdx : nullptr, c->d_vol, c->d_F,                  \
+                           write_sigma ? c->d_sigma : nullptr);                                                     \
     else                                                                                                            \
         hipLaunchKernelGGL((k_geom<NPE, DM, false>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes, \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \

@@ -115,11 +115,16 @@ class ElementBase(abc.ABC):
     def _extrap_basis(self, nat):           # overridden where extrapolation uses another basis
         return self.shapeFunc_pyscope(nat)
 
-    def extrapolate(self, internal_vals, nodal_vals):
-        vals = np.asarray(internal_vals.to_numpy() if hasattr(internal_vals, "to_numpy") else internal_vals)
-        out = vals @ self.extrap_matrix().T
+    def extrapolate(self, internal_vals, nodal_vals, comp: int = 0):
+        """Gauss-point values -> patch-wise nodal values (no averaging across elements).  A device
+        Gauss-point field (`backend.GaussField`) is extrapolated by the HIP kernel of its context;
+        a host array by one matrix product."""
+        if hasattr(internal_vals, "ctx"):
+            out = internal_vals.ctx.extrapolate(internal_vals.which, self.extrap_matrix(), comp)
+        else:
+            out = np.asarray(internal_vals) @ self.extrap_matrix().T
         if hasattr(nodal_vals, "from_numpy"):
             nodal_vals.from_numpy(out)
-        else:
+        elif nodal_vals is not None:
             nodal_vals[...] = out
         return out

@@ -29,7 +29,14 @@ def run(fileName: str, device: int = 0, verbose: bool = True):
     time1 = time.time()
     print(f"\033[40;33;1m system.dof = \n{system.dof.to_numpy()}, "
           f"time for finite element computing is {time1 - time0} s \033[0m")
+    system.get_elasEng()
+    print(f"total elastic energy is {system.elsEng}")
+    system.compute_strain_stress()
+    stress = system.mises_stress.to_numpy()
+    print(f"\033[35;1m max mises_stress at integration point is {stress.max()} MPa \033[0m", end="; ")
     print(f"\033[40;33;1m max dof (disp) = {field_abs_max(system.dof)} \033[0m")
+    system.ELE.extrapolate(system.mises_stress, system.nodal_vals)
+    print(f"\033[35;1m max nodal mises_stress = {np.asarray(system.nodal_vals).max()} \033[0m")
     print(f" solver statistics: {system.stats}")
     return inp, system
 
@@ -38,15 +45,19 @@ def main(argv=None):
     os.system("")
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("inp", nargs="?", default=None)
-    ap.add_argument("--save", default=None, help="write nodes / dof / Cauchy stress to this .npz")
+    ap.add_argument("--save", default=None, help="write results to this .npz, or a legacy .vtk (mesh + displacement + Mises) for ParaView")
     ap.add_argument("--device", type=int, default=int(os.environ.get("FEMCY_DEVICE", "0")))
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
     fileName = args.inp or input("\033[32;1m please give the .inp format's input file path and name: \033[0m")
     inp, system = run(fileName, device=args.device, verbose=not args.quiet)
     if args.save:
-        np.savez(args.save, nodes=inp.nodes, dof=system.dof.to_numpy(),
-                 cauchy_stress=system.cauchy_stress.to_numpy() if inp.geometric_nonlinear else np.zeros(0))
+        if args.save.endswith(".vtk"):
+            from .vtk_out import write_vtk
+            write_vtk(args.save, system)
+        else:
+            np.savez(args.save, nodes=inp.nodes, dof=system.dof.to_numpy(),
+                     cauchy_stress=system.cauchy_stress.to_numpy(), mises_stress=system.mises_stress.to_numpy())
         print(f" saved {args.save}")
 
 

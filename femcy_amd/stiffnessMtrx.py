@@ -14,7 +14,8 @@ Deliberate deviations, all outside the arithmetic of the path:
     same device PCG with a tight tolerance (`direct_eps`, default 1e-12 on max|r|/max|r0|), which
     reproduces the direct-solve control flow of every shipped deck to ~1e-11; at >= 1e5 DOF the
     reference's own CG settings (eps = 1e-3) apply.
-  * windows / PNG output are not produced (`show_newton_steps`, `save2path` are accepted and ignored).
+  * windows / PNG output are not produced (`show_newton_steps`, `save2path` are accepted and ignored);
+    `femcy_amd.vtk_out.write_vtk` writes the mesh, displacements and Mises stress for ParaView instead.
   * the reference raises UnboundLocalError when the very first residual is < 1e-9
     (`newton_loop` unbound, :767-822); here that case returns (True, 0).
 """
@@ -65,6 +66,10 @@ class System_of_equations:
         g = self.ctx.gauss_field
         self.F, self.cauchy_stress = g(be.GP_F), g(be.GP_SIGMA)
         self.dsdx, self.vol = g(be.GP_DSDX), g(be.GP_VOL)
+        self.strain, self.mises_stress, self.elsEngDens = g(be.GP_STRAIN), g(be.GP_MISES), g(be.GP_ENERGY)
+        self.visualize_field = self.mises_stress
+        self.nodal_vals = HostField(np.zeros((self.ctx.ne, self.ctx.npe)))
+        self.elsEng = 0.0
         self.sparseMtrx_rowMajor = self          # what the reference hands to the CG class
         self.sparseIJ = None
 
@@ -297,9 +302,12 @@ class System_of_equations:
 
     # -------------------------------------------------------------------- post-processing
     def compute_strain_stress(self):
-        raise NotImplementedError("device post-processing (strain / stress / Mises) is SURVEY.md 8(f) 'next'; "
-                                  "F and the Cauchy stress of the last force evaluation are available as "
-                                  "system.F.to_numpy() / system.cauchy_stress.to_numpy()")
+        """F, strain (infinitesimal / Green), Cauchy stress (small deformation: constitutiveOfSmallDeform;
+        nlgeom: the stress of the last force evaluation) and von Mises stress per Gauss point, on the device
+        (reference :436-501).  Results: .F, .strain, .cauchy_stress, .mises_stress (`.to_numpy()`)."""
+        self.ctx.compute_strain_stress(be.VEC_DOF, large=self.geometric_nonlinear)
 
     def get_elasEng(self):
-        raise NotImplementedError("elastic energy is SURVEY.md 8(f) 'next'")
+        """total elastic energy = sum over Gauss points of elasticEnergyDensity(F) * vol (reference :592-606)."""
+        self.elsEng = self.ctx.elastic_energy(be.VEC_DOF)
+        return self.elsEng

@@ -69,7 +69,10 @@ enum femcy_gpfield {
     FEMCY_GP_DSDX = 0,   /* f64[ne][nGP][npe][dm] */
     FEMCY_GP_VOL = 1,    /* f64[ne][nGP]          */
     FEMCY_GP_F = 2,      /* f64[ne][nGP][dm][dm]  */
-    FEMCY_GP_SIGMA = 3   /* f64[ne][nGP][dm][dm]  */
+    FEMCY_GP_SIGMA = 3,  /* f64[ne][nGP][dm][dm]  */
+    FEMCY_GP_STRAIN = 4, /* f64[ne][nGP][dm][dm]  (after femcy_compute_strain_stress) */
+    FEMCY_GP_MISES = 5,  /* f64[ne][nGP]          */
+    FEMCY_GP_ENERGY = 6  /* f64[ne][nGP] elastic energy density (after femcy_elastic_energy) */
 };
 
 /* assembly strategy (femcy_set_option FEMCY_OPT_ASSEMBLY) */
@@ -155,6 +158,17 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec);
  * Jacobi-PCG, x0 = 0, stop when max|r| < eps*max|r0|, at most maxit iterations (reference: n). */
 int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, int32_t* iters,
               double* rmax0, double* rmax);
+
+/* ------------------------------------------------------------------------ post-processing */
+/* compute_strain_stress (stiffnessMtrx.py:436-501): F at vec[u]; strain (infinitesimal, or Green when
+ * large != 0); Cauchy stress by constitutiveOfSmallDeform when large == 0 (kept from the last
+ * femcy_internal_force otherwise, as in the reference); von Mises stress by material type */
+int femcy_compute_strain_stress(femcy_ctx* ctx, int u_vec, int large);
+/* get_elasEng (stiffnessMtrx.py:592-606): F at vec[u], elasticEnergyDensity, sum(density * vol) with the
+ * vol left by the last geometry pass (reference behaviour) */
+int femcy_elastic_energy(femcy_ctx* ctx, int u_vec, double* total);
+/* ELE.extrapolate (element_zoo): out[e][a] = sum_g E[a][g] * field[e][g][comp]; E is npe x nGP */
+int femcy_extrapolate(femcy_ctx* ctx, int gp_field, int comp, const double* E, double* out /*[ne*npe]*/);
 
 /* --------------------------------------------------------------------- inspection (tests) */
 /* the reference's sparseIJ / sparseMtrx_rowMajor layouts (stiffnessMtrx.py:78-94) */

@@ -29,6 +29,17 @@ CASES = [  # (deck, tolerance)
 ]
 
 
+def run_keep(name):
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    inp = InpInfo(deck(name + ".inp"))
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    system.solve(inp)
+    return system, system.dof.to_numpy()
+
+
 def run(name):
     from femcy_amd.body import Body
     from femcy_amd.reader import InpInfo
@@ -61,3 +72,27 @@ def test_deck_displacements(name, tol):
 def test_twist_prescribed_rotation():
     system, u = run("twist_plate_C3D4")
     assert abs(np.abs(u).max() - 80.0) < 1e-9               # 180 degrees about (40, 5): max |u| = plate width
+
+
+def test_readme_known_answer_end_to_end(tmp_path):
+    """README.md:66-71 through the whole product path on the device: CPS6 sigma_yy at D = 93.32 (node) /
+    84.40 (Gauss point); CPS3 max sigma_yy = 93.45 (the README's Abaqus column)."""
+    system, u = run_keep("ellip_membrane_quadritic_trig_neumann")
+    system.compute_strain_stress()
+    sig = system.cauchy_stress.to_numpy()
+    nodal = system.ELE.extrapolate(system.cauchy_stress, None, comp=3)          # sigma_yy = component (1,1) of 2x2
+    nodes, el = system.body.np_nodes, system.body.np_elements
+    nD = int(np.argmin(np.linalg.norm(nodes - np.array([2., 0.]), axis=1)))
+    e, a = np.where(el == nD)
+    assert abs(nodal[e[0], a[0]] - 93.32) < 0.01 and abs(sig[e[0], :, 1, 1].max() - 84.40) < 0.005
+    from femcy_amd.vtk_out import write_vtk
+    write_vtk(str(tmp_path / "out.vtk"), system)
+    assert (tmp_path / "out.vtk").read_text().count("CELL_TYPES") == 1
+    system.ctx.close()
+    system, u = run_keep("ellip_membrane_linEle_localVeryFine")
+    system.compute_strain_stress()
+    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - 93.45) < 0.005
+    e0 = system.get_elasEng()
+    rhs_work = 0.5 * float(system.rhs.to_numpy() @ u)      # linear elasticity: W = 1/2 f.u (Dirichlet values are 0)
+    assert e0 > 0 and abs(e0 - rhs_work) < 1e-3 * e0       # Green strain in the energy: equal up to O(|grad u|)
+    system.ctx.close()

@@ -225,3 +225,52 @@ def test_errors_are_reported_not_fatal(gpu_ctx_factory):
         ctx.set_mesh(np.zeros((3, 3)), np.array([[0, 1, 2, 7]]))    # node id out of range
     with pytest.raises(be.FemcyError):
         be.Context(99)
+
+
+@pytest.mark.parametrize("name", DECKS)
+@pytest.mark.parametrize("large", [False, True])
+def test_postprocessing(gpu_ctx_factory, name, large):
+    """compute_strain_stress / get_elasEng / extrapolate on the device vs the oracle's restatement
+    (stiffnessMtrx.py:436-606, constitutiveOfSmallDeform x4, elasticEnergyDensity x4, extrapolate x6)."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ed = elem_def(et)
+    om = oracle_material(mat)
+    u = smooth_disp(inp.nodes, 0.03 if large else 1e-4)
+    ctx.upload(be.VEC_DOF, u)
+    if large:
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)          # leaves the large-deformation Cauchy stress
+    else:
+        ctx.assemble_K(-1)                                    # vol of the reference configuration, as in a linear run
+    dsdx_before = ctx.gauss_field(be.GP_DSDX).to_numpy()
+    ctx.compute_strain_stress(be.VEC_DOF, large=large)
+    F = orc.deformation_gradient(inp.nodes, el, u, ed)
+    assert rel(ctx.gauss_field(be.GP_F).to_numpy(), F) < 1e-13
+    I = np.eye(ed.dm)
+    strain = (np.swapaxes(F, -1, -2) @ F - I) / 2 if large else (F + np.swapaxes(F, -1, -2)) / 2 - I
+    assert np.abs(ctx.gauss_field(be.GP_STRAIN).to_numpy() - strain).max() < 1e-14      # absolute: strain = F - I cancels
+    sig = orc.cauchy_large(om, F) if large else orc.cauchy_small(om, F)
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), sig) < 1e-10
+    s3 = np.zeros(sig.shape[:-2] + (3, 3))
+    s3[..., :ed.dm, :ed.dm] = sig
+    if om.type == "planeStrain":
+        s3[..., 2, 2] = om.params[1] * (sig[..., 0, 0] + sig[..., 1, 1])
+    dev = s3 - np.eye(3) * (np.trace(s3, axis1=-2, axis2=-1) / 3.)[..., None, None]
+    mises = np.sqrt(1.5 * np.sum(dev * dev, axis=(-2, -1)))
+    assert rel(ctx.gauss_field(be.GP_MISES).to_numpy(), mises) < 1e-10
+    assert np.array_equal(ctx.gauss_field(be.GP_DSDX).to_numpy(), dsdx_before)     # geometry untouched
+    # energy: density * vol with the vol left by the last geometry pass
+    vol = ctx.gauss_field(be.GP_VOL).to_numpy()
+    dens = orc.energy_density(om, F)
+    tot = ctx.elastic_energy(be.VEC_DOF)
+    etol = 1e-9 if large else 1e-6      # tiny strains: psi = O(eps^2) is a difference of O(1) terms (Neo-Hookean: I1 - 3 - 2 ln J)
+    assert rel(ctx.gauss_field(be.GP_ENERGY).to_numpy(), dens) < etol
+    assert abs(tot - np.sum(dens * vol)) < etol * abs(np.sum(dens * vol))
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), sig) < 1e-10                # energy pass leaves sigma alone
+    # extrapolation to patch-wise nodal values, scalar and tensor component
+    nod = inp.ELE.extrapolate(ctx.gauss_field(be.GP_MISES), None)
+    assert rel(nod, mises @ ed.extrap.T) < 1e-10
+    comp = 1 * ed.dm + 1
+    nod = ctx.extrapolate(be.GP_SIGMA, inp.ELE.extrap_matrix(), comp)
+    assert np.abs(nod - sig[..., 1, 1] @ ed.extrap.T).max() < 1e-10 * np.abs(sig).max()
