@@ -36,8 +36,12 @@ struct PcgState {
     double r0;       // max|r0|
     double rmax;     // max|r| after the last completed iteration
     double dAd;      // multi-rank: reduced d.Ad
-    int32_t iters;   // completed iterations
+    double eps;      // stopping tolerance of this solve (kept on the device so that kernel arguments are
+                     // solve-independent and a burst of iterations can be replayed from a hipGraph)
+    int32_t iters;   // completed iterations (written by k_update_d, read by k_update_xr of the next iteration)
+    int32_t it_k3;   // iteration index handed from k_update_xr to k_update_d
     int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown
+    int32_t pad_;
 };
 
 // contiguous slice range of each XCD for the SpMV (balanced by stored blocks), passed by value
@@ -107,6 +111,12 @@ struct Ctx {
     double* d_val_scratch = nullptr;
     int64_t scratch_cap = 0;
 
+    // ---- hipGraph of one poll-burst of PCG iterations (single rank, timing off)
+    hipGraphExec_t pcg_graph = nullptr;
+    const double* pcg_graph_x = nullptr;
+    int pcg_graph_iters = 0, pcg_graph_g = 0, pcg_graph_np1 = 0;
+    int opt_graph = 1;
+
     // ---- options / timing
     int opt_assembly = FEMCY_ASM_GATHER;
     int opt_poll = 32;
@@ -159,6 +169,7 @@ int vec_sumsq(Ctx* c, const double* d, double* out);
 int vec_absmax(Ctx* c, const double* d, double* out);
 int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k);
 int ensure_scratch(Ctx* c, int64_t k);
+void set_ew_cap(int cap);
 // comm.cpp
 int comm_unique_id(void* id128);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
@@ -166,6 +177,7 @@ int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
 int comm_destroy(Ctx* c);
 int iface_sum(Ctx* c, double* d_v);
+void pcg_graph_reset(Ctx* c);
 
 }  // namespace femcy
 

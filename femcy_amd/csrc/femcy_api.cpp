@@ -180,6 +180,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
+    pcg_graph_reset(c);
     dev_free(&c->d_nodes); dev_free(&c->d_elems); dev_free(&c->d_dN); dev_free(&c->d_w); dev_free(&c->d_C);
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr);
@@ -217,6 +218,13 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case FEMCY_OPT_TIMING:
             if (!value) timing_collect(c);
             c->opt_timing = value < 0 ? 0 : (int)value;
+            break;
+        case FEMCY_OPT_EW_GRID:
+            set_ew_cap((int)value);
+            break;
+        case FEMCY_OPT_PCG_GRAPH:
+            FEMCY_REQUIRE(value >= 0 && value <= 2, "graph mode must be 0 (off), 1 (auto) or 2 (always)");
+            c->opt_graph = (int)value;
             break;
         case FEMCY_OPT_SPMV_VARIANT:
             c->opt_spmv_variant = (int)value;
@@ -261,6 +269,7 @@ int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, 
     if ((rc = dev_alloc(&c->d_r, nalloc)) || (rc = dev_alloc(&c->d_d, nalloc)) || (rc = dev_alloc(&c->d_M, nalloc)) ||
         (rc = dev_alloc(&c->d_Ad, nalloc)))
         return rc;
+    pcg_graph_reset(c);
     c->have_mesh = true;
     c->have_element = c->have_pattern = false;
     return FEMCY_OK;
@@ -314,6 +323,7 @@ int femcy_build_pattern(femcy_ctx* ctx) {
     CTX_OR_FAIL(ctx);
     FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
     FEMCY_HIP(hipStreamSynchronize(c->stream));
+    pcg_graph_reset(c);
     int rc = build_pattern(c);
     if (rc) return rc;
     c->have_pattern = true;

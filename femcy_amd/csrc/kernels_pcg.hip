@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(BS) k_pcg_init(int64_t n2, const double2* __re
 }
 
 __global__ void __launch_bounds__(BS) k_pcg_init_final(int np, const double* __restrict__ part2, PcgState* st,
-                                                       const double* __restrict__ gathered, int nranks) {
+                                                       const double* __restrict__ gathered, int nranks, double eps) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     double s = 0.0, m = 0.0;
     if (gathered) {   // multi-rank: (sum, max) pairs already reduced per rank
@@ -199,13 +199,15 @@ __global__ void __launch_bounds__(BS) k_pcg_init_final(int np, const double* __r
         st->rmax = m;
         st->dAd = 0.0;
         st->iters = 0;
+        st->it_k3 = 0;
+        st->eps = eps;
         st->done = (m == 0.0) ? 1 : ((m != m || isinf(m)) ? 2 : 0);
     }
 }
 
 // x += alpha d; r -= alpha Ad; partials (r.M.r, max|r|)
-__global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, const double* __restrict__ part1,
-                                                  const double* __restrict__ dAd_reduced, const PcgState* st,
+__global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const double* __restrict__ part1,
+                                                  const double* __restrict__ dAd_reduced, PcgState* st,
                                                   const double2* __restrict__ d, const double2* __restrict__ Ad,
                                                   const double2* __restrict__ M, double2* __restrict__ x,
                                                   double2* __restrict__ r, const uint8_t* __restrict__ owner,
@@ -224,6 +226,8 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, c
         xv = x[i];
         rv = r[i];
     }
+    const int it = st->iters;                       // stable: written by the previous iteration's k_update_d
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->it_k3 = it;
     const double dAd = dAd_reduced ? *dAd_reduced : reduce_partials_sum(part1, np1, sm1);
     const double alpha = st->rMr[it & 1] / dAd;
     double rMr = 0.0, rm = 0.0;
@@ -258,9 +262,8 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int it, int np1, c
 }
 
 // d = M r + beta d; publish scalars and the stopping decision
-__global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int it, int np2, const double* __restrict__ part2,
-                                                 const double* __restrict__ gathered, int nranks, double eps,
-                                                 PcgState* st, const double2* __restrict__ r,
+__global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const double* __restrict__ part2,
+                                                 const double* __restrict__ gathered, int nranks, PcgState* st, const double2* __restrict__ r,
                                                  const double2* __restrict__ M, double2* __restrict__ d) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->done) return;
@@ -287,6 +290,8 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int it, int np2, co
     }
     const double rMr_new = block_sum(s, sm1);
     const double rmax = block_max(m, sm2);
+    const int it = st->it_k3;                       // stable: written by this iteration's k_update_xr
+    const double eps = st->eps;
     const double rMr_old = st->rMr[it & 1];
     const double r0 = st->r0;
     const double beta = rMr_new / rMr_old;
@@ -382,9 +387,11 @@ __global__ void __launch_bounds__(BS) k_reduce_final(int np, const double* __res
     if (threadIdx.x == 0) *out = t;
 }
 
+static int g_ew_cap = 512;   // FEMCY_OPT_EW_GRID: cap on workgroups of the element-wise kernels (tuning knob)
+void set_ew_cap(int cap) { g_ew_cap = std::max(1, std::min(cap, MAX_PARTIALS)); }
 static inline int ew_grid(int64_t n) {
     int64_t g = (n + BS - 1) / BS;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, g_ew_cap));
 }
 
 int vec_fill(Ctx* c, double* d, double v, int64_t n) {
@@ -441,7 +448,16 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     const bool sample = c->opt_timing == 1 || (c->opt_timing > 1 && (c->spmv_count++ % c->opt_timing) == 0);
     EventPair* ev = sample ? timing_acquire(c, T_SPMV) : nullptr;
     hipEvent_t ea = ev ? ev->a : nullptr, eb = ev ? ev->b : nullptr;
-    if (c->dm == 3)
+    if (!ev) {   // plain launch (also the form that is captured into the PCG hipGraph)
+        if (c->dm == 3)
+            hipLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->xcd,
+                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
+                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
+        else
+            hipLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->xcd,
+                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
+                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
+    } else if (c->dm == 3)
         hipExtLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->xcd,
                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
@@ -468,6 +484,12 @@ int iface_sum(Ctx* c, double* d_v) {
                            c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, d_v);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
+}
+
+void pcg_graph_reset(Ctx* c) {
+    if (c->pcg_graph) (void)hipGraphExecDestroy(c->pcg_graph);
+    c->pcg_graph = nullptr;
+    c->pcg_graph_x = nullptr;
 }
 
 // ----------------------------------------------------------------------------------------- PCG
@@ -500,44 +522,83 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_pcg_init_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, c->d_state,
-                       (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks);
+                       (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, eps);
     FEMCY_HIP(hipGetLastError());
 
-    int np1 = 0;
+    // one CG iteration = 3 launches (+ the exchange in multi-rank mode); nothing in their arguments depends on
+    // the iteration number or on eps (both live in PcgState), so a burst can be captured once and replayed
+    auto enqueue_iteration = [&]() -> int {
+        int np1 = 0;
+        int rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1);
+        if (rc) return rc;
+        const double* dAd_red = nullptr;
+        if (multi) {
+            // interface rows of Ad hold partial sums: pack them + the local d.Ad, all-reduce, unpack
+            double* slot = c->d_commbuf + c->niface_global;
+            FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, c->stream, np1, c->d_part1, slot);
+            if (c->niface_local > 0)
+                hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
+                                   c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_Ad, c->d_commbuf);
+            if ((rc = comm_allreduce_sum(c, c->d_commbuf, (int64_t)c->niface_global + 1))) return rc;
+            if (c->niface_local > 0)
+                hipLaunchKernelGGL(k_iface_unpack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
+                                   c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
+            dAd_red = slot;
+        }
+        hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red, c->d_state,
+                           (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)d_x,
+                           (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2);
+        if (multi) {
+            double* pair = c->d_commbuf + c->niface_global + 2;
+            hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, pair);
+            if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
+        }
+        hipLaunchKernelGGL(k_update_d, dim3(g), dim3(BS), 0, c->stream, n2, g, c->d_part2,
+                           (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state,
+                           (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d);
+        return FEMCY_OK;
+    };
+
+    // hipGraph of one poll-burst: removes the per-launch host cost, which dominates below ~1e5 DOF
+    const int P = c->opt_poll;
+    // measured on MI355X: replay is ~17 % faster end-to-end on a 969-DOF deck (launch-bound) and ~2 us per
+    // iteration SLOWER at 548 535 DOF (GPU-bound), so "auto" (1) only uses it below 2e5 DOF; 2 forces it on
+    const bool want_graph = c->opt_graph == 2 || (c->opt_graph == 1 && c->n < 200000);
+    const bool use_graph = want_graph && !multi && !c->opt_timing && maxit >= P;
+    if (use_graph && (!c->pcg_graph || c->pcg_graph_x != d_x || c->pcg_graph_iters != P || c->pcg_graph_g != g ||
+                      c->pcg_graph_np1 != c->spmv_grid)) {
+        pcg_graph_reset(c);
+        hipGraph_t graph = nullptr;
+        FEMCY_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = FEMCY_OK;
+        for (int k = 0; k < P && !rc; ++k) rc = enqueue_iteration();
+        hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        FEMCY_HIP(ce);
+        FEMCY_HIP(hipGraphInstantiate(&c->pcg_graph, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        c->pcg_graph_x = d_x;
+        c->pcg_graph_iters = P;
+        c->pcg_graph_g = g;
+        c->pcg_graph_np1 = c->spmv_grid;
+    }
+
     int32_t it = 0;
     bool finished = false;
     while (!finished) {
-        const int32_t burst_end = (int32_t)std::min<int64_t>((int64_t)it + c->opt_poll, maxit);
-        for (; it < burst_end; ++it) {
-            int rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1);
-            if (rc) return rc;
-            const double* dAd_red = nullptr;
-            if (multi) {
-                // interface rows of Ad hold partial sums: pack them + the local d.Ad, all-reduce, unpack
-                double* slot = c->d_commbuf + c->niface_global;
-                FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
-                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, c->stream, np1, c->d_part1, slot);
-                if (c->niface_local > 0)
-                    hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
-                                       c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_Ad, c->d_commbuf);
-                if ((rc = comm_allreduce_sum(c, c->d_commbuf, (int64_t)c->niface_global + 1))) return rc;
-                if (c->niface_local > 0)
-                    hipLaunchKernelGGL(k_iface_unpack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
-                                       c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
-                dAd_red = slot;
+        if (use_graph && (int64_t)it + P <= maxit) {
+            FEMCY_HIP(hipGraphLaunch(c->pcg_graph, c->stream));
+            it += P;
+        } else {
+            const int32_t burst_end = (int32_t)std::min<int64_t>((int64_t)it + P, maxit);
+            for (; it < burst_end; ++it) {
+                int rc = enqueue_iteration();
+                if (rc) return rc;
             }
-            hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(BS), 0, c->stream, n2, (int)it, np1, c->d_part1, dAd_red,
-                               c->d_state, (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M,
-                               (double2*)d_x, (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr),
-                               c->d_part2);
-            if (multi) {
-                double* pair = c->d_commbuf + c->niface_global + 2;
-                hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, pair);
-                if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
-            }
-            hipLaunchKernelGGL(k_update_d, dim3(g), dim3(BS), 0, c->stream, n2, (int)it, g, c->d_part2,
-                               (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, eps, c->d_state,
-                               (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d);
         }
         FEMCY_HIP(hipGetLastError());
         FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));

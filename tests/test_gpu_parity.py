@@ -187,6 +187,14 @@ def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
         if it == ito:
             assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < tol
         assert np.abs(K @ x - bb).max() < 2 * eps * r0 + 1e-9 * r0     # it solves the system
+    # hipGraph replay of poll-bursts is bit-identical to plain launches
+    it_g, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+    x_g = ctx.download(be.VEC_X)
+    for mode in (0, 2):
+        ctx.set_option(be.OPT_PCG_GRAPH, mode)
+        it_p, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+        assert it_p == it_g and np.array_equal(ctx.download(be.VEC_X), x_g)
+    ctx.set_option(be.OPT_PCG_GRAPH, 1)
     # maxit honoured, poll interval irrelevant to the result
     ctx.set_option(be.OPT_PCG_POLL, 3)
     it5, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=5)

@@ -76,6 +76,14 @@ def main():
         dt = time.perf_counter() - t0
         print(f"pcg poll={poll}: {it} iters in {dt*1e3:.2f} ms -> {it/dt:.0f} it/s, {dt/it*1e6:.1f} us/it, "
               f"{(spmv_bytes + 88*n)*it/dt/1e9:.0f} GB/s algorithmic")
+    for cap in (128, 256, 512, 1024, 2048, 4096):
+        ctx.set_option(be.OPT_EW_GRID, cap)
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=50)
+        t0 = time.perf_counter()
+        it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=500)
+        dt = time.perf_counter() - t0
+        print(f"pcg ew_cap={cap}: {dt/it*1e6:.2f} us/it")
+    ctx.set_option(be.OPT_EW_GRID, 2048)
     t0 = time.perf_counter()
     it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
     dt = time.perf_counter() - t0
