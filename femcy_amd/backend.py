@@ -41,7 +41,14 @@ EXPORTS = [
 
 
 class FemcyError(RuntimeError):
-    pass
+    """a non-zero femcy_status; `.status` carries the code (include/femcy.h)."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+FEMCY_ENUMERIC = -4
 
 
 class PatternInfo(C.Structure):
@@ -181,7 +188,7 @@ class Context:
     def _call(self, name, *args):
         rc = getattr(self.lib, name)(self._h, *args)
         if rc != 0:
-            raise FemcyError(f"{name} -> {rc}: {self.lib.femcy_last_error().decode()}")
+            raise FemcyError(f"{name} -> {rc}: {self.lib.femcy_last_error().decode()}", status=rc)
 
     def close(self):
         if getattr(self, "_h", None):

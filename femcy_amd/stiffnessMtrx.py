@@ -266,7 +266,15 @@ class System_of_equations:
             newton_loop += 1
             if newton_loop >= 24:
                 return False, newton_loop
-            du = self.solve_dof()                     # dof -= K^-1 residual
+            try:
+                du = self.solve_dof()                 # dof -= K^-1 residual
+            except be.FemcyError as e:
+                if e.status != be.FEMCY_ENUMERIC:
+                    raise
+                # the reference's solvers would hand back Inf/NaN here and trip the NaN test below on the
+                # next residual; the device PCG reports the breakdown instead -> same outcome: cut the step
+                self._say("linear solve broke down (NaN/Inf), automatically recompute with smaller time step")
+                return False, newton_loop
             residual = self._residual(dirichletBCs)
             if np.isnan(residual):
                 self._say("NaN occurs, automatically recompute with smaller time step")
