@@ -118,7 +118,7 @@ struct Ctx {
     int opt_graph = 1;
 
     // ---- options / timing
-    int opt_assembly = FEMCY_ASM_GATHER;
+    int opt_assembly = FEMCY_ASM_AUTO;
     int opt_poll = 32;
     int opt_timing = 0;               // 0 off, 1 every launch, k > 1: every k-th SpMV launch
     int64_t spmv_count = 0;

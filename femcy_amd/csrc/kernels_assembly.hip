@@ -348,6 +348,65 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
     for (int k = 0; k < DM * DM; ++k) Kvals[(row * (DM * DM) + k) * SLICE + lane] = acc[k];
 }
 
+// row-centric assembly: one wavefront per node (matrix block row).  Lanes are the (incident element, local
+// column node) pairs of the row -- 24 x 4 = 96 for an interior C3D4 node -- so the four lanes of one element read
+// one contiguous 96-byte dsdx record (1 cache line per element instead of 1 per lane), every lane evaluates
+// exactly one B_a^T C B_b block (no trip-count imbalance between diagonal and off-diagonal blocks), and the row
+// is reduced in a wave-private LDS accumulator with ds_add_f64 before it is written out.  Deterministic: the
+// accumulator is private to the wave and LDS serves conflicting lanes of one instruction in lane order.
+template <int DM>
+__global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, int32_t nGP, int32_t Lmax,
+                                                       const int32_t* __restrict__ ne_ptr,
+                                                       const int32_t* __restrict__ ne_idx,
+                                                       const uint16_t* __restrict__ slotj,
+                                                       const int32_t* __restrict__ rowlen,
+                                                       const int64_t* __restrict__ slice_off,
+                                                       const double* __restrict__ dsdx,
+                                                       const double* __restrict__ vol, const double* __restrict__ C,
+                                                       double* __restrict__ Kvals) {
+    extern __shared__ __attribute__((aligned(16))) double lds_rows[];
+    constexpr int DD = DM * DM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* acc = lds_rows + (size_t)wave * Lmax * DD;
+    for (int32_t base = blockIdx.x * 4; base < nn; base += gridDim.x * 4) {   // uniform trip count per workgroup
+        const int32_t a = base + wave;
+        const bool valid = a < nn;
+        const int32_t L = valid ? rowlen[a] : 0;
+        for (int idx = lane; idx < L * DD; idx += 64) acc[idx] = 0.0;
+        __syncthreads();
+        if (valid) {
+            const int32_t k0 = ne_ptr[a];
+            const int32_t ntask = (ne_ptr[a + 1] - k0) * npe;
+            for (int32_t t = lane; t < ntask; t += 64) {
+                const int32_t kk = t / npe, lb = t - kk * npe;
+                const int32_t code = ne_idx[k0 + kk];          // e*npe + la
+                const int64_t e = code / npe;
+                const int32_t la = code - (int32_t)e * npe;
+                const int32_t j = slotj[(int64_t)code * npe + lb];
+                double blk[DD];
+#pragma unroll
+                for (int k = 0; k < DD; ++k) blk[k] = 0.0;
+                for (int g = 0; g < nGP; ++g) {
+                    const int64_t row = (e * nGP + g) * npe;
+                    kblock_add<DM>(dsdx + (row + la) * DM, dsdx + (row + lb) * DM, C, vol[e * nGP + g], blk);
+                }
+#pragma unroll
+                for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            const int64_t off = slice_off[a >> 6];
+            const int lanea = a & 63;
+            for (int idx = lane; idx < L * DD; idx += 64) {
+                const int j = idx / DD, k = idx - j * DD;
+                Kvals[((off + j) * DD + k) * SLICE + lanea] = acc[idx];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // scatter assembly with hardware f64 atomics: one lane per element-local (a,b) block
 template <int DM>
 __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t npe, int32_t nGP,
@@ -753,7 +812,20 @@ int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bo
 int launch_assemble(Ctx* c) {
     const int bs = 256;
     size_t th = timing_begin(c, T_ASM);
-    if (c->opt_assembly == FEMCY_ASM_ATOMIC) {
+    int mode = c->opt_assembly;
+    if (mode == FEMCY_ASM_AUTO) mode = (c->npe > 4) ? FEMCY_ASM_ROWS : FEMCY_ASM_GATHER;
+    if (mode == FEMCY_ASM_ROWS) {
+        const int grid = std::min((c->nn + 3) / 4, 256 * 16);
+        const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);
+        if (c->dm == 3)
+            hipLaunchKernelGGL((k_assemble_rows<3>), dim3(grid), dim3(bs), lds, c->stream, c->nn, c->npe, c->nGP,
+                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_slice_off,
+                               c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
+        else
+            hipLaunchKernelGGL((k_assemble_rows<2>), dim3(grid), dim3(bs), lds, c->stream, c->nn, c->npe, c->nGP,
+                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_slice_off,
+                               c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
+    } else if (mode == FEMCY_ASM_ATOMIC) {
         FEMCY_HIP(hipMemsetAsync(c->d_Kvals, 0, (size_t)c->stored_rows * c->dm * c->dm * SLICE * sizeof(double),
                                  c->stream));
         const int64_t npair = (int64_t)c->ne * c->npe * c->npe;

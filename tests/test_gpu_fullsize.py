@@ -102,7 +102,13 @@ def test_fullsize_properties(full):
     ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ATOMIC)
     ctx.assemble_K(be.VEC_DOF)
     assert np.abs(Kx(x) - Kx1).max() < 1e-12 * scale
-    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_GATHER)
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ROWS)
+    ctx.assemble_K(be.VEC_DOF)
+    y_rows = Kx(x)
+    assert np.abs(y_rows - Kx1).max() < 1e-12 * scale
+    ctx.assemble_K(be.VEC_DOF)
+    assert np.array_equal(Kx(x), y_rows)                                # row-centric variant is deterministic too
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_AUTO)
     ctx.assemble_K(be.VEC_DOF)
     # Dirichlet: constrained rows/columns become identity
     b = rng.standard_normal(ctx.n)

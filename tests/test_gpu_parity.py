@@ -59,7 +59,7 @@ def smooth_disp(nodes, scale):
 
 
 @pytest.mark.parametrize("name", DECKS)
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_assemble_K(gpu_ctx_factory, name, mode):
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
@@ -282,3 +282,65 @@ def test_postprocessing(gpu_ctx_factory, name, large):
     comp = 1 * ed.dm + 1
     nod = ctx.extrapolate(be.GP_SIGMA, inp.ELE.extrap_matrix(), comp)
     assert np.abs(nod - sig[..., 1, 1] @ ed.extrap.T).max() < 1e-10 * np.abs(sig).max()
+
+
+@pytest.mark.parametrize("name,etype", [("ellip_membrane_linEle_localVeryFine.inp", "CPS3"), ("ellip_CPS4.inp", "CPS4"),
+                                        ("ellip_membrane_quadritic_trig_neumann.inp", "CPS6"),
+                                        ("ellip_CPS8.inp", "CPS8"), ("twist_plate_C3D4.inp", "C3D4"),
+                                        ("twist_C3D10_coarse.inp", "C3D10")])
+def test_single_element_against_golden_vectors(gpu_ctx_factory, name, etype):
+    """smallest possible input: a one-element mesh.  The device K is the committed golden element
+    stiffness (tests/golden/oracle_element_vectors.npz), dsdx / vol likewise."""
+    import os
+    from helpers import GOLDEN
+    from femcy_amd import backend as be
+    g = np.load(os.path.join(GOLDEN, "oracle_element_vectors.npz"))
+    inp, et, el, mat = load(name)
+    assert et == etype
+    ids = el[0]
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(inp.nodes[ids], np.arange(ids.size, dtype=np.int32)[None, :])
+    ctx.set_element(inp.ELE)
+    ctx.set_material(mat)
+    info = ctx.build_pattern()
+    assert info.nnzb == ids.size ** 2 and info.nslices == 1
+    for mode in (be.ASM_GATHER, be.ASM_ROWS, be.ASM_ATOMIC):
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(-1)
+        K = ctx.get_K_bsr().toarray()
+        assert np.abs(K - g[etype]).max() <= 1e-12 * np.abs(g[etype]).max()
+    assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy()[0], g[etype + "/dsdx"]) < 1e-13
+    assert rel(ctx.gauss_field(be.GP_VOL).to_numpy()[0], g[etype + "/vol"]) < 1e-13
+
+
+def test_edge_cases(gpu_ctx_factory):
+    """empty Dirichlet lists, maxit below the poll interval, zero right-hand side, a node that belongs to no
+    element (zero diagonal -> reported breakdown, not a hang), odd DOF counts."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load("twist_plate_C3D4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    assert ctx.n % 2 == 1                                        # 969: exercises the double2 tail
+    ctx.assemble_K(-1)
+    ctx.dirichlet_newton(np.zeros(0, dtype=np.int32), be.VEC_RESIDUAL)              # k = 0 is a no-op
+    ctx.dirichlet_linear(np.zeros(0, dtype=np.int32), np.zeros(0), be.VEC_RHS)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in inp.dirichlet_bc_info]))
+    ctx.vector(be.VEC_RESIDUAL).fill(0.0)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)                      # b = 0: x = 0 at once
+    assert it == 0 and r0 == 0.0 and not ctx.download(be.VEC_X).any()
+    ctx.upload(be.VEC_RESIDUAL, np.where(np.isin(np.arange(ctx.n), cons), 0.0, 1.0))
+    it, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=1)                 # maxit < poll interval
+    assert it == 1
+    # an isolated node: zero diagonal block -> M = inf -> NaN, reported as FEMCY_ENUMERIC
+    nodes2 = np.vstack([inp.nodes, [[1e3, 1e3, 1e3]]])
+    ctx2 = gpu_ctx_factory()
+    ctx2.set_mesh(nodes2, el)
+    ctx2.set_element(inp.ELE)
+    ctx2.set_material(mat)
+    info = ctx2.build_pattern()
+    assert info.nnzb == ctx.pattern_info().nnzb + 1
+    ctx2.assemble_K(-1)
+    ctx2.upload(be.VEC_RESIDUAL, np.ones(ctx2.n))
+    with pytest.raises(be.FemcyError) as ei:
+        ctx2.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3, maxit=10)
+    assert ei.value.status == be.FEMCY_ENUMERIC
