@@ -30,6 +30,20 @@ void set_error(const char* fmt, ...);
 constexpr int SLICE = 64;           // nodes per SELL slice = one wavefront
 constexpr int MAX_PARTIALS = 4096;  // upper bound on per-launch reduction partials
 
+// Position of entry k (= r*dm + c) of the dm x dm block stored in block-row `row` for lane `lane`.
+// Entries are interleaved in pairs, [row][k/2][lane][k%2] with the odd last entry (dm = 3: k = 8) as a
+// trailing [lane] plane, so that a lane reads/writes two consecutive doubles per instruction: a wavefront
+// moves 1 KiB per 16-byte load (4 + one 8-byte load per 3x3 block instead of 9 8-byte loads).
+template <int DM>
+__host__ __device__ __forceinline__ int64_t kv_index(int64_t row, int k, int lane) {
+    constexpr int DD = DM * DM, NP = DD / 2;
+    const int64_t base = row * (int64_t)(DD * SLICE);
+    return (k < 2 * NP) ? base + (k >> 1) * (2 * SLICE) + lane * 2 + (k & 1) : base + NP * (2 * SLICE) + lane;
+}
+inline int64_t kv_index_rt(int dm, int64_t row, int k, int lane) {
+    return dm == 3 ? kv_index<3>(row, k, lane) : kv_index<2>(row, k, lane);
+}
+
 // device-side scalar state of a PCG solve (conjugateGradientSolver.py:103-127)
 struct PcgState {
     double rMr[2];   // r.M.r, double-buffered by iteration parity
@@ -74,6 +88,7 @@ struct Ctx {
     int32_t nslices = 0;
     XcdRanges xcd{};                  // SpMV: slice range per XCD
     int32_t spmv_grid = 0;            // 8 * max blocks per XCD
+    int32_t spmv_wps = 1;             // wavefronts per slice (1, 2 or 4)
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
     int64_t nnzb = 0;
     int32_t max_row_blocks = 0, max_node_elems = 0;
@@ -122,6 +137,7 @@ struct Ctx {
     int opt_poll = 32;
     int opt_timing = 0;               // 0 off, 1 every launch, k > 1: every k-th SpMV launch
     int64_t spmv_count = 0;
+    int opt_timing_fence = 1;
     int opt_spmv_variant = 0;
     femcy_timing_t timing{};
     std::vector<EventPair> ev_pool;
@@ -149,6 +165,7 @@ void timing_collect(Ctx* c);
 
 // pattern.cpp
 int build_pattern(Ctx* c);
+void spmv_split(Ctx* c);
 // kernels_*.hip (host launchers)
 int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom = true, bool write_sigma = true);
 int launch_post(Ctx* c, int large);

@@ -222,12 +222,20 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case FEMCY_OPT_EW_GRID:
             set_ew_cap((int)value);
             break;
+        case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
+            c->opt_timing_fence = value ? 1 : 0;
+            break;
         case FEMCY_OPT_PCG_GRAPH:
             FEMCY_REQUIRE(value >= 0 && value <= 2, "graph mode must be 0 (off), 1 (auto) or 2 (always)");
             c->opt_graph = (int)value;
             break;
         case FEMCY_OPT_SPMV_VARIANT:
+            FEMCY_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4, "wavefronts per slice: 0 (auto), 1, 2 or 4");
             c->opt_spmv_variant = (int)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
             break;
         default:
             set_error("unknown option %d", option);
@@ -608,7 +616,7 @@ int femcy_get_K_ell(femcy_ctx* ctx, int32_t* ij, double* A) {
             for (int j = 0; j < L; ++j)
                 for (int cc = 0; cc < dm; ++cc) {
                     row_ij[1 + j * dm + cc] = c->h_bcol[(off + j) * SLICE + lane] * dm + cc;
-                    row_A[j * dm + cc] = vals[((off + j) * (dm * dm) + r * dm + cc) * SLICE + lane];
+                    row_A[j * dm + cc] = vals[kv_index_rt(dm, off + j, r * dm + cc, lane)];
                 }
         }
     }
@@ -633,7 +641,7 @@ int femcy_get_K_bsr(femcy_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* ou
         std::sort(order.begin(), order.end());
         for (auto& pr : order) {
             colidx[w] = pr.first;
-            for (int k = 0; k < bb; ++k) out[w * bb + k] = vals[((off + pr.second) * bb + k) * SLICE + lane];
+            for (int k = 0; k < bb; ++k) out[w * bb + k] = vals[kv_index_rt(dm, off + pr.second, k, lane)];
             ++w;
         }
         rowptr[a + 1] = (int32_t)w;

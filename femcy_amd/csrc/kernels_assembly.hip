@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
     const int64_t row = p >> 6;
     const int lane = (int)(p & 63);
 #pragma unroll
-    for (int k = 0; k < DM * DM; ++k) Kvals[(row * (DM * DM) + k) * SLICE + lane] = acc[k];
+    for (int k = 0; k < DM * DM; ++k) Kvals[kv_index<DM>(row, k, lane)] = acc[k];
 }
 
 // row-centric assembly: one wavefront per node (matrix block row).  Lanes are the (incident element, local
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, 
             const int lanea = a & 63;
             for (int idx = lane; idx < L * DD; idx += 64) {
                 const int j = idx / DD, k = idx - j * DD;
-                Kvals[((off + j) * DD + k) * SLICE + lanea] = acc[idx];
+                Kvals[kv_index<DM>(off + j, k, lanea)] = acc[idx];
             }
         }
         __syncthreads();
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
     const int64_t row = slice_off[a >> 6] + slotj[t];
     const int lane = a & 63;
 #pragma unroll
-    for (int k = 0; k < DM * DM; ++k) unsafeAtomicAdd(&Kvals[(row * (DM * DM) + k) * SLICE + lane], acc[k]);
+    for (int k = 0; k < DM * DM; ++k) unsafeAtomicAdd(&Kvals[kv_index<DM>(row, k, lane)], acc[k]);
 }
 
 // ----------------------------------------------------------------------------- nodal force gather
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
     const int64_t rowa = slice_off[a >> 6] + j;
     const int lanea = a & 63;
 #pragma unroll
-    for (int cc = 0; cc < DM; ++cc) Kvals[(rowa * (DM * DM) + r * DM + cc) * SLICE + lanea] = 0.0;
+    for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(rowa, r * DM + cc, lanea)] = 0.0;
     const int32_t b = bcol[rowa * SLICE + lanea];
     // mirror block: slot of a in the row of b (diagonal first, then ascending)
     int32_t js = 0;
@@ -504,11 +504,11 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
         const int64_t rowb = slice_off[b >> 6] + js;
         const int laneb = b & 63;
 #pragma unroll
-        for (int cc = 0; cc < DM; ++cc) Kvals[(rowb * (DM * DM) + cc * DM + r) * SLICE + laneb] = 0.0;
+        for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(rowb, cc * DM + r, laneb)] = 0.0;
     }
     if (j == 0) {
         // multi-rank: K is sub-assembled, so only the owning rank contributes the unit diagonal
-        Kvals[(rowa * (DM * DM) + r * DM + r) * SLICE + lanea] = owner ? (double)owner[dof] : 1.0;
+        Kvals[kv_index<DM>(rowa, r * DM + r, lanea)] = owner ? (double)owner[dof] : 1.0;
         if (resid) resid[dof] = 0.0;
     }
 }

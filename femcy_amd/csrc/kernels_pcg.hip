@@ -80,47 +80,88 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
 }
 
 // ------------------------------------------------------------------------------------------ SpMV
-template <int DM>
+// WPS = wavefronts per slice: long rows (C3D10: 27-65 blocks per node) are split into WPS contiguous j-chunks
+// handled by WPS waves of the same workgroup and summed through LDS, so that the chain per wave stays short and
+// the few thousand slices still fill 1024 SIMDs evenly.
+template <int DM, int WPS>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
                                              const int32_t* __restrict__ bcol, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done) {
     __shared__ double sm[BS / 64];
+    __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
     // XCD-aware mapping: physical block b runs on XCD b % 8 (observed dispatch order; speed only).  XCD k
     // walks the contiguous slice range [xr.start[k], xr.start[k+1]), ranges balanced by stored work, so the
     // x-gathers of neighbouring slices share one private L2.  gridDim.x = 8 * blocks-per-XCD; blocks past
     // the end of their range only contribute a zero partial.
+    constexpr int SPB = (BS / 64) / WPS;             // slices per workgroup task
     const int k = blockIdx.x % NXCD;
+    const int bpx = gridDim.x / NXCD;                // workgroups per XCD (<= 256: the partial count stays bounded
+                                                     // for any problem size; larger ranges are walked in a loop)
     const int lane = threadIdx.x & 63;
-    const int s = xr.start[k] + (blockIdx.x / NXCD) * (BS / 64) + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int part = wave % WPS;
+    const int s_end = xr.start[k + 1];
+    const int ntask = (s_end - xr.start[k] + SPB - 1) / SPB;
     double dot = 0.0;
-    if (s < xr.start[k + 1]) {
-        const int32_t L = slice_len[s];
-        const int64_t off = slice_off[s];
-        const int64_t a = (int64_t)s * SLICE + lane;
+    for (int task = blockIdx.x / NXCD; task < ntask; task += bpx) {   // uniform trip count within a workgroup
+        const int s = xr.start[k] + task * SPB + wave / WPS;
+        const bool active = s < s_end;
         double acc[DM];
 #pragma unroll
         for (int r = 0; r < DM; ++r) acc[r] = 0.0;
-        const int32_t* __restrict__ bc = bcol + off * SLICE + lane;
-        const double* __restrict__ v = vals + off * (DM * DM) * SLICE + lane;
+        if (active) {
+            const int32_t L = slice_len[s];
+            const int32_t chunk = (L + WPS - 1) / WPS;
+            const int32_t j0 = part * chunk, j1 = min(L, j0 + chunk);
+            const int64_t off = slice_off[s];
+            const int32_t* __restrict__ bc = bcol + off * SLICE + lane;
+            constexpr int DD = DM * DM, NP = DD / 2;
+            // pairs of entries as double2 (16 B per lane, 1 KiB per wave instruction); see kv_index()
+            const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals + off * (int64_t)(DD * SLICE)) + lane;
+            const double* __restrict__ vs = vals + off * (int64_t)(DD * SLICE) + NP * (2 * SLICE) + lane;
 #pragma unroll 2
-        for (int32_t j = 0; j < L; ++j) {
-            const int64_t col = bc[(int64_t)j * SLICE];
-            double xv[DM];
+            for (int32_t j = j0; j < j1; ++j) {
+                const int64_t col = bc[(int64_t)j * SLICE];
+                double xv[DM];
 #pragma unroll
-            for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
+                for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
+                double e[DD];
 #pragma unroll
-            for (int r = 0; r < DM; ++r)
+                for (int kp = 0; kp < NP; ++kp) {
+                    const double2 t = vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE];
+                    e[2 * kp] = t.x;
+                    e[2 * kp + 1] = t.y;
+                }
+                if (DD & 1) e[DD - 1] = vs[(int64_t)j * (DD * SLICE)];
 #pragma unroll
-                for (int cc = 0; cc < DM; ++cc) acc[r] += v[((int64_t)j * (DM * DM) + r * DM + cc) * SLICE] * xv[cc];
+                for (int r = 0; r < DM; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
+            }
         }
-        if (a < nn) {
+        if (WPS > 1) {
+            __syncthreads();                         // previous task's readers are done with `red`
 #pragma unroll
-            for (int r = 0; r < DM; ++r) {
-                y[a * DM + r] = acc[r];
-                dot += x[a * DM + r] * acc[r];
+            for (int r = 0; r < DM; ++r) red[(wave * DM + r) * 64 + lane] = acc[r];
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int w = 1; w < WPS; ++w)
+#pragma unroll
+                    for (int r = 0; r < DM; ++r) acc[r] += red[((wave + w) * DM + r) * 64 + lane];
+            }
+        }
+        if (active && part == 0) {
+            const int64_t a = (int64_t)s * SLICE + lane;
+            if (a < nn) {
+#pragma unroll
+                for (int r = 0; r < DM; ++r) {
+                    y[a * DM + r] = acc[r];
+                    dot += x[a * DM + r] * acc[r];
+                }
             }
         }
     }
@@ -140,7 +181,7 @@ __global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int64_t* __rest
     const int lane = (int)(a & 63);
 #pragma unroll
     for (int r = 0; r < DM; ++r) {
-        const double dg = vals[(row * (DM * DM) + r * DM + r) * SLICE + lane];
+        const double dg = vals[kv_index<DM>(row, r * DM + r, lane)];
         M[a * DM + r] = invert ? 1.0 / dg : dg;
     }
 }
@@ -434,6 +475,8 @@ int vec_sumsq(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 0,
 int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1, out); }
 
 // ---------------------------------------------------------------------------------------- SpMV
+__global__ void k_fence_noop() {}
+
 int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
     const int grid = c->spmv_grid;
     if (grid > MAX_PARTIALS) {
@@ -448,23 +491,31 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     const bool sample = c->opt_timing == 1 || (c->opt_timing > 1 && (c->spmv_count++ % c->opt_timing) == 0);
     EventPair* ev = sample ? timing_acquire(c, T_SPMV) : nullptr;
     hipEvent_t ea = ev ? ev->a : nullptr, eb = ev ? ev->b : nullptr;
-    if (!ev) {   // plain launch (also the form that is captured into the PCG hipGraph)
-        if (c->dm == 3)
-            hipLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->xcd,
-                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
-                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
-        else
-            hipLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, c->nn, c->xcd,
-                               (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
-                               (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
-    } else if (c->dm == 3)
-        hipExtLaunchKernelGGL((k_spmv<3>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->xcd,
-                              (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
-                              (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
-    else
-        hipExtLaunchKernelGGL((k_spmv<2>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, c->nn, c->xcd,
-                              (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,
-                              (const int32_t*)c->d_bcol, (const double*)c->d_Kvals, d_x, d_y, d_partials, done);
+    // a sampled dispatch is preceded by an empty kernel: the profiled start stamp is taken when the packet is
+    // picked up, i.e. possibly while the previous PCG kernel is still draining; the empty kernel absorbs that wait
+    if (ev && c->opt_timing_fence) hipLaunchKernelGGL(k_fence_noop, dim3(1), dim3(64), 0, c->stream);
+#define SPMV_ARGS                                                                                              \
+    c->nn, c->xcd, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,  \
+        (const double*)c->d_Kvals, d_x, d_y, d_partials, done
+#define SPMV_LAUNCH(DM_, WPS_)                                                                                 \
+    do {                                                                                                       \
+        if (ev)                                                                                                \
+            hipExtLaunchKernelGGL((k_spmv<DM_, WPS_>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, SPMV_ARGS); \
+        else /* plain launch: also the form that is captured into the PCG hipGraph */                          \
+            hipLaunchKernelGGL((k_spmv<DM_, WPS_>), dim3(grid), dim3(BS), 0, c->stream, SPMV_ARGS);             \
+    } while (0)
+    const int wps = c->spmv_wps;
+    if (c->dm == 3) {
+        if (wps == 1) SPMV_LAUNCH(3, 1);
+        else if (wps == 2) SPMV_LAUNCH(3, 2);
+        else SPMV_LAUNCH(3, 4);
+    } else {
+        if (wps == 1) SPMV_LAUNCH(2, 1);
+        else if (wps == 2) SPMV_LAUNCH(2, 2);
+        else SPMV_LAUNCH(2, 4);
+    }
+#undef SPMV_LAUNCH
+#undef SPMV_ARGS
     FEMCY_HIP(hipGetLastError());
     if (nblocks_out) *nblocks_out = grid;
     return FEMCY_OK;

@@ -41,6 +41,33 @@ static int upload(T** dptr, const std::vector<T>& h) {
     return FEMCY_OK;
 }
 
+// SpMV work split: XCD k gets the contiguous slice range holding the k-th eighth of the stored blocks; long
+// rows are shared by WPS wavefronts of one workgroup (FEMCY_OPT_SPMV_VARIANT: 0 = choose from the mean row
+// length, else 1 / 2 / 4).
+void spmv_split(Ctx* c) {
+    constexpr int NX = 8, WAVES = 4;
+    const int32_t nslices = c->nslices;
+    const int64_t stored_rows = c->stored_rows;
+    int wps = c->opt_spmv_variant;
+    if (wps != 1 && wps != 2 && wps != 4) {
+        const double mean_len = nslices ? (double)stored_rows / nslices : 0.0;
+        wps = mean_len <= 24.0 ? 1 : (mean_len <= 48.0 ? 2 : 4);
+    }
+    c->spmv_wps = wps;
+    const int spb = WAVES / wps;   // slices per workgroup
+    int32_t s = 0;
+    c->xcd.start[0] = 0;
+    for (int k = 1; k < NX; ++k) {
+        const int64_t target = stored_rows * k / NX;
+        while (s < nslices && c->h_slice_off[s] < target) ++s;
+        c->xcd.start[k] = s;
+    }
+    c->xcd.start[NX] = nslices;
+    int32_t per = 1;
+    for (int k = 0; k < NX; ++k) per = std::max(per, (c->xcd.start[k + 1] - c->xcd.start[k] + spb - 1) / spb);
+    c->spmv_grid = std::min(per, 256) * NX;   // <= 2048 workgroups: larger ranges are looped inside the kernel
+}
+
 int build_pattern(Ctx* c) {
     const int32_t nn = c->nn, ne = c->ne, npe = c->npe, dm = c->dm;
     const int32_t* el = c->h_elems.data();
@@ -170,22 +197,6 @@ int build_pattern(Ctx* c) {
         }
     }
 
-    // ---- SpMV work split: XCD k gets the contiguous slice range holding the k-th eighth of the stored blocks
-    {
-        constexpr int NX = 8, WPB = 4;   // XCDs, waves (= slices) per workgroup
-        int32_t s = 0;
-        c->xcd.start[0] = 0;
-        for (int k = 1; k < NX; ++k) {
-            const int64_t target = stored_rows * k / NX;
-            while (s < nslices && slice_off[s] < target) ++s;
-            c->xcd.start[k] = s;
-        }
-        c->xcd.start[NX] = nslices;
-        int32_t per = 1;
-        for (int k = 0; k < NX; ++k) per = std::max(per, (c->xcd.start[k + 1] - c->xcd.start[k] + WPB - 1) / WPB);
-        c->spmv_grid = per * NX;
-    }
-
     // ---- commit to the context
     c->nslices = nslices;
     c->stored_rows = stored_rows;
@@ -196,6 +207,7 @@ int build_pattern(Ctx* c) {
     c->h_slice_off.assign(slice_off.begin(), slice_off.end());
     c->h_rowlen = rowlen_pad;
     c->h_bcol = bcol;
+    spmv_split(c);
 
     int rc;
     if ((rc = upload(&c->d_slice_len, slice_len))) return rc;

@@ -88,7 +88,7 @@ enum femcy_option {
     FEMCY_OPT_PCG_POLL = 1,     /* iterations between host polls of the device "done" flag      */
     FEMCY_OPT_TIMING = 2,       /* 1 = time kernel classes with hipEvents (femcy_timing);       */
                                 /* k > 1 = same, but only every k-th SpMV launch is sampled     */
-    FEMCY_OPT_SPMV_VARIANT = 3, /* reserved                                                     */
+    FEMCY_OPT_SPMV_VARIANT = 3, /* SpMV wavefronts per 64-node slice: 0 auto (by mean row length), 1, 2, 4 */
     FEMCY_OPT_EW_GRID = 4,      /* cap on workgroups of the element-wise PCG kernels (tuning)   */
     FEMCY_OPT_PCG_GRAPH = 5     /* hipGraph replay of poll-bursts of PCG iterations: 0 off, 1 auto (default:
                                    below 2e5 DOF, where the loop is launch-bound), 2 always             */

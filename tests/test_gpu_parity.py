@@ -99,6 +99,11 @@ def test_spmv_and_vectors(gpu_ctx_factory, name):
     ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
     y = ctx.download(be.VEC_TMP1)
     assert rel(y, K @ x) < 1e-13
+    for wps in (1, 2, 4):                       # long rows split over 1 / 2 / 4 wavefronts per slice
+        ctx.set_option(be.OPT_SPMV_VARIANT, wps)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
+    ctx.set_option(be.OPT_SPMV_VARIANT, 0)
     # tiGadgets
     ctx.upload(be.VEC_RHS, 2.0 * x)
     ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_TMP0, be.VEC_RHS)

@@ -67,8 +67,10 @@ def main():
     ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
     x = np.random.default_rng(0).standard_normal(n)
     ctx.upload(be.VEC_TMP0, x)
-    t = timeit(lambda: ctx.spmv(be.VEC_TMP0, be.VEC_TMP1), 200)
-    print(f"spmv: {t*1e6:.1f} us  -> {spmv_bytes/t/1e9:.0f} GB/s algorithmic ({spmv_bytes/1e6:.1f} MB)")
+    for wps in (1, 2, 4, 0):
+        ctx.set_option(be.OPT_SPMV_VARIANT, wps)
+        t = timeit(lambda: ctx.spmv(be.VEC_TMP0, be.VEC_TMP1), 200)
+        print(f"spmv wps={wps}: {t*1e6:.1f} us  -> {spmv_bytes/t/1e9:.0f} GB/s algorithmic ({spmv_bytes/1e6:.1f} MB)")
     for poll in (32, 128):
         ctx.set_option(be.OPT_PCG_POLL, poll)
         t0 = time.perf_counter()
