@@ -38,6 +38,11 @@ def log(*a):
 
 
 def main():
+    # the contract is ONE JSON line on rank 0's stdout: libraries (RCCL prints a version banner on init) must not
+    # be able to add to it, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -46,6 +51,7 @@ def main():
     ap.add_argument("--sample", type=int, default=16, help="time every k-th SpMV launch with HIP events (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
+    ap.add_argument("--force-dist", action="store_true", help="N=1: still create the torch.distributed (nccl) group and use its barrier / broadcast / all-reduce (exercises the N>1 host code on one GPU)")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
     args = ap.parse_args()
 
@@ -66,12 +72,14 @@ def main():
                              f"--nnodes=1 --nproc-per-node {N} --master-addr 127.0.0.1 bench.py --gpus {N}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {N}")
     torch.cuda.set_device(local_rank)
-    if N > 1:
+    use_dist = N > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if N > 1:
+        if use_dist:
             dist.barrier()
 
     # ------------------------------------------------------------------ problem (deterministic)
@@ -95,7 +103,7 @@ def main():
     info = ctx.build_pattern()
     if use_comm:
         uid = [be.Context.comm_unique_id() if rank == 0 else None]
-        if N > 1:
+        if use_dist:
             dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
     n, ne = ctx.n, ctx.ne
@@ -139,7 +147,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
-    if N > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,9 +203,10 @@ def main():
             log(f"[bench] cpu_baseline failed: {e!r}")
             result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
     ctx.close()
-    if N > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -151,6 +151,7 @@ struct Ctx {
     int32_t niface_local = 0, niface_global = 0;
     int32_t* d_iface_dof = nullptr;
     int32_t* d_iface_slot = nullptr;
+    int32_t* d_slot2dof = nullptr;    // [niface_global] local DOF of each global interface slot, -1 if not held
     uint8_t* d_owner = nullptr;
     double* d_commbuf = nullptr;      // [niface_global + 8]
     double* d_gather = nullptr;       // [nranks*2]

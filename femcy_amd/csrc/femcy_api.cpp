@@ -191,7 +191,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad);
     dev_free(&c->d_part1); dev_free(&c->d_part2); dev_free(&c->d_state);
     dev_free(&c->d_idx_scratch); dev_free(&c->d_val_scratch);
-    dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
+    dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_slot2dof); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
     dev_free(&c->d_gather);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -714,6 +714,15 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
     if ((rc = dev_alloc(&c->d_owner, (size_t)c->n + 64))) return rc;
     if ((rc = dev_alloc(&c->d_commbuf, (size_t)niface_global + 8))) return rc;
     if ((rc = dev_alloc(&c->d_gather, (size_t)nranks * 2 + 2))) return rc;
+    {
+        std::vector<int32_t> slot2dof((size_t)std::max(niface_global, 1), -1);
+        for (int32_t i = 0; i < niface_local; ++i) {
+            FEMCY_REQUIRE(slot2dof[iface_global_slot[i]] < 0, "interface slot %d listed twice", iface_global_slot[i]);
+            slot2dof[iface_global_slot[i]] = iface_local_dofs[i];
+        }
+        if ((rc = dev_alloc(&c->d_slot2dof, slot2dof.size(), false))) return rc;
+        FEMCY_HIP(hipMemcpy(c->d_slot2dof, slot2dof.data(), sizeof(int32_t) * slot2dof.size(), hipMemcpyHostToDevice));
+    }
     if (niface_local > 0) {
         FEMCY_HIP(hipMemcpy(c->d_iface_dof, iface_local_dofs, sizeof(int32_t) * niface_local, hipMemcpyHostToDevice));
         FEMCY_HIP(hipMemcpy(c->d_iface_slot, iface_global_slot, sizeof(int32_t) * niface_local, hipMemcpyHostToDevice));

@@ -358,12 +358,7 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     }
 }
 
-// single-block sum of SpMV partials into one slot (multi-rank path)
-__global__ void __launch_bounds__(BS) k_sum_partials(int np, const double* __restrict__ part, double* out) {
-    __shared__ double sm[BS / 64];
-    const double t = reduce_partials_sum(part, np, sm);
-    if (threadIdx.x == 0) *out = t;
-}
+// single-block reduction of the (r.M.r, max|r|) partials into one pair (multi-rank path)
 __global__ void __launch_bounds__(BS) k_sum_partials2(int np, const double* __restrict__ part2, double* out2) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     double s = 0.0, m = 0.0;
@@ -378,10 +373,25 @@ __global__ void __launch_bounds__(BS) k_sum_partials2(int np, const double* __re
         out2[1] = m;
     }
 }
-__global__ void k_iface_pack(int32_t k, const int32_t* __restrict__ dof, const int32_t* __restrict__ slot,
-                             const double* __restrict__ v, double* __restrict__ buf) {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k) buf[slot[i]] = v[dof[i]];
+// packed global interface vector in one launch: buf[s] = v[local dof of slot s] (0 where this rank does not hold
+// the slot -- the all-reduce sums the contributions of the sharing ranks); the extra last workgroup reduces the
+// SpMV partials into buf[nslots] (local d.K_loc.d), so one collective carries both.
+__global__ void __launch_bounds__(BS) k_iface_pack_all(int32_t nslots, const int32_t* __restrict__ slot2dof,
+                                                       const double* __restrict__ v, double* __restrict__ buf, int np,
+                                                       const double* __restrict__ part) {
+    __shared__ double sm[BS / 64];
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        if (part) {
+            const double t = reduce_partials_sum(part, np, sm);
+            if (threadIdx.x == 0) buf[nslots] = t;
+        }
+        return;
+    }
+    const int32_t s = blockIdx.x * BS + threadIdx.x;
+    if (s < nslots) {
+        const int32_t d = slot2dof[s];
+        buf[s] = d >= 0 ? v[d] : 0.0;
+    }
 }
 __global__ void k_iface_unpack(int32_t k, const int32_t* __restrict__ dof, const int32_t* __restrict__ slot,
                                const double* __restrict__ buf, double* __restrict__ v) {
@@ -524,10 +534,8 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 // sum a sub-assembled vector over the ranks that share each interface DOF
 int iface_sum(Ctx* c, double* d_v) {
     if (!c->comm) return FEMCY_OK;
-    FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
-    if (c->niface_local > 0)
-        hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream, c->niface_local,
-                           c->d_iface_dof, c->d_iface_slot, d_v, c->d_commbuf);
+    hipLaunchKernelGGL(k_iface_pack_all, dim3((c->niface_global + BS - 1) / BS + 1), dim3(BS), 0, c->stream,
+                       c->niface_global, c->d_slot2dof, d_v, c->d_commbuf, 0, (const double*)nullptr);
     int rc = comm_allreduce_sum(c, c->d_commbuf, c->niface_global);
     if (rc) return rc;
     if (c->niface_local > 0)
@@ -586,11 +594,8 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         if (multi) {
             // interface rows of Ad hold partial sums: pack them + the local d.Ad, all-reduce, unpack
             double* slot = c->d_commbuf + c->niface_global;
-            FEMCY_HIP(hipMemsetAsync(c->d_commbuf, 0, sizeof(double) * c->niface_global, c->stream));
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, c->stream, np1, c->d_part1, slot);
-            if (c->niface_local > 0)
-                hipLaunchKernelGGL(k_iface_pack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
-                                   c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_Ad, c->d_commbuf);
+            hipLaunchKernelGGL(k_iface_pack_all, dim3((c->niface_global + BS - 1) / BS + 1), dim3(BS), 0, c->stream,
+                               c->niface_global, c->d_slot2dof, c->d_Ad, c->d_commbuf, np1, c->d_part1);
             if ((rc = comm_allreduce_sum(c, c->d_commbuf, (int64_t)c->niface_global + 1))) return rc;
             if (c->niface_local > 0)
                 hipLaunchKernelGGL(k_iface_unpack, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream,
