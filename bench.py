@@ -238,8 +238,26 @@ def cpu_baseline(nodes, el, mesh, u, cons):
     t = time.perf_counter()
     _, it, _, _ = co.cg(f, eps=0.0, maxit=its)
     dt = time.perf_counter() - t
+    # second, implementation-independent anchor: single-thread scipy CSR A @ x
+    Kcsr = co.to_csr()
+    xs = np.random.default_rng(0).standard_normal(co.n)
+    Kcsr @ xs
+    t = time.perf_counter()
+    for _ in range(5):
+        Kcsr @ xs
+    t_scipy = (time.perf_counter() - t) / 5
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": it / dt, "unit": "CG iters/s", "cores": co.threads(), "kind": "port",
             "assemblies_per_s": co.ne / t_asm, "assembly_ms": t_asm * 1e3,
+            "cpu_model": cpu_model, "host_threads_available": os.cpu_count(),
+            "scipy_csr_spmv_per_s_1thread": 1.0 / t_scipy,
             "sample": f"same 1M-element mesh and state: 1 as-written assembly ({t_asm:.2f} s) + {it} CG iterations "
                       f"({dt:.1f} s) of oracle/femcy_oracle.c, OpenMP x{co.threads()} threads; setup {setup:.0f} s untimed"}
 

@@ -331,7 +331,26 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) acc[k] = 0.0;
     const int32_t c0 = ctr_ptr[p], c1 = ctr_ptr[p + 1];
-    for (int32_t c = c0; c < c1; ++c) {
+    int32_t c = c0;
+    // two contributions per trip: their (dependent) code -> dsdx -> FMA chains are independent, which doubles
+    // the loads in flight per lane of this latency-bound gather; summation order stays ascending
+    for (; c + 1 < c1; c += 2) {
+        const int32_t code0 = ctr[c], code1 = ctr[c + 1];
+        const int32_t lb0 = code0 % npe, t0 = code0 / npe, la0 = t0 % npe;
+        const int32_t lb1 = code1 % npe, t1 = code1 / npe, la1 = t1 % npe;
+        const int64_t e0 = t0 / npe, e1 = t1 / npe;
+        double acc1[DM * DM];
+#pragma unroll
+        for (int k = 0; k < DM * DM; ++k) acc1[k] = 0.0;
+        for (int g = 0; g < nGP; ++g) {
+            const int64_t b0 = (e0 * nGP + g) * npe, b1 = (e1 * nGP + g) * npe;
+            kblock_add<DM>(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, C, vol[e0 * nGP + g], acc);
+            kblock_add<DM>(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, C, vol[e1 * nGP + g], acc1);
+        }
+#pragma unroll
+        for (int k = 0; k < DM * DM; ++k) acc[k] += acc1[k];
+    }
+    for (; c < c1; ++c) {
         const int32_t code = ctr[c];
         const int32_t lb = code % npe;
         const int32_t t = code / npe;
