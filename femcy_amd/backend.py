@@ -34,7 +34,8 @@ EXPORTS = [
     "femcy_vec_upload", "femcy_vec_download", "femcy_vec_fill", "femcy_vec_copy", "femcy_vec_scatter",
     "femcy_vec_sub", "femcy_vec_axpy", "femcy_vec_scale", "femcy_vec_norm", "femcy_vec_absmax",
     "femcy_assemble_K", "femcy_internal_force", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
-    "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
+    "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
+    "femcy_dofset_scatter", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
     "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_init", "femcy_iface_sum",
 ]
@@ -97,6 +98,9 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_vec_norm": [p, cint, C.POINTER(f64)], "femcy_vec_absmax": [p, cint, C.POINTER(f64)],
         "femcy_assemble_K": [p, cint], "femcy_internal_force": [p, cint, cint],
         "femcy_apply_dirichlet_linear": [p, p, p, i32, cint], "femcy_apply_dirichlet_newton": [p, p, i32, cint],
+        "femcy_dofset_create": [p, p, i32, C.POINTER(i32)], "femcy_dofset_dirichlet_newton": [p, i32, cint],
+        "femcy_dofset_dirichlet_linear": [p, i32, f64, cint], "femcy_dofset_fill": [p, i32, cint, f64],
+        "femcy_dofset_scatter": [p, i32, cint, p],
         "femcy_spmv": [p, cint, cint],
         "femcy_pcg": [p, cint, cint, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)],
         "femcy_compute_strain_stress": [p, cint, cint], "femcy_elastic_energy": [p, cint, C.POINTER(f64)],
@@ -287,6 +291,25 @@ class Context:
     def dirichlet_newton(self, dofs, residual_vec: int = VEC_RESIDUAL):
         dofs = _i32(dofs).ravel()
         self._call("femcy_apply_dirichlet_newton", _ptr(dofs), dofs.size, int(residual_vec))
+
+    # device-resident DOF lists of *Boundary blocks (no per-call upload / sync)
+    def dofset(self, dofs) -> int:
+        dofs = _i32(dofs).ravel()
+        out = C.c_int32()
+        self._call("femcy_dofset_create", _ptr(dofs), dofs.size, C.byref(out))
+        return out.value
+
+    def dofset_dirichlet_newton(self, ds: int, residual_vec: int = VEC_RESIDUAL):
+        self._call("femcy_dofset_dirichlet_newton", int(ds), int(residual_vec))
+
+    def dofset_dirichlet_linear(self, ds: int, value: float, rhs_vec: int = VEC_RHS):
+        self._call("femcy_dofset_dirichlet_linear", int(ds), float(value), int(rhs_vec))
+
+    def dofset_fill(self, ds: int, vec_id: int, value: float):
+        self._call("femcy_dofset_fill", int(ds), int(vec_id), float(value))
+
+    def dofset_scatter(self, ds: int, vec_id: int, vals):
+        self._call("femcy_dofset_scatter", int(ds), int(vec_id), _ptr(_f64(vals).ravel()))
 
     def spmv(self, x_vec: int, y_vec: int):
         self._call("femcy_spmv", int(x_vec), int(y_vec))

@@ -132,6 +132,10 @@ struct Ctx {
     int pcg_graph_iters = 0, pcg_graph_g = 0, pcg_graph_np1 = 0;
     int opt_graph = 1;
 
+    // ---- device-resident DOF lists of *Boundary blocks
+    struct DofSet { int32_t* d_dofs; double* d_vals; int32_t k; };
+    std::vector<DofSet> dofsets;
+
     // ---- options / timing
     int opt_assembly = FEMCY_ASM_AUTO;
     int opt_poll = 32;
@@ -186,6 +190,7 @@ int vec_scale(Ctx* c, double* d, double s);
 int vec_sumsq(Ctx* c, const double* d, double* out);
 int vec_absmax(Ctx* c, const double* d, double* out);
 int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k);
+int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32_t k);
 int ensure_scratch(Ctx* c, int64_t k);
 void set_ew_cap(int cap);
 // comm.cpp

@@ -195,6 +195,10 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_gather);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    for (auto& ds : c->dofsets) {
+        if (ds.d_dofs) (void)hipFree(ds.d_dofs);
+        if (ds.d_vals) (void)hipFree(ds.d_vals);
+    }
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -511,6 +515,70 @@ int femcy_apply_dirichlet_newton(femcy_ctx* ctx, const int32_t* dofs, int32_t k,
     if ((rc = launch_dirichlet_zero(c, c->d_idx_scratch, k, c->d_vec[residual_vec]))) return rc;
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     return FEMCY_OK;
+}
+
+int femcy_dofset_create(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int32_t* id_out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh && id_out && k >= 0 && (k == 0 || dofs), "bad dofset arguments");
+    for (int32_t i = 0; i < k; ++i) FEMCY_REQUIRE(dofs[i] >= 0 && dofs[i] < c->n, "DOF %d out of range", dofs[i]);
+    Ctx::DofSet ds{nullptr, nullptr, k};
+    FEMCY_HIP(hipMalloc((void**)&ds.d_dofs, std::max<size_t>(k, 1) * sizeof(int32_t)));
+    FEMCY_HIP(hipMalloc((void**)&ds.d_vals, std::max<size_t>(k, 1) * sizeof(double)));
+    if (k) FEMCY_HIP(hipMemcpy(ds.d_dofs, dofs, sizeof(int32_t) * k, hipMemcpyHostToDevice));
+    c->dofsets.push_back(ds);
+    *id_out = (int32_t)c->dofsets.size() - 1;
+    return FEMCY_OK;
+}
+
+#define DOFSET_OR_FAIL(id)                                                              \
+    FEMCY_REQUIRE((id) >= 0 && (size_t)(id) < c->dofsets.size(), "unknown dofset %d", (int)(id)); \
+    const Ctx::DofSet& ds = c->dofsets[(id)]
+
+int femcy_dofset_dirichlet_newton(femcy_ctx* ctx, int32_t id, int residual_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(residual_vec);
+    DOFSET_OR_FAIL(id);
+    return launch_dirichlet_zero(c, ds.d_dofs, ds.k, c->d_vec[residual_vec]);
+}
+
+int femcy_dofset_fill(femcy_ctx* ctx, int32_t id, int vec, double value) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    DOFSET_OR_FAIL(id);
+    return vec_scatter_const(c, c->d_vec[vec], ds.d_dofs, value, ds.k);
+}
+
+int femcy_dofset_scatter(femcy_ctx* ctx, int32_t id, int vec, const double* vals) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(vec);
+    DOFSET_OR_FAIL(id);
+    if (ds.k == 0) return FEMCY_OK;
+    FEMCY_REQUIRE(vals, "null values");
+    FEMCY_HIP(hipMemcpyAsync(ds.d_vals, vals, sizeof(double) * ds.k, hipMemcpyHostToDevice, c->stream));
+    int rc = vec_scatter(c, c->d_vec[vec], ds.d_dofs, ds.d_vals, ds.k);
+    FEMCY_HIP(hipStreamSynchronize(c->stream));   // the host buffer is only borrowed for the call
+    return rc;
+}
+
+int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int rhs_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(rhs_vec);
+    DOFSET_OR_FAIL(id);
+    FEMCY_REQUIRE(rhs_vec != FEMCY_VEC_TMP0 && rhs_vec != FEMCY_VEC_TMP1, "rhs may not alias the scratch vectors");
+    if (ds.k == 0) return FEMCY_OK;
+    int rc;
+    if (value != 0.0) {   // rhs -= K s with s = value on the block's DOFs (see femcy_apply_dirichlet_linear)
+        double* s = c->d_vec[FEMCY_VEC_TMP0];
+        double* Ks = c->d_vec[FEMCY_VEC_TMP1];
+        if ((rc = vec_fill(c, s, 0.0, c->n))) return rc;
+        if ((rc = vec_scatter_const(c, s, ds.d_dofs, value, ds.k))) return rc;
+        if ((rc = launch_spmv(c, s, Ks, nullptr, nullptr))) return rc;
+        if ((rc = vec_sub(c, c->d_vec[rhs_vec], c->d_vec[rhs_vec], Ks))) return rc;
+    }
+    if ((rc = vec_scatter_const(c, c->d_vec[rhs_vec], ds.d_dofs, value, ds.k))) return rc;
+    return launch_dirichlet_zero(c, ds.d_dofs, ds.k, nullptr);
 }
 
 int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {

@@ -420,6 +420,10 @@ __global__ void k_scatter(int32_t k, const int32_t* __restrict__ idx, const doub
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) v[idx[i]] = vals[i];
 }
+__global__ void k_scatter_const(int32_t k, const int32_t* __restrict__ idx, double val, double* __restrict__ v) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) v[idx[i]] = val;
+}
 // mode 0: sum of squares, mode 1: max |.|; partials then a single-block finish into *out
 __global__ void __launch_bounds__(BS) k_reduce(int64_t n, const double* __restrict__ v, int mode,
                                                double* __restrict__ part) {
@@ -468,6 +472,12 @@ int vec_scale(Ctx* c, double* d, double s) {
 int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k) {
     if (k <= 0) return FEMCY_OK;
     hipLaunchKernelGGL(k_scatter, dim3((k + BS - 1) / BS), dim3(BS), 0, c->stream, k, d_idx, d_vals, d);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32_t k) {
+    if (k <= 0) return FEMCY_OK;
+    hipLaunchKernelGGL(k_scatter_const, dim3((k + BS - 1) / BS), dim3(BS), 0, c->stream, k, d_idx, val, d);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }

@@ -77,6 +77,7 @@ class System_of_equations:
         self.time1 = 0.
         self.dt = 0.
         self.compiled = False
+        self._dofsets = {}
         self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0}
 
     def _say(self, msg):
@@ -135,12 +136,21 @@ class System_of_equations:
     def _node_ids(nodeSet):
         return np.asarray(nodeSet.to_numpy() if hasattr(nodeSet, "to_numpy") else nodeSet, dtype=np.int64)
 
+    def _dofset(self, nodeSet, dm_specified: int) -> int:
+        """device-resident DOF list of a (node set, component) pair; the reference likewise turns every node
+        set into a ti.field once per solve (:656-659).  Cached per node-set object."""
+        key = (id(nodeSet), dm_specified)
+        hit = self._dofsets.get(key)
+        if hit is None or hit[0] is not nodeSet:
+            hit = (nodeSet, self.ctx.dofset(self._node_ids(nodeSet) * self.dm + dm_specified))
+            self._dofsets[key] = hit
+        return hit[1]
+
     def dirichletBC_linearEquations(self, nodeSet, dm_specified: int, sval: float):
-        dofs = self._node_ids(nodeSet) * self.dm + dm_specified
-        self.ctx.dirichlet_linear(dofs, np.full(dofs.size, sval), be.VEC_RHS)
+        self.ctx.dofset_dirichlet_linear(self._dofset(nodeSet, dm_specified), sval, be.VEC_RHS)
 
     def dirichletBC_forNewtonMethod_kernel(self, nodeSet, dm_specified: int, sval: float):
-        self.ctx.dirichlet_newton(self._node_ids(nodeSet) * self.dm + dm_specified, be.VEC_RESIDUAL)
+        self.ctx.dofset_dirichlet_newton(self._dofset(nodeSet, dm_specified), be.VEC_RESIDUAL)
 
     def dirichletBC_forNewtonMethod(self, dirichletBCs):
         for bc in dirichletBCs:
@@ -154,8 +164,7 @@ class System_of_equations:
             ud.user_dirichletBC(self.dof, nodeSet, self.dm, dm_specified, self.nodes, time)
 
     def dirichletBC_val(self, nodeSet, dm_specified: int, sval: float):
-        dofs = self._node_ids(nodeSet) * self.dm + dm_specified
-        self.ctx.scatter(be.VEC_DOF, dofs, np.full(dofs.size, sval))
+        self.ctx.dofset_fill(self._dofset(nodeSet, dm_specified), be.VEC_DOF, sval)
 
     def neumannBC(self, load_facets, load_val: float, load_dir=np.array([])):
         """consistent nodal loads of a surface traction (dead load on the undeformed geometry).

@@ -160,6 +160,14 @@ int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec);
 int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const double* vals, int32_t k, int rhs_vec);
 /* dirichletBC_forNewtonMethod_kernel (stiffnessMtrx.py:317-341) */
 int femcy_apply_dirichlet_newton(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int residual_vec);
+/* Device-resident copy of one *Boundary block's DOF list (node_set*dm + dof).  The reference keeps each node
+ * set in a ti.field for the whole run (stiffnessMtrx.py:656-659); the femcy_dofset_* calls are the
+ * femcy_apply_dirichlet_* / femcy_vec_scatter calls without the per-call upload and stream sync. */
+int femcy_dofset_create(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int32_t* id_out);
+int femcy_dofset_dirichlet_newton(femcy_ctx* ctx, int32_t id, int residual_vec);
+int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int rhs_vec);
+int femcy_dofset_fill(femcy_ctx* ctx, int32_t id, int vec, double value);       /* dirichletBC_val */
+int femcy_dofset_scatter(femcy_ctx* ctx, int32_t id, int vec, const double* vals /*[k]*/);
 /* compute_Ad (conjugateGradientSolver.py:53-58): vec[y] = K vec[x] */
 int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec);
 /* ConjugateGradientSolver_rowMajor.re_init + solve (conjugateGradientSolver.py:32-51, 103-127):

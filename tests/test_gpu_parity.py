@@ -349,3 +349,36 @@ def test_edge_cases(gpu_ctx_factory):
     with pytest.raises(be.FemcyError) as ei:
         ctx2.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3, maxit=10)
     assert ei.value.status == be.FEMCY_ENUMERIC
+
+
+def test_dofsets_equal_host_list_calls(gpu_ctx_factory):
+    """femcy_dofset_* (device-resident *Boundary DOF lists) == femcy_apply_dirichlet_* / femcy_vec_scatter."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load("twist_plate_C3D4.inp")
+    a, b = make_ctx(gpu_ctx_factory, inp, el, mat), make_ctx(gpu_ctx_factory, inp, el, mat)
+    rhs0 = np.cos(np.arange(a.n) * 0.37)
+    blocks = [(np.asarray(bc["node_set"]) * 3 + bc["dof"], 0.25 * (k - 2)) for k, bc in enumerate(inp.dirichlet_bc_info)]
+    for ctx in (a, b):
+        ctx.assemble_K(-1)
+        ctx.upload(be.VEC_RHS, rhs0)
+        ctx.upload(be.VEC_RESIDUAL, rhs0)
+        ctx.upload(be.VEC_DOF, rhs0)
+    for dofs, val in blocks[:3]:
+        a.dirichlet_linear(dofs, np.full(dofs.size, val), be.VEC_RHS)
+        b.dofset_dirichlet_linear(b.dofset(dofs), val, be.VEC_RHS)
+    assert np.array_equal(a.download(be.VEC_RHS), b.download(be.VEC_RHS))
+    assert abs(a.get_K_bsr() - b.get_K_bsr()).max() == 0.0
+    for dofs, val in blocks[3:]:
+        a.dirichlet_newton(dofs, be.VEC_RESIDUAL)
+        ds = b.dofset(dofs)
+        b.dofset_dirichlet_newton(ds, be.VEC_RESIDUAL)
+        a.scatter(be.VEC_DOF, dofs, np.full(dofs.size, val))
+        b.dofset_fill(ds, be.VEC_DOF, val)
+        vals = np.sin(dofs * 0.1)
+        a.scatter(be.VEC_TMP0, dofs, vals)
+        b.dofset_scatter(ds, be.VEC_TMP0, vals)
+    for v in (be.VEC_RESIDUAL, be.VEC_DOF, be.VEC_TMP0):
+        assert np.array_equal(a.download(v), b.download(v))
+    assert abs(a.get_K_bsr() - b.get_K_bsr()).max() == 0.0
+    with pytest.raises(be.FemcyError):
+        b.dofset_fill(999, be.VEC_DOF, 0.0)
