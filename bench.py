@@ -71,12 +71,20 @@ def main():
             raise SystemExit(f"--gpus {N} needs {N} ranks: launch with python -m torch.distributed.run "
                              f"--nnodes=1 --nproc-per-node {N} --master-addr 127.0.0.1 bench.py --gpus {N}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {N}")
-    torch.cuda.set_device(local_rank)
+    # test hooks (tests/test_bench_multirank_cpu.py runs the N>1 host logic on CPU with gloo and a mock Context):
+    dist_backend = os.environ.get("FEMCY_BENCH_DIST_BACKEND", "nccl")
+    on_gpu = os.environ.get("FEMCY_BENCH_DEVICE", "cuda") == "cuda"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
     use_dist = N > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     def barrier():
         if use_dist:
@@ -137,18 +145,24 @@ def main():
         step()
     ctx.timing_reset()
 
+    def device_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+        else:
+            ctx.sync()
+
     barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t_start = time.perf_counter()
     total_iters = 0
     for _ in range(args.steps):
         it, r0, rmax = step()
         total_iters += it
-    torch.cuda.synchronize()
+    device_sync()
     barrier()
     elapsed = time.perf_counter() - t_start
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timing()

@@ -1,0 +1,158 @@
+"""CPU suite: bench.py's N > 1 host logic (rank/env handling, partition, S1 state per rank, communicator set-up,
+interface sums, weak-scaling value, one JSON line from rank 0) executed with world_size 2 over gloo.
+
+No GPU is involved: `femcy_amd.backend.Context` is replaced -- here in the test only -- by a mock that does the same
+operations with the CPU oracle and the gloo mirror of the distributed PCG (tests/dist_reference.py).  This cannot say
+anything about the HIP kernels or RCCL (the -m gpu suite and the 1-rank communicator test do); it guards the Python
+branch of bench.py that no single-GPU run ever executes."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+
+from helpers import ROOT
+
+
+class MockContext:
+    """oracle-backed stand-in for femcy_amd.backend.Context, just enough for bench.py"""
+    uid_calls = 0
+
+    def __init__(self, device=0):
+        self.device = device
+        self.vec = {}
+        self.part = None
+        self.opts = {}
+
+    # ---- definition
+    def set_mesh(self, nodes, el):
+        from oracle import femcy_oracle as orc
+        from oracle.elements import elem_def
+        self.nodes, self.el = np.asarray(nodes, float), np.asarray(el)
+        self.nn, self.dm = self.nodes.shape
+        self.ne, self.npe = self.el.shape
+        self.n = self.nn * self.dm
+        self.topo = orc.Topology(self.nodes, self.el, elem_def("C3D4"))
+
+    def set_element(self, ELE):
+        self.nGP = ELE.tables()["nGP"]
+
+    def set_material(self, mat):
+        from oracle import femcy_oracle as orc
+        self.mat = orc.Material("lin3d", tuple(mat.params))
+
+    def build_pattern(self):
+        class Info:
+            pass
+        info = Info()
+        info.nnzb = int(self.topo.adj_idx.size)
+        info.nnz = info.nnzb * 9
+        return info
+
+    @staticmethod
+    def comm_unique_id():
+        MockContext.uid_calls += 1
+        return b"\x07" * 128
+
+    def comm_init(self, rank, nranks, uid, iface_local_dofs, iface_global_slot, niface_global, owner):
+        assert uid == b"\x07" * 128 and len(owner) == self.n
+        from types import SimpleNamespace
+        self.part = SimpleNamespace(iface_local_dofs=np.asarray(iface_local_dofs), iface_global_slot=np.asarray(iface_global_slot),
+                                    niface_global=niface_global, owner=np.asarray(owner))
+
+    # ---- vectors
+    class _Vec:
+        def __init__(self, ctx, vid):
+            self.ctx, self.id = ctx, vid
+
+        def fill(self, v):
+            self.ctx.vec[self.id] = np.full(self.ctx.n, float(v))
+
+    def vector(self, vid):
+        return MockContext._Vec(self, vid)
+
+    def upload(self, vid, arr):
+        self.vec[vid] = np.array(arr, float)
+
+    def vec_sub(self, c, a, b):
+        self.vec[c] = self.vec[a] - self.vec[b]
+
+    def iface_sum(self, vid):
+        from dist_reference import iface_sum
+        self.vec[vid] = iface_sum(self.part, self.vec[vid])
+
+    # ---- hot path
+    def internal_force(self, u_vec, f_vec):
+        from oracle import femcy_oracle as orc
+        self.vec[f_vec] = orc.internal_force(self.topo, self.vec[u_vec], self.mat)[0]
+
+    def assemble_K(self, u_vec):
+        from oracle import femcy_oracle as orc
+        self.K = orc.assemble_K(self.topo, self.vec[u_vec], self.mat.C)
+
+    def dirichlet_newton(self, cons, vid):
+        from oracle import femcy_oracle as orc
+        cons = np.asarray(cons, dtype=np.int64)
+        K = orc._zero_rows_cols_unit_diag(self.K, cons).tolil()
+        for i in cons:
+            K[i, i] = float(self.part.owner[i]) if self.part is not None else 1.0
+        self.K = K.tocsr()
+        self.vec[vid][cons] = 0.0
+
+    def pcg(self, b_vec, x_vec, eps=1e-3, maxit=0):
+        from dist_reference import distributed_pcg
+        x, it, r0, rmax = distributed_pcg(self.part, self.K, self.vec[b_vec], eps=eps, maxit=maxit)
+        self.vec[x_vec] = x
+        return it, r0, rmax
+
+    # ---- plumbing
+    def set_option(self, k, v):
+        self.opts[k] = v
+
+    def timing_reset(self):
+        pass
+
+    def timing(self):
+        return {"geom_ms": 1.0, "geom_launches": 1, "assemble_ms": 1.0, "assemble_launches": 1, "force_ms": 0.0,
+                "force_launches": 0, "spmv_ms": 1.0, "spmv_launches": 1, "pcg_ms": 1.0, "pcg_iters": 1}
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), FEMCY_BENCH_DIST_BACKEND="gloo", FEMCY_BENCH_DEVICE="cpu")
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from femcy_amd import backend as be
+    be.Context = MockContext                                   # the mock exists only inside this test process
+    out = os.open(os.path.join(out_dir, f"stdout{rank}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.dup2(out, 1)
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "1", "--iters", "4", "--cells", "4,2,6",
+                "--no-cpu-baseline"]
+    import bench
+    bench.main()
+    np.save(os.path.join(out_dir, f"uid{rank}.npy"), np.array([MockContext.uid_calls]))
+
+
+def test_bench_two_ranks_on_cpu(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    line0 = open(tmp_path / "stdout0.txt").read().strip().splitlines()
+    assert len(line0) == 1                                       # exactly one JSON line, from rank 0 only
+    assert open(tmp_path / "stdout1.txt").read().strip() == ""
+    d = json.loads(line0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2 and d["dtype"] == "f64"
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
+    assert int(np.load(tmp_path / "uid0.npy")[0]) == 1 and int(np.load(tmp_path / "uid1.npy")[0]) == 0
