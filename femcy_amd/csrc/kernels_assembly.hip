@@ -456,36 +456,50 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
 }
 
 // ----------------------------------------------------------------------------- nodal force gather
+// assemble_nodal_force_GN_kernel (stiffnessMtrx.py:620-644) is node-parallel with a serial loop over the padded
+// nodeEles row.  Here half a wavefront (32 lanes) owns a node and the lanes are its incident elements, so the
+// ~24 dependent (code -> dsdx row, sigma, vol) load chains of a row run side by side instead of one after the
+// other; the dm partial sums are combined by a fixed xor-shuffle tree (deterministic) and lane 0 stores.
 template <int DM>
 __global__ void __launch_bounds__(256) k_nodal_force(int32_t nn, int32_t npe, int32_t nGP,
                                                      const int32_t* __restrict__ ne_ptr,
                                                      const int32_t* __restrict__ ne_idx,
                                                      const double* __restrict__ dsdx, const double* __restrict__ sigma,
                                                      const double* __restrict__ vol, double* __restrict__ f) {
-    const int32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= nn) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t a = (int32_t)(t >> 5);
+    const int sub = (int)(t & 31);
     double acc[DM];
 #pragma unroll
     for (int i = 0; i < DM; ++i) acc[i] = 0.0;
-    for (int32_t k = ne_ptr[a]; k < ne_ptr[a + 1]; ++k) {
-        const int32_t code = ne_idx[k];
-        const int64_t e = code / npe;
-        const int32_t la = code % npe;
-        for (int g = 0; g < nGP; ++g) {
-            const double* __restrict__ gr = dsdx + ((e * nGP + g) * npe + la) * DM;
-            const double* __restrict__ sg = sigma + (e * nGP + g) * DM * DM;
-            const double v = vol[e * nGP + g];
+    if (a < nn) {
+        const int32_t k1 = ne_ptr[a + 1];
+        for (int32_t k = ne_ptr[a] + sub; k < k1; k += 32) {
+            const int32_t code = ne_idx[k];
+            const int64_t e = code / npe;
+            const int32_t la = code % npe;
+            for (int g = 0; g < nGP; ++g) {
+                const double* __restrict__ gr = dsdx + ((e * nGP + g) * npe + la) * DM;
+                const double* __restrict__ sg = sigma + (e * nGP + g) * DM * DM;
+                const double v = vol[e * nGP + g];
 #pragma unroll
-            for (int i = 0; i < DM; ++i) {
-                double d = 0.0;
+                for (int i = 0; i < DM; ++i) {
+                    double d = 0.0;
 #pragma unroll
-                for (int j = 0; j < DM; ++j) d += gr[j] * sg[j * DM + i];
-                acc[i] = acc[i] + d * v;
+                    for (int j = 0; j < DM; ++j) d += gr[j] * sg[j * DM + i];
+                    acc[i] = acc[i] + d * v;
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < DM; ++i) f[(int64_t)a * DM + i] = acc[i];
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < DM; ++i) acc[i] += __shfl_xor(acc[i], o, 32);
+    if (a < nn && sub == 0) {
+#pragma unroll
+        for (int i = 0; i < DM; ++i) f[(int64_t)a * DM + i] = acc[i];
+    }
 }
 
 // ------------------------------------------------------------------ Dirichlet 0/1 on the matrix
@@ -871,7 +885,8 @@ int launch_assemble(Ctx* c) {
 }
 
 int launch_nodal_force(Ctx* c, double* d_f) {
-    const int bs = 256, grid = (c->nn + bs - 1) / bs;
+    const int bs = 256;
+    const int grid = (int)(((int64_t)c->nn * 32 + bs - 1) / bs);   // 32 lanes per node
     size_t th = timing_begin(c, T_FORCE);
     if (c->dm == 3)
         hipLaunchKernelGGL((k_nodal_force<3>), dim3(grid), dim3(bs), 0, c->stream, c->nn, c->npe, c->nGP, c->d_ne_ptr,
