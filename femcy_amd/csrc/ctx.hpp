@@ -131,6 +131,7 @@ struct Ctx {
     const double* pcg_graph_x = nullptr;
     int pcg_graph_iters = 0, pcg_graph_g = 0, pcg_graph_np1 = 0;
     int opt_graph = 1;
+    int ew_cap = 512;                 // FEMCY_OPT_EW_GRID
 
     // ---- device-resident DOF lists of *Boundary blocks
     struct DofSet { int32_t* d_dofs; double* d_vals; int32_t k; };
@@ -192,7 +193,6 @@ int vec_absmax(Ctx* c, const double* d, double* out);
 int vec_scatter(Ctx* c, double* d, const int32_t* d_idx, const double* d_vals, int32_t k);
 int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32_t k);
 int ensure_scratch(Ctx* c, int64_t k);
-void set_ew_cap(int cap);
 // comm.cpp
 int comm_unique_id(void* id128);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);

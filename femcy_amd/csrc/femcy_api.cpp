@@ -224,7 +224,9 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->opt_timing = value < 0 ? 0 : (int)value;
             break;
         case FEMCY_OPT_EW_GRID:
-            set_ew_cap((int)value);
+            FEMCY_REQUIRE(value >= 1 && value <= MAX_PARTIALS, "element-wise grid cap out of range");
+            pcg_graph_reset(c);
+            c->ew_cap = (int)value;
             break;
         case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
             c->opt_timing_fence = value ? 1 : 0;
@@ -461,11 +463,10 @@ int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec) {
     return launch_nodal_force(c, c->d_vec[f_vec]);
 }
 
-static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k, std::vector<int32_t>& uniq) {
-    uniq.assign(dofs, dofs + k);
-    for (int32_t d : uniq)
-        if (d < 0 || d >= c->n) {
-            set_error("constrained DOF %d out of range", d);
+static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k) {
+    for (int32_t i = 0; i < k; ++i)
+        if (dofs[i] < 0 || dofs[i] >= c->n) {
+            set_error("constrained DOF %d out of range", dofs[i]);
             return FEMCY_EINVAL;
         }
     int rc = ensure_scratch(c, k);
@@ -482,8 +483,7 @@ int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const doub
     if (k == 0) return FEMCY_OK;
     FEMCY_REQUIRE(dofs && vals && k > 0, "bad Dirichlet arguments");
     FEMCY_REQUIRE(rhs_vec != FEMCY_VEC_TMP0 && rhs_vec != FEMCY_VEC_TMP1, "rhs may not alias the scratch vectors");
-    std::vector<int32_t> uniq;
-    int rc = stage_dofs(c, dofs, vals, k, uniq);
+    int rc = stage_dofs(c, dofs, vals, k);
     if (rc) return rc;
     bool any = false;
     for (int32_t i = 0; i < k; ++i) any = any || (vals[i] != 0.0);
@@ -509,8 +509,7 @@ int femcy_apply_dirichlet_newton(femcy_ctx* ctx, const int32_t* dofs, int32_t k,
     VEC_OR_FAIL(residual_vec);
     if (k == 0) return FEMCY_OK;
     FEMCY_REQUIRE(dofs && k > 0, "bad Dirichlet arguments");
-    std::vector<int32_t> uniq;
-    int rc = stage_dofs(c, dofs, nullptr, k, uniq);
+    int rc = stage_dofs(c, dofs, nullptr, k);
     if (rc) return rc;
     if ((rc = launch_dirichlet_zero(c, c->d_idx_scratch, k, c->d_vec[residual_vec]))) return rc;
     FEMCY_HIP(hipStreamSynchronize(c->stream));
@@ -641,16 +640,19 @@ int femcy_extrapolate(femcy_ctx* ctx, int gp_field, int comp, const double* E, d
         default: set_error("field %d cannot be extrapolated", gp_field); return FEMCY_EINVAL;
     }
     FEMCY_REQUIRE(comp >= 0 && comp < width, "component %d out of range for field %d", comp, gp_field);
-    double *d_E = nullptr, *d_out = nullptr;
+    struct Tmp {   // freed on every return path
+        double* p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } tE, tout;
     const size_t nE = (size_t)c->npe * c->nGP, nout = (size_t)c->ne * c->npe;
-    FEMCY_HIP(hipMalloc((void**)&d_E, nE * sizeof(double)));
-    FEMCY_HIP(hipMalloc((void**)&d_out, nout * sizeof(double)));
-    FEMCY_HIP(hipMemcpyAsync(d_E, E, nE * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int rc = launch_extrapolate(c, d_E, field, width, comp, d_out);
-    if (!rc) FEMCY_HIP(hipMemcpyAsync(out, d_out, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipMalloc((void**)&tE.p, nE * sizeof(double)));
+    FEMCY_HIP(hipMalloc((void**)&tout.p, nout * sizeof(double)));
+    FEMCY_HIP(hipMemcpyAsync(tE.p, E, nE * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = launch_extrapolate(c, tE.p, field, width, comp, tout.p);
+    if (!rc) FEMCY_HIP(hipMemcpyAsync(out, tout.p, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FEMCY_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_E);
-    (void)hipFree(d_out);
     return rc;
 }
 

