@@ -201,6 +201,9 @@ def main():
         "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,
         "pcg_us_per_iter": tm["pcg_ms"] * 1e3 / max(total_iters, 1),
+        # algorithmic flop rates: SpMV 2*nnz per launch; C3D4 assembly ~2.9 kflop per element
+        "spmv_tflops": 2 * info.nnz / (spmv_us * 1e-6) / 1e12 if spmv_us > 0 else 0.0,
+        "assembly_tflops": 2.9e3 * ne_global / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
         "roofline": {"kernel": "k_spmv<3> (compute_Ad)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us,
