@@ -92,11 +92,14 @@ struct Ctx {
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
     int64_t nnzb = 0;
     int32_t max_row_blocks = 0, max_node_elems = 0;
-    std::vector<int32_t> h_slice_len, h_rowlen, h_bcol;
+    std::vector<int32_t> h_slice_len, h_rowlen, h_bcol, h_pos;
     std::vector<int64_t> h_slice_off;
     int32_t* d_slice_len = nullptr;
     int64_t* d_slice_off = nullptr;
-    int32_t* d_rowlen = nullptr;      // [nslices*64]
+    int32_t* d_rowlen = nullptr;      // [nn] blocks per node (indexed by node)
+    int32_t* d_pos = nullptr;         // [nn] node -> storage position (slice*64 + lane): SELL-C-sigma row order
+    int32_t* d_node_of = nullptr;     // [nslices*64] storage position -> node, -1 for padding lanes
+    int32_t sell_sigma = 4096;        // sorting window (nodes); 64 = natural order
     int32_t* d_bcol = nullptr;        // [stored_rows*64]
     double* d_Kvals = nullptr;        // [stored_rows*dm*dm*64]
     uint16_t* d_slotj = nullptr;      // [ne*npe*npe] element-local (a,b) -> slot j in row of node a

@@ -183,6 +183,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     pcg_graph_reset(c);
     dev_free(&c->d_nodes); dev_free(&c->d_elems); dev_free(&c->d_dN); dev_free(&c->d_w); dev_free(&c->d_C);
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
+    dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr);
     dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
@@ -230,6 +231,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             break;
         case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
             c->opt_timing_fence = value ? 1 : 0;
+            break;
+        case FEMCY_OPT_SELL_SIGMA:
+            FEMCY_REQUIRE(value >= SLICE && value <= (1 << 24), "sorting window must be in [64, 2^24] nodes");
+            FEMCY_REQUIRE(!c->have_pattern, "set the sorting window before femcy_build_pattern");
+            c->sell_sigma = (int32_t)value;
             break;
         case FEMCY_OPT_PCG_GRAPH:
             FEMCY_REQUIRE(value >= 0 && value <= 2, "graph mode must be 0 (off), 1 (auto) or 2 (always)");
@@ -672,8 +678,8 @@ int femcy_get_K_ell(femcy_ctx* ctx, int32_t* ij, double* A) {
     if (rc) return rc;
     const int dm = c->dm, W = c->max_row_blocks * dm;
     for (int32_t a = 0; a < c->nn; ++a) {
-        const int64_t off = c->h_slice_off[a / SLICE];
-        const int lane = a % SLICE, L = c->h_rowlen[a];
+        const int64_t off = c->h_slice_off[c->h_pos[a] / SLICE];
+        const int lane = c->h_pos[a] % SLICE, L = c->h_rowlen[a];
         for (int r = 0; r < dm; ++r) {
             const int64_t i = (int64_t)a * dm + r;
             int32_t* row_ij = ij + i * (W + 1);
@@ -704,8 +710,8 @@ int femcy_get_K_bsr(femcy_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* ou
     rowptr[0] = 0;
     std::vector<std::pair<int32_t, int32_t>> order;
     for (int32_t a = 0; a < c->nn; ++a) {
-        const int64_t off = c->h_slice_off[a / SLICE];
-        const int lane = a % SLICE, L = c->h_rowlen[a];
+        const int64_t off = c->h_slice_off[c->h_pos[a] / SLICE];
+        const int lane = c->h_pos[a] % SLICE, L = c->h_rowlen[a];
         order.clear();
         for (int j = 0; j < L; ++j) order.push_back({c->h_bcol[(off + j) * SLICE + lane], j});
         std::sort(order.begin(), order.end());

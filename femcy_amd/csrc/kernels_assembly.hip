@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, 
                                                        const int32_t* __restrict__ ne_idx,
                                                        const uint16_t* __restrict__ slotj,
                                                        const int32_t* __restrict__ rowlen,
+                                                       const int32_t* __restrict__ pos,
                                                        const int64_t* __restrict__ slice_off,
                                                        const double* __restrict__ dsdx,
                                                        const double* __restrict__ vol, const double* __restrict__ C,
@@ -415,8 +416,9 @@ __global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, 
         }
         __syncthreads();
         if (valid) {
-            const int64_t off = slice_off[a >> 6];
-            const int lanea = a & 63;
+            const int32_t pa = pos[a];
+            const int64_t off = slice_off[pa >> 6];
+            const int lanea = pa & 63;
             for (int idx = lane; idx < L * DD; idx += 64) {
                 const int j = idx / DD, k = idx - j * DD;
                 Kvals[kv_index<DM>(off + j, k, lanea)] = acc[idx];
@@ -431,6 +433,7 @@ template <int DM>
 __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t npe, int32_t nGP,
                                                          const int32_t* __restrict__ elems,
                                                          const uint16_t* __restrict__ slotj,
+                                                         const int32_t* __restrict__ pos,
                                                          const int64_t* __restrict__ slice_off,
                                                          const double* __restrict__ dsdx,
                                                          const double* __restrict__ vol, const double* __restrict__ C,
@@ -448,9 +451,9 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
         const int64_t base = (e * nGP + g) * npe;
         kblock_add<DM>(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, C, vol[e * nGP + g], acc);
     }
-    const int32_t a = elems[e * npe + la];
-    const int64_t row = slice_off[a >> 6] + slotj[t];
-    const int lane = a & 63;
+    const int32_t pa = pos[elems[e * npe + la]];
+    const int64_t row = slice_off[pa >> 6] + slotj[t];
+    const int lane = pa & 63;
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) unsafeAtomicAdd(&Kvals[kv_index<DM>(row, k, lane)], acc[k]);
 }
@@ -509,6 +512,7 @@ template <int DM>
 __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL, const int32_t* __restrict__ dofs,
                                                         const int64_t* __restrict__ slice_off,
                                                         const int32_t* __restrict__ rowlen,
+                                                        const int32_t* __restrict__ pos,
                                                         const int32_t* __restrict__ bcol, double* __restrict__ Kvals,
                                                         double* __restrict__ resid,
                                                         const uint8_t* __restrict__ owner) {
@@ -518,24 +522,27 @@ __global__ void __launch_bounds__(256) k_dirichlet_zero(int32_t k, int32_t maxL,
     const int32_t dof = dofs[q];
     const int32_t a = dof / DM, r = dof % DM;
     if (j >= rowlen[a]) return;
-    const int64_t rowa = slice_off[a >> 6] + j;
-    const int lanea = a & 63;
+    const int32_t pa = pos[a];
+    const int64_t rowa = slice_off[pa >> 6] + j;
+    const int lanea = pa & 63;
 #pragma unroll
     for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(rowa, r * DM + cc, lanea)] = 0.0;
     const int32_t b = bcol[rowa * SLICE + lanea];
     // mirror block: slot of a in the row of b (diagonal first, then ascending)
     int32_t js = 0;
     if (b != a) {
-        const int64_t offb = slice_off[b >> 6];
-        const int laneb = b & 63;
+        const int32_t pb = pos[b];
+        const int64_t offb = slice_off[pb >> 6];
+        const int laneb = pb & 63;
         const int32_t Lb = rowlen[b];
         js = -1;
         for (int32_t jj = 1; jj < Lb; ++jj)
             if (bcol[(offb + jj) * SLICE + laneb] == a) js = jj;
     }
     if (js >= 0) {
-        const int64_t rowb = slice_off[b >> 6] + js;
-        const int laneb = b & 63;
+        const int32_t pb = pos[b];
+        const int64_t rowb = slice_off[pb >> 6] + js;
+        const int laneb = pb & 63;
 #pragma unroll
         for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(rowb, cc * DM + r, laneb)] = 0.0;
     }
@@ -852,11 +859,11 @@ int launch_assemble(Ctx* c) {
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);
         if (c->dm == 3)
             hipLaunchKernelGGL((k_assemble_rows<3>), dim3(grid), dim3(bs), lds, c->stream, c->nn, c->npe, c->nGP,
-                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_slice_off,
+                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_pos, c->d_slice_off,
                                c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
         else
             hipLaunchKernelGGL((k_assemble_rows<2>), dim3(grid), dim3(bs), lds, c->stream, c->nn, c->npe, c->nGP,
-                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_slice_off,
+                               c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_pos, c->d_slice_off,
                                c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
     } else if (mode == FEMCY_ASM_ATOMIC) {
         FEMCY_HIP(hipMemsetAsync(c->d_Kvals, 0, (size_t)c->stored_rows * c->dm * c->dm * SLICE * sizeof(double),
@@ -865,10 +872,10 @@ int launch_assemble(Ctx* c) {
         const int grid = (int)((npair + bs - 1) / bs);
         if (c->dm == 3)
             hipLaunchKernelGGL((k_assemble_atomic<3>), dim3(grid), dim3(bs), 0, c->stream, npair, c->npe, c->nGP,
-                               c->d_elems, c->d_slotj, c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
+                               c->d_elems, c->d_slotj, c->d_pos, c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
         else
             hipLaunchKernelGGL((k_assemble_atomic<2>), dim3(grid), dim3(bs), 0, c->stream, npair, c->npe, c->nGP,
-                               c->d_elems, c->d_slotj, c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
+                               c->d_elems, c->d_slotj, c->d_pos, c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
     } else {
         const int64_t npos = c->stored_rows * SLICE;
         const int grid = (int)((npos + bs - 1) / bs);
@@ -907,10 +914,10 @@ int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_re
     const uint8_t* owner = c->comm ? c->d_owner : nullptr;
     if (c->dm == 3)
         hipLaunchKernelGGL((k_dirichlet_zero<3>), dim3(grid), dim3(bs), 0, c->stream, k, c->max_row_blocks, d_dofs,
-                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid, owner);
+                           c->d_slice_off, c->d_rowlen, c->d_pos, c->d_bcol, c->d_Kvals, d_resid, owner);
     else
         hipLaunchKernelGGL((k_dirichlet_zero<2>), dim3(grid), dim3(bs), 0, c->stream, k, c->max_row_blocks, d_dofs,
-                           c->d_slice_off, c->d_rowlen, c->d_bcol, c->d_Kvals, d_resid, owner);
+                           c->d_slice_off, c->d_rowlen, c->d_pos, c->d_bcol, c->d_Kvals, d_resid, owner);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }

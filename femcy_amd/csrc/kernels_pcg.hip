@@ -86,7 +86,8 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
 template <int DM, int WPS>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
-                                             const int32_t* __restrict__ bcol, const double* __restrict__ vals,
+                                             const int32_t* __restrict__ bcol, const int32_t* __restrict__ node_of,
+                                             const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done) {
     __shared__ double sm[BS / 64];
@@ -155,8 +156,8 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
             }
         }
         if (active && part == 0) {
-            const int64_t a = (int64_t)s * SLICE + lane;
-            if (a < nn) {
+            const int64_t a = node_of[(int64_t)s * SLICE + lane];   // row permutation (SELL-C-sigma); -1 = padding lane
+            if (a >= 0) {
 #pragma unroll
                 for (int r = 0; r < DM; ++r) {
                     y[a * DM + r] = acc[r];
@@ -173,12 +174,14 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
 
 // M = 1/diag(K) (M_init, conjugateGradientSolver.py:48-51): diagonal block is stored row 0 of the slice
 template <int DM>
-__global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int64_t* __restrict__ slice_off,
+__global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int32_t* __restrict__ pos,
+                                               const int64_t* __restrict__ slice_off,
                                                const double* __restrict__ vals, double* __restrict__ M, int invert) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nn) return;
-    const int64_t row = slice_off[a >> 6];
-    const int lane = (int)(a & 63);
+    const int32_t pa = pos[a];
+    const int64_t row = slice_off[pa >> 6];
+    const int lane = pa & 63;
 #pragma unroll
     for (int r = 0; r < DM; ++r) {
         const double dg = vals[kv_index<DM>(row, r * DM + r, lane)];
@@ -516,7 +519,7 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     if (ev && c->opt_timing_fence) hipLaunchKernelGGL(k_fence_noop, dim3(1), dim3(64), 0, c->stream);
 #define SPMV_ARGS                                                                                              \
     c->nn, c->xcd, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,  \
-        (const double*)c->d_Kvals, d_x, d_y, d_partials, done
+        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done
 #define SPMV_LAUNCH(DM_, WPS_)                                                                                 \
     do {                                                                                                       \
         if (ev)                                                                                                \
@@ -572,10 +575,10 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     // M = 1 / diag(K) (M_init).  Multi-rank: K is sub-assembled, so diag is summed over the interface first.
     const int jg = (c->nn + BS - 1) / BS;
     if (c->dm == 3)
-        hipLaunchKernelGGL((k_jacobi<3>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_slice_off, c->d_Kvals,
+        hipLaunchKernelGGL((k_jacobi<3>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_pos, c->d_slice_off, c->d_Kvals,
                            c->d_M, multi ? 0 : 1);
     else
-        hipLaunchKernelGGL((k_jacobi<2>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_slice_off, c->d_Kvals,
+        hipLaunchKernelGGL((k_jacobi<2>), dim3(jg), dim3(BS), 0, c->stream, c->nn, c->d_pos, c->d_slice_off, c->d_Kvals,
                            c->d_M, multi ? 0 : 1);
     if (multi) {
         int rc = iface_sum(c, c->d_M);

@@ -130,13 +130,33 @@ int build_pattern(Ctx* c) {
         }
     });
 
-    // ---- SELL-64 slices
+    // ---- SELL-C-sigma: inside windows of `sigma` nodes, rows are stored in order of decreasing length, so the 64
+    // rows of a slice have (nearly) equal length and the padding disappears (C3D10: 16 % -> < 2 %); the window keeps
+    // a slice's nodes spatially close, so the x-gathers stay local.  pos[a] = storage position of node a.
     const int32_t nslices = (nn + SLICE - 1) / SLICE;
+    const int32_t sigma = std::max(SLICE, (c->sell_sigma / SLICE) * SLICE);
+    std::vector<int32_t> node_of((size_t)nslices * SLICE, -1), pos(nn);
+    parallel_for((nn + sigma - 1) / sigma, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> idx;
+        for (int64_t w = lo; w < hi; ++w) {
+            const int32_t a0 = (int32_t)(w * sigma), a1 = std::min(nn, a0 + sigma);
+            idx.resize(a1 - a0);
+            for (int32_t a = a0; a < a1; ++a) idx[a - a0] = a;
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return rowlen[x] > rowlen[y]; });
+            for (int32_t k = 0; k < a1 - a0; ++k) {
+                node_of[a0 + k] = idx[k];
+                pos[idx[k]] = a0 + k;
+            }
+        }
+    });
     std::vector<int32_t> slice_len(nslices, 0);
     std::vector<int64_t> slice_off(nslices + 1, 0);
     for (int32_t s = 0; s < nslices; ++s) {
         int32_t L = 0;
-        for (int32_t a = s * SLICE; a < std::min(nn, (s + 1) * SLICE); ++a) L = std::max(L, rowlen[a]);
+        for (int32_t lane = 0; lane < SLICE; ++lane) {
+            const int32_t a = node_of[(size_t)s * SLICE + lane];
+            if (a >= 0) L = std::max(L, rowlen[a]);
+        }
         slice_len[s] = L;
         slice_off[s + 1] = slice_off[s] + L;
     }
@@ -145,16 +165,14 @@ int build_pattern(Ctx* c) {
         set_error("pattern too large for 32-bit block positions (%lld stored blocks)", (long long)stored_rows * SLICE);
         return FEMCY_EINVAL;
     }
-    std::vector<int32_t> rowlen_pad((size_t)nslices * SLICE, 0);
-    std::memcpy(rowlen_pad.data(), rowlen.data(), sizeof(int32_t) * nn);
     std::vector<int32_t> bcol((size_t)stored_rows * SLICE);
     parallel_for(nslices, [&](int64_t lo, int64_t hi, int) {
         for (int64_t s = lo; s < hi; ++s)
             for (int32_t j = 0; j < slice_len[s]; ++j)
                 for (int32_t lane = 0; lane < SLICE; ++lane) {
-                    int64_t a = s * SLICE + lane;
+                    const int32_t a = node_of[s * SLICE + lane];
                     int32_t col = 0;
-                    if (a < nn) col = (j < rowlen[a]) ? adj[adj_ptr[a] + j] : (int32_t)a;   // padding: zero block on own node
+                    if (a >= 0) col = (j < rowlen[a]) ? adj[adj_ptr[a] + j] : a;   // padding: zero block on own node
                     bcol[(slice_off[s] + j) * SLICE + lane] = col;
                 }
     });
@@ -167,7 +185,9 @@ int build_pattern(Ctx* c) {
     }
     std::vector<uint16_t> slotj((size_t)npair);
     std::vector<int32_t> ctr_cnt((size_t)stored_rows * SLICE + 1, 0);
-    auto block_pos = [&](int32_t a, int32_t j) -> int64_t { return (slice_off[a / SLICE] + j) * SLICE + (a % SLICE); };
+    auto block_pos = [&](int32_t a, int32_t j) -> int64_t {
+        return (slice_off[pos[a] / SLICE] + j) * SLICE + (pos[a] % SLICE);
+    };
     parallel_for(ne, [&](int64_t lo, int64_t hi, int) {
         for (int64_t e = lo; e < hi; ++e)
             for (int32_t la = 0; la < npe; ++la) {
@@ -205,14 +225,17 @@ int build_pattern(Ctx* c) {
     c->max_node_elems = max_node_elems;
     c->h_slice_len = slice_len;
     c->h_slice_off.assign(slice_off.begin(), slice_off.end());
-    c->h_rowlen = rowlen_pad;
+    c->h_rowlen = rowlen;
+    c->h_pos = pos;
     c->h_bcol = bcol;
     spmv_split(c);
 
     int rc;
     if ((rc = upload(&c->d_slice_len, slice_len))) return rc;
     if ((rc = upload(&c->d_slice_off, c->h_slice_off))) return rc;
-    if ((rc = upload(&c->d_rowlen, rowlen_pad))) return rc;
+    if ((rc = upload(&c->d_rowlen, rowlen))) return rc;
+    if ((rc = upload(&c->d_pos, pos))) return rc;
+    if ((rc = upload(&c->d_node_of, node_of))) return rc;
     if ((rc = upload(&c->d_bcol, bcol))) return rc;
     if ((rc = upload(&c->d_slotj, slotj))) return rc;
     if ((rc = upload(&c->d_ctr_ptr, ctr_cnt))) return rc;

@@ -71,11 +71,23 @@ def to_quadratic(nodes: np.ndarray, tets: np.ndarray):
     return np.concatenate([nodes, mid], axis=0), t10.astype(np.int32)
 
 
-def twist_plate(nx: int, ny: int, nz: int, quadratic: bool = False) -> Dict:
+def spatial_renumber(nodes: np.ndarray, el: np.ndarray):
+    """renumber nodes in (z, y, x) lexicographic order: mid-side nodes of a quadratic mesh then sit next to the
+    corner nodes they connect (to_quadratic appends them after all corners), which is what the SpMV's x-gathers
+    and the sliced-ELL padding like."""
+    order = np.lexsort((nodes[:, 0], nodes[:, 1], nodes[:, 2]))
+    new_id = np.empty(order.size, dtype=np.int64)
+    new_id[order] = np.arange(order.size)
+    return np.ascontiguousarray(nodes[order]), new_id[el].astype(np.int32)
+
+
+def twist_plate(nx: int, ny: int, nz: int, quadratic: bool = False, renumber: bool = False) -> Dict:
     """the twist-plate model on an (nx,ny,nz)-cell grid, in the reader's vocabulary."""
     nodes, el = plate_grid(nx, ny, nz)
     if quadratic:
         nodes, el = to_quadratic(nodes, el)
+        if renumber:
+            nodes, el = spatial_renumber(nodes, el)
     tol = 1e-9 * BOX[2]
     clamp = np.nonzero(np.abs(nodes[:, 2] - BOX[2]) < tol)[0]
     twist = np.nonzero(np.abs(nodes[:, 2]) < tol)[0]
@@ -89,9 +101,9 @@ def twist_plate(nx: int, ny: int, nz: int, quadratic: bool = False) -> Dict:
             "cells": (nx, ny, nz)}
 
 
-def twist_plate_k(k: int, quadratic: bool = False) -> Dict:
+def twist_plate_k(k: int, quadratic: bool = False, renumber: bool = False) -> Dict:
     """BASELINE.md family: cells (8k, k, 12k)."""
-    return twist_plate(8 * k, k, 12 * k, quadratic)
+    return twist_plate(8 * k, k, 12 * k, quadratic, renumber)
 
 
 def scaling_cells(n_gpus: int) -> Tuple[int, int, int]:

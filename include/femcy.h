@@ -90,6 +90,8 @@ enum femcy_option {
                                 /* k > 1 = same, but only every k-th SpMV launch is sampled     */
     FEMCY_OPT_SPMV_VARIANT = 3, /* SpMV wavefronts per 64-node slice: 0 auto (by mean row length), 1, 2, 4 */
     FEMCY_OPT_EW_GRID = 4,      /* cap on workgroups of the element-wise PCG kernels (tuning)   */
+    FEMCY_OPT_SELL_SIGMA = 6,   /* rows are sorted by length inside windows of this many nodes before slicing
+                                   (SELL-C-sigma, default 4096; 64 = natural order); set before build_pattern */
     FEMCY_OPT_PCG_GRAPH = 5     /* hipGraph replay of poll-bursts of PCG iterations: 0 off, 1 auto (default:
                                    below 2e5 DOF, where the loop is launch-bound), 2 always             */
 };

@@ -382,3 +382,38 @@ def test_dofsets_equal_host_list_calls(gpu_ctx_factory):
     assert abs(a.get_K_bsr() - b.get_K_bsr()).max() == 0.0
     with pytest.raises(be.FemcyError):
         b.dofset_fill(999, be.VEC_DOF, 0.0)
+
+
+@pytest.mark.parametrize("name", ["twist_C3D10_coarse.inp", "ellip_membrane_linEle_localVeryFine.inp"])
+def test_sell_sigma_row_order_is_transparent(gpu_ctx_factory, name):
+    """SELL-C-sigma stores rows sorted by length inside windows; results must not depend on the window
+    (64 = natural order) and the padding must not grow."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    outs = []
+    for sigma in (64, 256, 4096):
+        ctx = gpu_ctx_factory()
+        ctx.set_option(be.OPT_SELL_SIGMA, sigma)
+        ctx.set_mesh(inp.nodes, el)
+        ctx.set_element(inp.ELE)
+        ctx.set_material(mat)
+        info = ctx.build_pattern()
+        u = smooth_disp(inp.nodes, 0.01)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.assemble_K(be.VEC_DOF)
+        x = np.cos(np.arange(ctx.n) * 0.3)
+        ctx.upload(be.VEC_TMP0, x)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * ctx.dm + b["dof"] for b in inp.dirichlet_bc_info]))
+        ctx.upload(be.VEC_RESIDUAL, x)
+        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-6)
+        outs.append((info.stored_blocks, ctx.get_K_bsr().tocsr(), ctx.download(be.VEC_TMP1), it, ctx.download(be.VEC_X)))
+        with pytest.raises(be.FemcyError):
+            ctx.set_option(be.OPT_SELL_SIGMA, 128)          # only before the pattern exists
+    s0, K0, y0, it0, x0 = outs[0]
+    for s, K, y, it, xs in outs[1:]:
+        assert s <= s0
+        assert abs(K - K0).max() == 0.0                                   # identical blocks
+        assert rel(y, y0) < 1e-14        # long rows are split over wavefronts by slice length: order may differ
+        assert it == it0 and np.linalg.norm(xs - x0) <= 1e-9 * np.linalg.norm(x0)

@@ -16,7 +16,8 @@ def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     quad = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
     t0 = time.time()
-    m = meshgen.twist_plate_k(k, quadratic=quad)
+    renum = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+    m = meshgen.twist_plate_k(k, quadratic=quad, renumber=renum)
     print(f"mesh k={k} quad={quad}: {m['elements'].shape[0]} elements, {m['nodes'].shape[0]} nodes  ({time.time()-t0:.2f}s)")
     ctx = be.Context(0)
     ctx.set_mesh(m["nodes"], m["elements"])
