@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfemcy_hip.so")
+LIB_PATH = os.environ.get("FEMCY_HIP_LIB") or os.path.join(_HERE, "libfemcy_hip.so")   # override: kernel A/B runs
 
 # enum femcy_vec
 VEC_DOF, VEC_RHS, VEC_RESIDUAL, VEC_FORCE, VEC_DU, VEC_DOF_OLD, VEC_X, VEC_TMP0, VEC_TMP1 = range(9)

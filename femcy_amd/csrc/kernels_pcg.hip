@@ -123,7 +123,10 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
             // pairs of entries as double2 (16 B per lane, 1 KiB per wave instruction); see kv_index()
             const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals + off * (int64_t)(DD * SLICE)) + lane;
             const double* __restrict__ vs = vals + off * (int64_t)(DD * SLICE) + NP * (2 * SLICE) + lane;
-#pragma unroll 2
+#ifndef FEMCY_SPMV_UNROLL
+#define FEMCY_SPMV_UNROLL 2
+#endif
+#pragma unroll FEMCY_SPMV_UNROLL
             for (int32_t j = j0; j < j1; ++j) {
                 const int64_t col = bc[(int64_t)j * SLICE];
                 double xv[DM];
