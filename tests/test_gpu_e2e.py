@@ -96,3 +96,35 @@ def test_readme_known_answer_end_to_end(tmp_path):
     rhs_work = 0.5 * float(system.rhs.to_numpy() @ u)      # linear elasticity: W = 1/2 f.u (Dirichlet values are 0)
     assert e0 > 0 and abs(e0 - rhs_work) < 1e-3 * e0       # Green strain in the energy: equal up to O(|grad u|)
     system.ctx.close()
+
+
+def test_synthetic_twist_plate_end_to_end():
+    """BASELINE configs[2]'s model (generated twist plate, nlgeom, user Dirichlet BC) through the whole
+    increment / cut-back / modified-Newton driver on the device, at a size the GPU finishes in seconds
+    (15 552 C3D4; the 1 M mesh is exercised kernel-by-kernel in test_gpu_fullsize.py).  No oracle at this size:
+    checked through invariants of the prescribed motion."""
+    from types import SimpleNamespace
+    from femcy_amd import meshgen
+    from femcy_amd.body import Body
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    m = meshgen.twist_plate_k(3)
+    ELE = Element_linear_tetrahedral()
+    inp = SimpleNamespace(nodes=m["nodes"], eSets={"C3D4": m["elements"]}, ELE=ELE,
+                          dirichlet_bc_info=m["dirichlet_bc_info"], neumann_bc_info=[], time_incs=m["time_incs"],
+                          geometric_nonlinear=True, materials={"Elastic": LinearIsotropic(*m["elastic"])})
+    s = System_of_equations(Body(inp.nodes, m["elements"], ELE), inp.materials["Elastic"], True, verbose=False)
+    s.solve(inp)
+    u = s.dof.to_numpy().reshape(-1, 3)
+    assert s.time0 == 1.0                                              # the full 180 degree twist was reached
+    assert any(not i["converged"] for i in s.increments)               # ... through automatic cut-backs
+    clamp, twist = m["node_sets"]["Set-10"], m["node_sets"]["fit_right_z"]
+    assert np.abs(u[clamp]).max() == 0.0
+    X = m["nodes"][twist]
+    target = np.stack([80.0 - 2 * X[:, 0], 10.0 - 2 * X[:, 1], np.zeros(len(X))], axis=1)   # rotation by pi about (40, 5)
+    assert np.abs(u[twist] - target).max() < 1e-9
+    assert abs(np.abs(u).max() - 80.0) < 1e-6
+    s.compute_strain_stress()
+    assert np.isfinite(s.mises_stress.to_numpy()).all() and (s.vol.to_numpy() > 0).all()   # no inverted element at the end
+    s.ctx.close()
