@@ -51,7 +51,9 @@ void spmv_split(Ctx* c) {
     int wps = c->opt_spmv_variant;
     if (wps != 1 && wps != 2 && wps != 4) {
         const double mean_len = nslices ? (double)stored_rows / nslices : 0.0;
-        wps = mean_len <= 24.0 ? 1 : (mean_len <= 48.0 ? 2 : 4);
+        // rocprofv3, C3D10 plate (mean 27 blocks per row): 99 / 88 / 84 us for 1 / 2 / 4 wavefronts per slice;
+        // C3D4 (15 blocks per row): equal
+        wps = mean_len <= 20.0 ? 1 : 4;
     }
     c->spmv_wps = wps;
     const int spb = WAVES / wps;   // slices per workgroup
