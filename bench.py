@@ -135,9 +135,11 @@ def main():
         ctx.iface_sum(be.VEC_FORCE)
     ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)           # Newton residual = f_int - rhs
 
+    cons_set = ctx.dofset(cons)            # device-resident *Boundary DOF list (what System_of_equations uses)
+
     def step():
         ctx.assemble_K(be.VEC_DOF)
-        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
         return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
 
     ctx.set_option(be.OPT_TIMING, args.sample)    # HIP events on the ctx stream; every k-th SpMV launch is sampled

@@ -91,6 +91,14 @@ class MockContext:
         from oracle import femcy_oracle as orc
         self.K = orc.assemble_K(self.topo, self.vec[u_vec], self.mat.C)
 
+    def dofset(self, dofs):
+        self._sets = getattr(self, "_sets", [])
+        self._sets.append(np.asarray(dofs, dtype=np.int64))
+        return len(self._sets) - 1
+
+    def dofset_dirichlet_newton(self, ds, vid):
+        self.dirichlet_newton(self._sets[ds], vid)
+
     def dirichlet_newton(self, cons, vid):
         from oracle import femcy_oracle as orc
         cons = np.asarray(cons, dtype=np.int64)
