@@ -1,0 +1,32 @@
+"""-m gpu: bench.py prints exactly one JSON line with the contract's keys (small mesh, seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--iters", "20",
+                          "--cells", "16,4,24"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), (key, d[key])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64"
+    assert d["metric"].startswith("CG iters/sec") and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and r["launches_timed"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "CG iters/s" and c["sample"]
+    assert d["value"] > 0 and d["cg_iters_per_s"] > 0 and d["assemblies_per_s"] > 0
