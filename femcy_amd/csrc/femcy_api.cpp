@@ -229,6 +229,14 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             pcg_graph_reset(c);
             c->ew_cap = (int)value;
             break;
+        case 101:   /* test knob: SpMV workgroups per XCD (1 forces the in-kernel loop on small meshes) */
+            FEMCY_REQUIRE(value >= 1 && value <= 512, "workgroups per XCD out of range");
+            c->spmv_bpx_cap = (int32_t)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
+            break;
         case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
             c->opt_timing_fence = value ? 1 : 0;
             break;

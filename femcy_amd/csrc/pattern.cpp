@@ -67,7 +67,7 @@ void spmv_split(Ctx* c) {
     c->xcd.start[NX] = nslices;
     int32_t per = 1;
     for (int k = 0; k < NX; ++k) per = std::max(per, (c->xcd.start[k + 1] - c->xcd.start[k] + spb - 1) / spb);
-    c->spmv_grid = std::min(per, 256) * NX;   // <= 2048 workgroups: larger ranges are looped inside the kernel
+    c->spmv_grid = std::min(per, std::max(1, c->spmv_bpx_cap)) * NX;   // <= 2048 workgroups: larger ranges are looped inside the kernel
 }
 
 int build_pattern(Ctx* c) {

@@ -103,6 +103,10 @@ def test_spmv_and_vectors(gpu_ctx_factory, name):
         ctx.set_option(be.OPT_SPMV_VARIANT, wps)
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
         assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
+        ctx.set_option(101, 1)                  # one workgroup per XCD: the in-kernel loop over slice groups
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)      # (what meshes beyond ~6 M elements use)
+        assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
+        ctx.set_option(101, 256)
     ctx.set_option(be.OPT_SPMV_VARIANT, 0)
     # tiGadgets
     ctx.upload(be.VEC_RHS, 2.0 * x)
