@@ -50,13 +50,23 @@ class Body:
         """facet (sorted global node tuple, facets as listed by ELE.facet_natural_coos) -> the one
         element that owns it, for facets that belong to a single element."""
         if not hasattr(self, "boundary") or redo:
-            facetDic = {}
-            for facet in self.ELE.facet_natural_coos.keys():
-                keys = np.sort(self.np_elements[:, list(facet)], axis=1)
-                for iele, key in enumerate(map(tuple, keys.tolist())):
-                    facetDic.setdefault(key, []).append(iele)
-            self.facetDic = facetDic
-            self.boundary = {f: es[0] for f, es in facetDic.items() if len(es) == 1}
+            el = self.np_elements
+            facets = list(self.ELE.facet_natural_coos.keys())
+            sizes = {len(f) for f in facets}
+            boundary = {}
+            for k in sizes:                                   # all facets of one element type have one size; be general
+                fk = [f for f in facets if len(f) == k]
+                keys = np.concatenate([np.sort(el[:, list(f)], axis=1) for f in fk])          # [len(fk)*ne, k]
+                owner = np.tile(np.arange(el.shape[0]), len(fk))
+                order = np.lexsort(keys.T[::-1])
+                ks = keys[order]
+                new = np.ones(ks.shape[0], dtype=bool)
+                new[1:] = (ks[1:] != ks[:-1]).any(axis=1)
+                start = np.nonzero(new)[0]
+                count = np.diff(np.append(start, ks.shape[0]))
+                single = start[count == 1]
+                boundary.update(zip(map(tuple, ks[single].tolist()), owner[order[single]].tolist()))
+            self.boundary = boundary
             node2boundary = {}
             for f in self.boundary:
                 for node in f:
@@ -64,6 +74,19 @@ class Body:
             self.node2boundary = node2boundary
             self.boundaryNodes = set(node2boundary.keys())
         return self.boundary
+
+    @property
+    def facetDic(self):
+        """every facet -> list of the elements that hold it (reference body.py:203-216); built on demand, the
+        boundary query above does not need the interior facets as Python objects."""
+        if not hasattr(self, "_facetDic"):
+            d = {}
+            for facet in self.ELE.facet_natural_coos.keys():
+                keys = np.sort(self.np_elements[:, list(facet)], axis=1)
+                for iele, key in enumerate(map(tuple, keys.tolist())):
+                    d.setdefault(key, []).append(iele)
+            self._facetDic = d
+        return self._facetDic
 
     def get_surfaceEdges(self, redo=False):
         if not hasattr(self, "surfaceEdges") or redo:

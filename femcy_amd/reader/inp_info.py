@@ -47,9 +47,59 @@ ELEMENT_CLASSES = {"CPE3": Element_linear_triangular, "CPS3": Element_linear_tri
                    "C3D4": Element_linear_tetrahedral, "C3D10": Element_quadratic_tetrahedral}
 
 
+class _Deck:
+    """the file, read once: its lines and the positions of the lines that contain '*' (keyword and comment lines).
+    Data blocks are the runs between two such lines, so the section readers below visit keyword lines only and
+    hand whole data blocks to numpy -- at 1e6 elements the per-line Python loops of the reference
+    (inp_info.py:28-113) were the wall-clock, not the solve."""
+
+    def __init__(self, path):
+        with open(path, "r") as fh:
+            self.lines = fh.read().split("\n")
+        self.star = [i for i, line in enumerate(self.lines) if "*" in line]
+        self.star.append(len(self.lines))            # sentinel: end of file closes the last block
+
+    def keywords(self):
+        """(keyword line, its data lines) for every non-comment keyword line, in file order.  Comment lines are
+        transparent (the data of a keyword continue after a `**` line, as in the reference's line loops); a
+        '*' inside a data line ends the block."""
+        lines, star = self.lines, self.star
+        k, last = 0, len(star) - 1
+        while k < last:
+            line = lines[star[k]]
+            if line[0] == "*" and not _is_comment(line):
+                block = lines[star[k] + 1:star[k + 1]]
+                j = k + 1
+                while j < last and _is_comment(lines[star[j]]):
+                    block = block + lines[star[j] + 1:star[j + 1]]
+                    j += 1
+                yield line, block
+                k = j
+            else:
+                k += 1
+
+
+_deck_cache = {}
+
+
+def _deck(path) -> "_Deck":
+    import os
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    if key not in _deck_cache:
+        _deck_cache.clear()                            # one deck at a time
+        _deck_cache[key] = _Deck(path)
+    return _deck_cache[key]
+
+
 def _lines(path):
-    with open(path, "r") as fh:
-        return fh.read().split("\n")
+    return _deck(path).lines
+
+
+def _numbers(block, dtype):
+    """all comma-separated numbers of a data block (trailing commas and blank lines tolerated)."""
+    body = ",".join(t for t in (line.rstrip().rstrip(",") for line in block) if t)
+    return np.fromstring(body, dtype=dtype, sep=",") if body else np.zeros(0, dtype=dtype)
 
 
 def _is_comment(line):
@@ -69,35 +119,27 @@ class InpInfo(InpInfoBase):
 
     # ------------------------------------------------------------------ nodes and elements
     def read_node_element(self, fileName):
-        lines = _lines(fileName)
-        labels, coords = [], []
-        in_nodes = False
-        for line in lines:
-            if "*" in line:
-                if in_nodes:
-                    break
-                in_nodes = ("*Node" in line) or ("*NODE" in line) or ("*node" in line)
-                continue
-            if in_nodes and line.strip():
-                rec = [float(t) for t in line.split(",")]
-                labels.append(int(rec[0]))
-                coords.append(rec[1:])
+        deck = _deck(fileName)
+        lines, star = deck.lines, deck.star
+        labels, coords = np.zeros(0, dtype=np.int64), np.zeros((0, 3))
+        for k in range(len(star) - 1):                       # the first *Node block only (reference :28-45)
+            line = lines[star[k]]
+            if ("*Node" in line) or ("*NODE" in line) or ("*node" in line):
+                block = [t for t in lines[star[k] + 1:star[k + 1]] if t.strip()]
+                if block:
+                    width = block[0].count(",") + 1
+                    rec = _numbers(block, np.float64).reshape(-1, width)
+                    labels, coords = rec[:, 0].astype(np.int64), np.ascontiguousarray(rec[:, 1:])
+                break
 
-        tokens: Dict[str, List[str]] = {}
-        current = None
-        for line in lines:
-            if "*" in line:
-                current = None
-                if ("*ELEMENT" in line) or ("*Element" in line) or ("*element" in line):
-                    if ("TYPE=" in line) or ("type=" in line):
-                        current = next((t for t in _TYPE_SCAN_ORDER if t in line), None)
-                        if current is not None:
-                            tokens.setdefault(current, [])
-                continue
-            if current is not None:
-                body = line.rstrip().rstrip(",")
-                if body:
-                    tokens[current].extend(body.split(","))
+        tokens: Dict[str, List[np.ndarray]] = {}
+        for k in range(len(star) - 1):
+            line = lines[star[k]]
+            if ("*ELEMENT" in line) or ("*Element" in line) or ("*element" in line):
+                if ("TYPE=" in line) or ("type=" in line):
+                    current = next((t for t in _TYPE_SCAN_ORDER if t in line), None)
+                    if current is not None:
+                        tokens.setdefault(current, []).append(_numbers(lines[star[k] + 1:star[k + 1]], np.int64))
         if len(tokens) > 1:
             print("\033[31;1m there are multiple element types in the file: {} \033[0m".format(list(tokens)))
 
@@ -107,9 +149,9 @@ class InpInfo(InpInfoBase):
                 print("\033[31;1m Error, element type {} is not found! \033[0m".format(eType))
                 sys.exit(1)
             width, keep = _RECORD[eType]
-            eSets[eType] = np.array([int(t) for t in toks], dtype=np.int64).reshape((-1, width))[:, keep]
+            eSets[eType] = np.concatenate(toks).reshape((-1, width))[:, keep]
 
-        nodes, eSets = self.sequence_order_of_body(dict(zip(labels, coords)), eSets)
+        nodes, eSets = self.sequence_order_of_body((labels, coords), eSets)
         first = list(eSets.keys())[0]
         if first not in ELEMENT_CLASSES:
             raise ValueError("element type {} has no element class in element_zoo".format(first))
@@ -120,42 +162,39 @@ class InpInfo(InpInfoBase):
 
     def sequence_order_of_body(self, nodes, eSets):
         """node labels -> 0-based positions in file order; connectivity renumbered accordingly."""
-        labels = np.fromiter(nodes.keys(), dtype=np.int64, count=len(nodes))
+        if isinstance(nodes, dict):                           # the reference's calling convention (:353-368)
+            labels = np.fromiter(nodes.keys(), dtype=np.int64, count=len(nodes))
+            coords = np.array(list(nodes.values()), dtype=np.float64)
+        else:
+            labels, coords = nodes
+            _, first = np.unique(labels, return_index=True)   # a repeated label keeps its first position and
+            if first.size != labels.size:                     # its last coordinates, as a dict would
+                keep = np.sort(first)
+                last = {int(l): i for i, l in enumerate(labels)}
+                coords = coords[[last[int(l)] for l in labels[keep]]]
+                labels = labels[keep]
         lut = np.full(int(labels.max()) + 1, -1, dtype=np.int64)
         lut[labels] = np.arange(labels.size)
         for eType in eSets:
             eSets[eType] = lut[eSets[eType]]
-        return np.array(list(nodes.values()), dtype=np.float64), eSets
+        return coords, eSets
 
     # --------------------------------------------------------------------------------- sets
     def read_set(self, fileName):
         node_sets, ele_sets = {}, {}
-        target, generate = None, False
-        for line in _lines(fileName):
-            if not line or _is_comment(line):
-                continue
-            if line[0] == "*":
-                fields = line.split(",")
-                if fields[0] in ("*Nset", "*Elset") and "instance" in line:
-                    store = node_sets if fields[0] == "*Nset" else ele_sets
-                    name = fields[1].split("=")[1]
-                    store[name] = set()          # a repeated name starts over, as in the reference
-                    target = store[name]
-                    generate = "generate" in fields[-1]
+        for line, block in _deck(fileName).keywords():
+            fields = line.split(",")
+            if fields[0] in ("*Nset", "*Elset") and "instance" in line:
+                store = node_sets if fields[0] == "*Nset" else ele_sets
+                name = fields[1].split("=")[1]
+                store[name] = set()                  # a repeated name starts over, as in the reference
+                if "generate" in fields[-1]:
+                    for data_line in block:
+                        if data_line:
+                            d = _numbers([data_line], np.int64)
+                            store[name].update(np.arange(d[0], d[1] + d[2], d[2]).tolist())
                 else:
-                    target = None
-                continue
-            if target is None:
-                continue
-            toks = line.split(",")
-            try:
-                data = [int(t) for t in toks]
-            except ValueError:
-                data = [int(t) for t in toks[:-1]]
-            if generate:
-                target.update(np.arange(data[0], data[1] + data[2], data[2]).tolist())
-            else:
-                target.update(data)
+                    store[name].update(_numbers(block, np.int64).tolist())
         as_array = lambda s: np.array(sorted(s), dtype=np.int64) - 1
         return {k: as_array(v) for k, v in node_sets.items()}, {k: as_array(v) for k, v in ele_sets.items()}
 
@@ -163,23 +202,17 @@ class InpInfo(InpInfoBase):
         if not hasattr(self, "eSets"):
             self.nodes, self.eSets = self.read_node_element(fileName)
         raw: Dict[str, List[tuple]] = {}
-        name = None
-        for line in _lines(fileName):
-            if not line or _is_comment(line):
-                continue
-            if line[0] == "*":
-                fields = line.split(",")
-                if fields[0] == "*Surface":
-                    name = fields[2].split("=")[1]
-                    raw[name] = []
-                else:
-                    name = None
-                continue
-            if name is not None:
-                fields = line.split(",")
-                raw[name].append((fields[0], fields[1]))
+        for line, block in _deck(fileName).keywords():
+            fields = line.split(",")
+            if fields[0] == "*Surface":
+                name = fields[2].split("=")[1]
+                raw[name] = []
+                for data_line in block:
+                    if data_line:
+                        f = data_line.split(",")
+                        raw[name].append((f[0], f[1]))
 
-        _, ele_sets = self.read_set(fileName)
+        ele_sets = self.ele_sets if hasattr(self, "ele_sets") else self.read_set(fileName)[1]
         conn = self.eSets[list(self.eSets.keys())[0]]
         face_sets = {}
         for sname, entries in raw.items():
@@ -199,49 +232,38 @@ class InpInfo(InpInfoBase):
         if not hasattr(self, "face_sets"):
             self.face_sets = self.read_face_set(fileName)
         dirichlet, neumann = [], []
-        mode, user = None, False
-        for line in _lines(fileName):
-            if not line or _is_comment(line):
-                continue
-            if line[0] == "*":
-                if line[0:9] == "*Boundary":
-                    mode, user = "D", ("user" in line)
-                elif line[0:7] == "*Dsload":
-                    mode = "N"
-                else:
-                    mode = None
-                continue
-            f = line.split(",")
-            if mode == "D":
-                dirichlet.append({"node_set": self.node_sets[f[0]], "dof": int(f[1]) - 1,
-                                  "val": float(f[3]) if len(f) >= 4 else 0., "user": user})
-            elif mode == "N":
-                if len(f) <= 3:       # pressure: positive value pushes against the outward normal
-                    neumann.append({"face_set": self.face_sets[f[0]], "traction": -float(f[2])})
-                else:                 # TRVEC: magnitude + direction
-                    neumann.append({"face_set": self.face_sets[f[0]], "traction": float(f[2]),
-                                    "direction": np.array([float(t) for t in f[3:6]])})
+        for line, block in _deck(fileName).keywords():
+            if line[0:9] == "*Boundary":
+                user = "user" in line
+                for data_line in block:
+                    if data_line:
+                        f = data_line.split(",")
+                        dirichlet.append({"node_set": self.node_sets[f[0]], "dof": int(f[1]) - 1,
+                                          "val": float(f[3]) if len(f) >= 4 else 0., "user": user})
+            elif line[0:7] == "*Dsload":
+                for data_line in block:
+                    if not data_line:
+                        continue
+                    f = data_line.split(",")
+                    if len(f) <= 3:       # pressure: positive value pushes against the outward normal
+                        neumann.append({"face_set": self.face_sets[f[0]], "traction": -float(f[2])})
+                    else:                 # TRVEC: magnitude + direction
+                        neumann.append({"face_set": self.face_sets[f[0]], "traction": float(f[2]),
+                                        "direction": np.array([float(t) for t in f[3:6]])})
         return dirichlet, neumann
 
     # ---------------------------------------------------------------------------- materials
     def read_material(self, fileName):
         raw = {}
-        state, mtype = None, None
-        for line in _lines(fileName):
-            if not line or _is_comment(line):
-                continue
-            if line[0] == "*" and line[0:9] == "*Material":
-                state = "expect_type"
-                continue
-            if state == "expect_type":
-                mtype = line.split("*")[1]
-                state = "data"
-                continue
-            if state == "data":
-                if line[0] != "*":
-                    raw[mtype] = [float(t) for t in line.split(",")]
-                else:
-                    state = None
+        expect_type = False
+        for line, block in _deck(fileName).keywords():        # *Material, then the type keyword and its data line
+            if line[0:9] == "*Material":
+                expect_type = True
+            elif expect_type:
+                expect_type = False
+                data = [t for t in block if t]
+                if data:
+                    raw[line.split("*")[1]] = [float(t) for t in data[-1].split(",")]
         ele_type = list(self.eSets.keys())[0]
         family = ele_type[0:3]
         materials = {}
@@ -262,20 +284,17 @@ class InpInfo(InpInfoBase):
 
     # ---------------------------------------------------------------------- step definition
     def read_geometric_nonlinear(self, fileName) -> bool:
-        for line in _lines(fileName):
+        for line, _ in _deck(fileName).keywords():
             if line[:5] == "*Step":
                 return line.split(",")[-1].split("nlgeom=")[-1] != "NO"
         raise ValueError("no *Step keyword in {}".format(fileName))
 
     def read_time_inc(self, fileName):
-        seen = False
-        for line in _lines(fileName):
+        for line, block in _deck(fileName).keywords():
             if line[:7] == "*Static":
-                seen = True
-                continue
-            if seen:
-                if _is_comment(line):
-                    continue
-                ini, tmax, dmin, dmax = [float(t) for t in line.split(",")][:4]
-                return {"ini_inc": min(ini, dmax), "max_time": tmax, "min_inc": dmin, "max_inc": dmax}
+                data = [t for t in block if t]
+                if data:
+                    ini, tmax, dmin, dmax = [float(t) for t in data[0].split(",")][:4]
+                    return {"ini_inc": min(ini, dmax), "max_time": tmax, "min_inc": dmin, "max_inc": dmax}
+                break
         raise ValueError("no *Static data line in {}".format(fileName))

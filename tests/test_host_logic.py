@@ -130,6 +130,40 @@ def test_reader_quirks(tmp_path):
     # generate expands start, stop, step inclusively
     p.write_text(base.replace("*End Assembly", "*Nset, nset=gen, instance=x, generate\n 3, 9, 3\n*End Assembly"))
     assert InpInfo(str(p)).node_sets["gen"].tolist() == [2, 5, 8]
+    # a `**` comment inside a data block does not end it; trailing commas and blank lines are tolerated
+    p.write_text(base.replace("*End Assembly", "*Nset, nset=cm, instance=x\n 1, 2, 3,\n** note\n 7, 8\n\n*End Assembly"))
+    assert InpInfo(str(p)).node_sets["cm"].tolist() == [0, 1, 2, 6, 7]
+    # ... but it does end the *Node block (reference inp_info.py:28-45 breaks at the first line holding a '*')
+    lines = base.split("\n")
+    k = next(i for i, l in enumerate(lines) if l.startswith("*Node")) + 3
+    p.write_text("\n".join(lines[:k] + ["** cut"] + lines[k:]))
+    with pytest.raises((IndexError, ValueError)):        # the connectivity now refers to labels that were not read
+        InpInfo(str(p))
+
+
+def test_reader_every_deck_equals_line_by_line_parse():
+    """the block-wise numpy parse of nodes / elements equals a plain per-line parse of the same decks."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(deck("twist_plate_C3D4.inp")), "*.inp"))):
+        inp = InpInfo(path)
+        nodes, conn, mode = {}, [], None
+        for line in open(path).read().split("\n"):
+            if "*" in line:
+                if mode == "n":
+                    seen_nodes = True
+                mode = "n" if line.startswith("*Node") and not nodes else "e" if line.startswith("*Element") else None
+                continue
+            if line.strip() and mode == "n":
+                t = line.split(",")
+                nodes[int(t[0])] = [float(v) for v in t[1:]]
+            elif line.strip() and mode == "e":
+                conn.extend(int(v) for v in line.rstrip().rstrip(",").split(","))
+        order = {lab: i for i, lab in enumerate(nodes)}
+        et = list(inp.eSets)[0]
+        el = inp.eSets[et]
+        ref = np.array(conn).reshape(-1, el.shape[1] + 1)[:, 1:]
+        assert np.array_equal(inp.nodes, np.array(list(nodes.values())))
+        assert np.array_equal(el, np.vectorize(order.get)(ref))
 
 
 # ------------------------------------------------------------------------ topology / meshes
@@ -143,6 +177,7 @@ def test_body_topology_matches_oracle():
         assert co[a] == topo.adj_idx[topo.adj_ptr[a]:topo.adj_ptr[a + 1]].tolist()
         assert body.get_nodeEles()[a] == sorted(np.where((el == a).any(axis=1))[0].tolist())
     assert body.get_boundary() == topo.boundary()
+    assert body.get_boundary() == {f: es[0] for f, es in body.facetDic.items() if len(es) == 1}
     ij = topo.sparseIJ()
     assert ij.shape == (969, np.diff(topo.adj_ptr).max() * 3 + 1) and (ij[:, 0] % 3 == 0).all()
 
