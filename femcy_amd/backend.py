@@ -35,7 +35,7 @@ EXPORTS = [
     "femcy_vec_sub", "femcy_vec_axpy", "femcy_vec_scale", "femcy_vec_norm", "femcy_vec_absmax",
     "femcy_assemble_K", "femcy_internal_force", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
     "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
-    "femcy_dofset_scatter", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
+    "femcy_dofset_scatter", "femcy_loadset_create", "femcy_loadset_neumann", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
     "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_init", "femcy_iface_sum",
 ]
@@ -101,6 +101,8 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_dofset_create": [p, p, i32, C.POINTER(i32)], "femcy_dofset_dirichlet_newton": [p, i32, cint],
         "femcy_dofset_dirichlet_linear": [p, i32, f64, cint], "femcy_dofset_fill": [p, i32, cint, f64],
         "femcy_dofset_scatter": [p, i32, cint, p],
+        "femcy_loadset_create": [p, i32, i32, i32, p, p, p, p, p, i32, p, p, C.POINTER(i32)],
+        "femcy_loadset_neumann": [p, i32, f64, p, cint],
         "femcy_spmv": [p, cint, cint],
         "femcy_pcg": [p, cint, cint, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)],
         "femcy_compute_strain_stress": [p, cint, cint], "femcy_elastic_energy": [p, cint, C.POINTER(f64)],
@@ -298,6 +300,23 @@ class Context:
         out = C.c_int32()
         self._call("femcy_dofset_create", _ptr(dofs), dofs.size, C.byref(out))
         return out.value
+
+    # device-resident *Dsload surfaces
+    def loadset(self, ELE, load_elem, load_ft) -> int:
+        """load_elem[k]: element owning loaded facet k; load_ft[k]: its facet type (index into ELE.facet_tables())."""
+        t = ELE.facet_tables()
+        load_elem, load_ft = _i32(load_elem).ravel(), _i32(load_ft).ravel()
+        out = C.c_int32()
+        self._call("femcy_loadset_create", t["nft"], t["nfn"], t["nip"], _ptr(t["ft_nodes"]), _ptr(t["N"]),
+                   _ptr(t["dN"]), _ptr(t["normal"]), _ptr(t["weight"]), load_elem.size, _ptr(load_elem), _ptr(load_ft),
+                   C.byref(out))
+        return out.value
+
+    def loadset_neumann(self, ls: int, traction: float, direction=None, rhs_vec: int = VEC_RHS):
+        d = None if direction is None or len(direction) == 0 else _f64(direction).ravel()
+        if d is not None and d.size < self.dm:
+            raise FemcyError(f"load direction needs {self.dm} components")
+        self._call("femcy_loadset_neumann", int(ls), float(traction), None if d is None else _ptr(d), int(rhs_vec))
 
     def dofset_dirichlet_newton(self, ds: int, residual_vec: int = VEC_RESIDUAL):
         self._call("femcy_dofset_dirichlet_newton", int(ds), int(residual_vec))

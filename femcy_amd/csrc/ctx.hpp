@@ -141,6 +141,14 @@ struct Ctx {
     struct DofSet { int32_t* d_dofs; double* d_vals; int32_t k; };
     std::vector<DofSet> dofsets;
 
+    // ---- device-resident *Dsload surfaces (femcy_loadset_*)
+    struct LoadSet {
+        int32_t nft, nfn, nip, nload, nnode;
+        int32_t *d_ft_nodes, *d_elem, *d_ft, *d_node, *d_ptr, *d_slot;
+        double *d_N, *d_dN, *d_normal, *d_weight, *d_contrib, *d_dir;
+    };
+    std::vector<LoadSet> loadsets;
+
     // ---- options / timing
     int opt_assembly = FEMCY_ASM_AUTO;
     int opt_poll = 32;
@@ -184,6 +192,7 @@ int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int wid
 int launch_energy_sum(Ctx* c, double* total);
 int launch_assemble(Ctx* c);
 int launch_nodal_force(Ctx* c, double* d_f);
+int launch_neumann(Ctx* c, const Ctx::LoadSet& ls, double traction, bool along_normal, double* d_rhs);
 int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,

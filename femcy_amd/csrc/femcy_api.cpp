@@ -200,6 +200,12 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
         if (ds.d_dofs) (void)hipFree(ds.d_dofs);
         if (ds.d_vals) (void)hipFree(ds.d_vals);
     }
+    for (auto& ls : c->loadsets) {
+        void* ptrs[] = {ls.d_ft_nodes, ls.d_elem, ls.d_ft, ls.d_node, ls.d_ptr, ls.d_slot,
+                        ls.d_N, ls.d_dN, ls.d_normal, ls.d_weight, ls.d_contrib, ls.d_dir};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+    }
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -592,6 +598,91 @@ int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int 
     }
     if ((rc = vec_scatter_const(c, c->d_vec[rhs_vec], ds.d_dofs, value, ds.k))) return rc;
     return launch_dirichlet_zero(c, ds.d_dofs, ds.k, nullptr);
+}
+
+// ------------------------------------------------------------------------------- Neumann load sets
+static int to_device(void* dptr, const void* h, size_t bytes) {
+    void** d = (void**)dptr;
+    FEMCY_HIP(hipMalloc(d, std::max<size_t>(bytes, 8)));
+    if (bytes) FEMCY_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return FEMCY_OK;
+}
+
+static void loadset_free(Ctx::LoadSet& ls) {
+    void* ptrs[] = {ls.d_ft_nodes, ls.d_elem, ls.d_ft, ls.d_node, ls.d_ptr, ls.d_slot,
+                    ls.d_N, ls.d_dN, ls.d_normal, ls.d_weight, ls.d_contrib, ls.d_dir};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    ls = Ctx::LoadSet{};
+}
+
+int femcy_loadset_create(femcy_ctx* ctx, int32_t nft, int32_t nfn, int32_t nip, const int32_t* ft_nodes,
+                         const double* ft_N, const double* ft_dN, const double* ft_normal, const double* ft_weight,
+                         int32_t nload, const int32_t* load_elem, const int32_t* load_ft, int32_t* id_out) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_mesh && id_out, "mesh not set or null id_out");
+    FEMCY_REQUIRE(nft > 0 && nip > 0 && nfn >= c->dm && nfn <= c->npe, "bad facet table sizes (nft %d, nfn %d, nip %d)", nft, nfn, nip);
+    FEMCY_REQUIRE(ft_nodes && ft_N && ft_dN && ft_normal && ft_weight, "null facet tables");
+    FEMCY_REQUIRE(nload >= 0 && (nload == 0 || (load_elem && load_ft)), "bad load facet lists");
+    for (int32_t i = 0; i < nft * nfn; ++i)
+        FEMCY_REQUIRE(ft_nodes[i] >= 0 && ft_nodes[i] < c->npe, "facet table: local node %d out of range", ft_nodes[i]);
+    for (int32_t l = 0; l < nload; ++l) {
+        FEMCY_REQUIRE(load_elem[l] >= 0 && load_elem[l] < c->ne, "load facet %d: element %d out of range", l, load_elem[l]);
+        FEMCY_REQUIRE(load_ft[l] >= 0 && load_ft[l] < nft, "load facet %d: facet type %d out of range", l, load_ft[l]);
+    }
+    // loaded nodes and, per node, its contribution slots (facet * nfn + facet node) in ascending order
+    const size_t nslot = (size_t)nload * nfn;
+    std::vector<int32_t> slot_node(nslot), order(nslot);
+    for (int32_t l = 0; l < nload; ++l)
+        for (int32_t f = 0; f < nfn; ++f)
+            slot_node[(size_t)l * nfn + f] = c->h_elems[(size_t)load_elem[l] * c->npe + ft_nodes[(size_t)load_ft[l] * nfn + f]];
+    for (size_t i = 0; i < nslot; ++i) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return slot_node[a] < slot_node[b]; });
+    std::vector<int32_t> ld_node, ld_ptr;
+    for (size_t i = 0; i < nslot; ++i) {
+        if (i == 0 || slot_node[order[i]] != slot_node[order[i - 1]]) {
+            ld_node.push_back(slot_node[order[i]]);
+            ld_ptr.push_back((int32_t)i);
+        }
+    }
+    ld_ptr.push_back((int32_t)nslot);
+
+    Ctx::LoadSet ls{};
+    ls.nft = nft; ls.nfn = nfn; ls.nip = nip; ls.nload = nload; ls.nnode = (int32_t)ld_node.size();
+    int rc = FEMCY_OK;
+    const size_t tip = (size_t)nft * nip;
+    if (!rc) rc = to_device(&ls.d_ft_nodes, ft_nodes, sizeof(int32_t) * nft * nfn);
+    if (!rc) rc = to_device(&ls.d_N, ft_N, sizeof(double) * tip * c->npe);
+    if (!rc) rc = to_device(&ls.d_dN, ft_dN, sizeof(double) * tip * c->npe * c->dm);
+    if (!rc) rc = to_device(&ls.d_normal, ft_normal, sizeof(double) * tip * c->dm);
+    if (!rc) rc = to_device(&ls.d_weight, ft_weight, sizeof(double) * tip);
+    if (!rc) rc = to_device(&ls.d_elem, load_elem, sizeof(int32_t) * nload);
+    if (!rc) rc = to_device(&ls.d_ft, load_ft, sizeof(int32_t) * nload);
+    if (!rc) rc = to_device(&ls.d_node, ld_node.data(), sizeof(int32_t) * ld_node.size());
+    if (!rc) rc = to_device(&ls.d_ptr, ld_ptr.data(), sizeof(int32_t) * ld_ptr.size());
+    if (!rc) rc = to_device(&ls.d_slot, order.data(), sizeof(int32_t) * nslot);
+    if (!rc && hipMalloc((void**)&ls.d_contrib, std::max<size_t>(nslot, 1) * c->dm * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
+    if (!rc && hipMalloc((void**)&ls.d_dir, 3 * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
+    if (rc) {
+        loadset_free(ls);
+        if (rc == FEMCY_ENOMEM) set_error("out of device memory for a load set of %d facets", nload);
+        return rc;
+    }
+    c->loadsets.push_back(ls);
+    *id_out = (int32_t)c->loadsets.size() - 1;
+    return FEMCY_OK;
+}
+
+int femcy_loadset_neumann(femcy_ctx* ctx, int32_t id, double traction, const double* direction, int rhs_vec) {
+    CTX_OR_FAIL(ctx);
+    VEC_OR_FAIL(rhs_vec);
+    FEMCY_REQUIRE(id >= 0 && (size_t)id < c->loadsets.size(), "unknown load set %d", (int)id);
+    const Ctx::LoadSet& ls = c->loadsets[id];
+    if (direction) {
+        FEMCY_HIP(hipMemcpyAsync(ls.d_dir, direction, sizeof(double) * c->dm, hipMemcpyHostToDevice, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));   // the host buffer is only borrowed for the call
+    }
+    return launch_neumann(c, ls, traction, direction == nullptr, c->d_vec[rhs_vec]);
 }
 
 int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {

@@ -789,6 +789,115 @@ int launch_energy(Ctx* c) {
     return FEMCY_OK;
 }
 
+// ------------------------------------------------------------------------------- Neumann loads
+// neumannBC (stiffnessMtrx.py:369-411): one lane per loaded facet evaluates the facet's integration points on the
+// UNDEFORMED element (dead load) and leaves the load of each facet node in contrib[facet][node][dm]; a second
+// kernel sums the contributions of each loaded node in ascending (facet, node slot) order -- no atomics, the same
+// bits on every run.  Loaded surfaces have 1e2..1e5 facets: launch-latency sized, kept on the device so that an
+// increment never waits for a host loop over facets.
+template <int DM>
+__global__ void __launch_bounds__(128) k_neumann_contrib(int32_t nload, int32_t npe, int32_t nfn, int32_t nip,
+                                                         const double* __restrict__ nodes,
+                                                         const int32_t* __restrict__ elems,
+                                                         const int32_t* __restrict__ load_elem,
+                                                         const int32_t* __restrict__ load_ft,
+                                                         const int32_t* __restrict__ ft_nodes,
+                                                         const double* __restrict__ ft_N,
+                                                         const double* __restrict__ ft_dN,
+                                                         const double* __restrict__ ft_normal,
+                                                         const double* __restrict__ ft_weight, double traction,
+                                                         const double* __restrict__ dir_or_null,
+                                                         double* __restrict__ contrib) {
+    const int32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nload) return;
+    const int32_t* en = elems + (int64_t)load_elem[l] * npe;
+    const int32_t t = load_ft[l];
+    const int32_t* key = ft_nodes + (int64_t)t * nfn;
+    // facet size from the first sorted local nodes (ELE.globalNormal): edge length, or corner-triangle area
+    double size;
+    {
+        const double* p0 = nodes + (int64_t)en[key[0]] * DM;
+        const double* p1 = nodes + (int64_t)en[key[1]] * DM;
+        if (DM == 2) {
+            const double dx = p0[0] - p1[0], dy = p0[1] - p1[1];
+            size = sqrt(dx * dx + dy * dy);
+        } else {
+            const double* p2 = nodes + (int64_t)en[key[2]] * DM;
+            const double a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+            const double b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+            const double c0 = a1 * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1 * b0;
+            size = 0.5 * sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+        }
+    }
+    for (int32_t fn = 0; fn < nfn; ++fn)
+        for (int d = 0; d < DM; ++d) contrib[((int64_t)l * nfn + fn) * DM + d] = 0.0;
+    for (int32_t ip = 0; ip < nip; ++ip) {
+        const int64_t tip = (int64_t)t * nip + ip;
+        double J[DM][DM], inv[DM][DM];
+        for (int i = 0; i < DM; ++i)
+            for (int j = 0; j < DM; ++j) J[i][j] = 0.0;
+        for (int32_t a = 0; a < npe; ++a) {
+            const double* x = nodes + (int64_t)en[a] * DM;
+            const double* dn = ft_dN + (tip * npe + a) * DM;
+            for (int i = 0; i < DM; ++i)
+                for (int j = 0; j < DM; ++j) J[i][j] += x[i] * dn[j];
+        }
+        det_inv<DM>(J, inv);
+        double flux[DM];
+        if (dir_or_null) {
+            for (int d = 0; d < DM; ++d) flux[d] = dir_or_null[d];
+        } else {
+            double nrm = 0.0;
+            for (int j = 0; j < DM; ++j) {
+                double v = 0.0;
+                for (int i = 0; i < DM; ++i) v += ft_normal[tip * DM + i] * inv[i][j];
+                flux[j] = v;
+                nrm += v * v;
+            }
+            nrm = sqrt(nrm) + 1.e-30;
+            for (int d = 0; d < DM; ++d) flux[d] /= nrm;
+        }
+        const double axw = size * ft_weight[tip];
+        for (int d = 0; d < DM; ++d) flux[d] = traction * flux[d] * axw;
+        for (int32_t fn = 0; fn < nfn; ++fn) {
+            const double shape = ft_N[tip * npe + key[fn]];
+            for (int d = 0; d < DM; ++d) contrib[((int64_t)l * nfn + fn) * DM + d] += flux[d] * shape;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(128) k_neumann_gather(int32_t nnode, int32_t dm, const int32_t* __restrict__ ld_node,
+                                                        const int32_t* __restrict__ ld_ptr,
+                                                        const int32_t* __restrict__ ld_slot,
+                                                        const double* __restrict__ contrib, double* __restrict__ rhs) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnode) return;
+    for (int d = 0; d < dm; ++d) {
+        double s = 0.0;
+        for (int32_t k = ld_ptr[i]; k < ld_ptr[i + 1]; ++k) s += contrib[(int64_t)ld_slot[k] * dm + d];
+        rhs[(int64_t)ld_node[i] * dm + d] = s;
+    }
+}
+
+int launch_neumann(Ctx* c, const Ctx::LoadSet& ls, double traction, bool along_normal, double* d_rhs) {
+    FEMCY_HIP(hipMemsetAsync(d_rhs, 0, sizeof(double) * c->n, c->stream));
+    if (ls.nload == 0) return FEMCY_OK;
+    const int bs = 128;
+    const double* dir = along_normal ? nullptr : ls.d_dir;
+    if (c->dm == 3)
+        hipLaunchKernelGGL((k_neumann_contrib<3>), dim3((ls.nload + bs - 1) / bs), dim3(bs), 0, c->stream, ls.nload,
+                           c->npe, ls.nfn, ls.nip, c->d_nodes, c->d_elems, ls.d_elem, ls.d_ft, ls.d_ft_nodes, ls.d_N,
+                           ls.d_dN, ls.d_normal, ls.d_weight, traction, dir, ls.d_contrib);
+    else
+        hipLaunchKernelGGL((k_neumann_contrib<2>), dim3((ls.nload + bs - 1) / bs), dim3(bs), 0, c->stream, ls.nload,
+                           c->npe, ls.nfn, ls.nip, c->d_nodes, c->d_elems, ls.d_elem, ls.d_ft, ls.d_ft_nodes, ls.d_N,
+                           ls.d_dN, ls.d_normal, ls.d_weight, traction, dir, ls.d_contrib);
+    hipLaunchKernelGGL(k_neumann_gather, dim3((ls.nnode + bs - 1) / bs), dim3(bs), 0, c->stream, ls.nnode, c->dm,
+                       ls.d_node, ls.d_ptr, ls.d_slot, ls.d_contrib, d_rhs);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
 int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int width, int comp, double* d_out) {
     const int64_t total = (int64_t)c->ne * c->npe;
     hipLaunchKernelGGL(k_extrapolate, dim3((int)((total + 255) / 256)), dim3(256), 0, c->stream, (int64_t)c->ne, c->npe,

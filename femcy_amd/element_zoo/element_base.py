@@ -62,6 +62,21 @@ class ElementBase(abc.ABC):
                 "w": np.ascontiguousarray(self.gaussWeights, dtype=np.float64),
                 "voigt_kind": VOIGT_2D if self.dm == 2 else VOIGT_3D}
 
+    def facet_tables(self) -> dict:
+        """the facet dictionaries (facet_natural_coos / facet_point_weights / facet_natural_normals, keyed by the
+        sorted local node tuple) as the plain arrays femcy_loadset_create takes; facet type = position of the key."""
+        keys = list(self.facet_natural_coos.keys())
+        nip = self.integPointNum_eachFacet
+        coos = np.array([[self.facet_natural_coos[k][i] for i in range(nip)] for k in keys], dtype=np.float64)
+        return {"keys": keys, "nft": len(keys), "nfn": len(keys[0]), "nip": nip,
+                "ft_nodes": np.ascontiguousarray(keys, dtype=np.int32),
+                "N": np.ascontiguousarray([[self.shapeFunc_pyscope(c) for c in row] for row in coos], dtype=np.float64),
+                "dN": np.ascontiguousarray([[self.dshape_dnat_pyscope(c) for c in row] for row in coos], dtype=np.float64),
+                "normal": np.ascontiguousarray([[self.facet_natural_normals[k][i] for i in range(nip)] for k in keys],
+                                               dtype=np.float64),
+                "weight": np.ascontiguousarray([[self.facet_point_weights[k][i] for i in range(nip)] for k in keys],
+                                               dtype=np.float64)}
+
     # ---- generic numpy bodies ----------------------------------------------------------
     def strainMtrx(self, dsdx) -> np.ndarray:
         """B(grad N) with the reference's Voigt ordering, shape (s, npe*dm)."""

@@ -78,6 +78,7 @@ class System_of_equations:
         self.dt = 0.
         self.compiled = False
         self._dofsets = {}
+        self._loadsets = {}
         self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0}
 
     def _say(self, msg):
@@ -166,26 +167,28 @@ class System_of_equations:
     def dirichletBC_val(self, nodeSet, dm_specified: int, sval: float):
         self.ctx.dofset_fill(self._dofset(nodeSet, dm_specified), be.VEC_DOF, sval)
 
+    def _loadset(self, load_facets) -> int:
+        """device load set of one *Dsload surface, built once per face set: owning element of each facet
+        (body.boundary, reference :386) and the facet's type = position of its sorted local node tuple in the
+        element plugin's facet tables (reference :388-392)."""
+        key = id(load_facets)
+        if key not in self._loadsets:
+            boundary = self.body.get_boundary()
+            facets = [tuple(f) for f in load_facets]
+            elem = np.fromiter((boundary[f] for f in facets), dtype=np.int64, count=len(facets))
+            fnodes = np.asarray(facets, dtype=np.int64).reshape(len(facets), -1)
+            conn = self.body.np_elements[elem]                                            # [nf, npe]
+            local = np.sort((conn[:, None, :] == fnodes[:, :, None]).argmax(axis=2), axis=1)   # sorted local ids
+            keys = self.ELE.facet_tables()["keys"]
+            type_of = {k: i for i, k in enumerate(keys)}
+            ft = np.fromiter((type_of[tuple(r)] for r in local.tolist()), dtype=np.int32, count=len(facets))
+            self._loadsets[key] = (self.ctx.loadset(self.ELE, elem, ft), load_facets)    # keep the set alive: id() is the key
+        return self._loadsets[key][0]
+
     def neumannBC(self, load_facets, load_val: float, load_dir=np.array([])):
-        """consistent nodal loads of a surface traction (dead load on the undeformed geometry).
-        rhs is refreshed on every call, as in the reference (:384)."""
-        body, ELE, dm = self.body, self.ELE, self.dm
-        boundary = body.get_boundary()
-        rhs = np.zeros(self.dof.shape[0])
-        for facet in load_facets:
-            ele = boundary[facet]
-            conn = body.np_elements[ele].tolist()
-            localNodes = body.np_nodes[body.np_elements[ele]]
-            localFacet = [conn.index(i) for i in facet]
-            key = tuple(sorted(localFacet))
-            for integId in range(ELE.integPointNum_eachFacet):
-                normal, area_x_weight = ELE.globalNormal(nodes=localNodes, facet=localFacet, integPointId=integId)
-                direction = normal if len(load_dir) == 0 else np.asarray(load_dir)
-                flux = load_val * direction * area_x_weight
-                shape = ELE.shapeFunc_pyscope(np.asarray(ELE.facet_natural_coos[key][integId], dtype=np.float64))
-                for node0, lid in zip(facet, localFacet):
-                    rhs[node0 * dm:node0 * dm + dm] += flux[:dm] * shape[lid]
-        self.rhs.from_numpy(rhs)
+        """consistent nodal loads of a surface traction (dead load on the undeformed geometry), evaluated on the
+        device.  rhs is refreshed on every call, as in the reference (:384)."""
+        self.ctx.loadset_neumann(self._loadset(load_facets), load_val, load_dir, be.VEC_RHS)
 
     def impose_boundary_condition(self, boundary_conditions: dict):
         for nb in boundary_conditions["neumannBCs"]:

@@ -170,6 +170,24 @@ int femcy_dofset_dirichlet_newton(femcy_ctx* ctx, int32_t id, int residual_vec);
 int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int rhs_vec);
 int femcy_dofset_fill(femcy_ctx* ctx, int32_t id, int vec, double value);       /* dirichletBC_val */
 int femcy_dofset_scatter(femcy_ctx* ctx, int32_t id, int vec, const double* vals /*[k]*/);
+/* neumannBC (stiffnessMtrx.py:369-411) on the device.  A load set is the device-resident description of one
+ * *Dsload surface: for each loaded facet its owning element (body.boundary[facet], body.py:197-216) and its
+ * facet type = index into the element plugin's facet tables (facet_natural_coos / facet_point_weights /
+ * facet_natural_normals keys, e.g. element_linear_tetrahedral.py:30-55), which are passed as plain arrays:
+ *   ft_nodes [nft][nfn]            sorted local node ids of the facet (the dict key)
+ *   ft_N     [nft][nip][npe]       shapeFunc at the facet integration points
+ *   ft_dN    [nft][nip][npe][dm]   dshape_dnat there
+ *   ft_normal[nft][nip][dm]        natural outward normals
+ *   ft_weight[nft][nip]            facet point weights
+ * femcy_loadset_neumann zero-fills vec[rhs] (reference :384) and writes the consistent nodal loads of
+ * traction * (direction, or the outward unit normal n_nat (dx/dxi)^-1 / (|.| + 1e-30) when direction is NULL)
+ * on the undeformed geometry; the facet size is |x1 - x0| (dm = 2) or the triangle area of the facet's first
+ * three sorted nodes (dm = 3), as ELE.globalNormal computes it.  Sums per node run in a fixed order. */
+int femcy_loadset_create(femcy_ctx* ctx, int32_t nft, int32_t nfn, int32_t nip, const int32_t* ft_nodes,
+                         const double* ft_N, const double* ft_dN, const double* ft_normal, const double* ft_weight,
+                         int32_t nload, const int32_t* load_elem, const int32_t* load_ft, int32_t* id_out);
+int femcy_loadset_neumann(femcy_ctx* ctx, int32_t id, double traction, const double* direction /*[dm] or NULL*/,
+                          int rhs_vec);
 /* compute_Ad (conjugateGradientSolver.py:53-58): vec[y] = K vec[x] */
 int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec);
 /* ConjugateGradientSolver_rowMajor.re_init + solve (conjugateGradientSolver.py:32-51, 103-127):

