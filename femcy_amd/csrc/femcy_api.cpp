@@ -243,6 +243,14 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 spmv_split(c);
             }
             break;
+        case 102:   /* test knob: SpMV matrix loads non-temporal (-1 auto: matrix larger than the Infinity Cache) */
+            FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
+            c->opt_spmv_nt = (int)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
+            break;
         case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
             c->opt_timing_fence = value ? 1 : 0;
             break;

@@ -83,7 +83,7 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
 // WPS = wavefronts per slice: long rows (C3D10: 27-65 blocks per node) are split into WPS contiguous j-chunks
 // handled by WPS waves of the same workgroup and summed through LDS, so that the chain per wave stays short and
 // the few thousand slices still fill 1024 SIMDs evenly.
-template <int DM, int WPS>
+template <int DM, int WPS, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
                                              const int32_t* __restrict__ bcol, const int32_t* __restrict__ node_of,
@@ -128,18 +128,20 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
 #endif
 #pragma unroll FEMCY_SPMV_UNROLL
             for (int32_t j = j0; j < j1; ++j) {
-                const int64_t col = bc[(int64_t)j * SLICE];
+                const int64_t col = NT ? __builtin_nontemporal_load(&bc[(int64_t)j * SLICE]) : bc[(int64_t)j * SLICE];
                 double xv[DM];
 #pragma unroll
                 for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
                 double e[DD];
 #pragma unroll
                 for (int kp = 0; kp < NP; ++kp) {
-                    const double2 t = vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE];
+                    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                    const nt_d2* tp = reinterpret_cast<const nt_d2*>(&vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE]);
+                    const nt_d2 t = NT ? __builtin_nontemporal_load(tp) : *tp;
                     e[2 * kp] = t.x;
                     e[2 * kp + 1] = t.y;
                 }
-                if (DD & 1) e[DD - 1] = vs[(int64_t)j * (DD * SLICE)];
+                if (DD & 1) e[DD - 1] = NT ? __builtin_nontemporal_load(&vs[(int64_t)j * (DD * SLICE)]) : vs[(int64_t)j * (DD * SLICE)];
 #pragma unroll
                 for (int r = 0; r < DM; ++r)
 #pragma unroll
@@ -523,12 +525,17 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 #define SPMV_ARGS                                                                                              \
     c->nn, c->xcd, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,  \
         (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done
-#define SPMV_LAUNCH(DM_, WPS_)                                                                                 \
+#define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \
-            hipExtLaunchKernelGGL((k_spmv<DM_, WPS_>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, SPMV_ARGS); \
+            hipExtLaunchKernelGGL((k_spmv<DM_, WPS_, NT_>), dim3(grid), dim3(BS), 0, c->stream, ea, eb, 0, SPMV_ARGS); \
         else /* plain launch: also the form that is captured into the PCG hipGraph */                          \
-            hipLaunchKernelGGL((k_spmv<DM_, WPS_>), dim3(grid), dim3(BS), 0, c->stream, SPMV_ARGS);             \
+            hipLaunchKernelGGL((k_spmv<DM_, WPS_, NT_>), dim3(grid), dim3(BS), 0, c->stream, SPMV_ARGS);        \
+    } while (0)
+#define SPMV_LAUNCH(DM_, WPS_)                          \
+    do {                                                \
+        if (c->spmv_nt) SPMV_LAUNCH_NT(DM_, WPS_, true); \
+        else SPMV_LAUNCH_NT(DM_, WPS_, false);          \
     } while (0)
     const int wps = c->spmv_wps;
     if (c->dm == 3) {
@@ -541,6 +548,7 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
         else SPMV_LAUNCH(2, 4);
     }
 #undef SPMV_LAUNCH
+#undef SPMV_LAUNCH_NT
 #undef SPMV_ARGS
     FEMCY_HIP(hipGetLastError());
     if (nblocks_out) *nblocks_out = grid;

@@ -166,6 +166,11 @@ def test_spmv_and_vectors(gpu_ctx_factory, name):
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)      # (what meshes beyond ~6 M elements use)
         assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
         ctx.set_option(101, 256)
+        y_plain = ctx.download(be.VEC_TMP1)
+        ctx.set_option(102, 1)                  # non-temporal matrix loads (what matrices beyond 256 MiB use)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        ctx.set_option(102, -1)
+        assert np.array_equal(ctx.download(be.VEC_TMP1), y_plain)     # a cache policy, not an arithmetic change
     ctx.set_option(be.OPT_SPMV_VARIANT, 0)
     # tiGadgets
     ctx.upload(be.VEC_RHS, 2.0 * x)
