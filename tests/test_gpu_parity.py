@@ -146,6 +146,56 @@ def test_neumann_pressure_on_generated_c3d10(gpu_ctx_factory):
     assert np.allclose(got.sum(axis=0), [0.0, 0.0, 80.0 * 10.0], rtol=1e-12)
 
 
+def test_user_defined_element_plugins(gpu_ctx_factory):
+    """the plugin surface is table-driven (any ElementBase subclass): a user element that only re-declares
+    its Gauss rule runs through the same kernels.  CPS4 with a 3 x 3 rule and C3D4 with a 4-point rule, K / f_int /
+    Gauss-point fields against the oracle given the same tables."""
+    import dataclasses
+    from femcy_amd import backend as be
+    from femcy_amd.element_zoo import Element_linear_quadrilateral, Element_linear_tetrahedral
+
+    g = (3. / 5.) ** 0.5
+    pts9 = [[a, b] for b in (-g, 0., g) for a in (-g, 0., g)]
+    w1 = {-g: 5. / 9., 0.: 8. / 9., g: 5. / 9.}
+    w9 = [w1[a] * w1[b] for a, b in pts9]
+
+    class Quad9(Element_linear_quadrilateral):
+        _gauss_points, _gauss_weights = pts9, w9
+
+    a4, b4 = 0.5854101966249685, 0.1381966011250105
+    pts4 = [[a4, b4, b4], [b4, a4, b4], [b4, b4, a4], [b4, b4, b4]]
+
+    class Tet4pt(Element_linear_tetrahedral):
+        _gauss_points, _gauss_weights = pts4, [1. / 24.] * 4
+
+    for name, cls in (("ellip_CPS4.inp", Quad9), ("twist_plate_C3D4.inp", Tet4pt)):
+        inp, et, el, mat = load(name)
+        ELE = cls()
+        ed = dataclasses.replace(elem_def(et), gauss_points=np.array(ELE._gauss_points),
+                                 gauss_weights=np.array(ELE._gauss_weights), extrap=None)
+        ctx = gpu_ctx_factory()
+        ctx.set_mesh(inp.nodes, el)
+        ctx.set_element(ELE)
+        ctx.set_material(mat)
+        ctx.build_pattern()
+        topo = orc.Topology(inp.nodes, el, ed)
+        u = smooth_disp(inp.nodes, 0.02)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.assemble_K(be.VEC_DOF)
+        K = ctx.get_K_bsr().tocsr()
+        Ko = orc.assemble_K(topo, u, oracle_material(mat).C)
+        assert abs(K - Ko).max() / abs(Ko).max() < 1e-12
+        assert ctx.gauss_field(be.GP_VOL).to_numpy().shape == (el.shape[0], ELE.gaussPoints.shape[0])
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        fo = orc.internal_force(topo, u, oracle_material(mat))[0]
+        assert rel(ctx.download(be.VEC_FORCE), fo) < 1e-11
+        if cls is Quad9:      # the rule matters on non-parallelogram quads: not the shipped element's matrix
+            ctx2 = make_ctx(gpu_ctx_factory, inp, el, mat)
+            ctx2.upload(be.VEC_DOF, u)
+            ctx2.assemble_K(be.VEC_DOF)
+            assert abs(ctx2.get_K_bsr().tocsr() - K).max() > 1e-6 * abs(Ko).max()
+
+
 @pytest.mark.parametrize("name", DECKS)
 def test_spmv_and_vectors(gpu_ctx_factory, name):
     from femcy_amd import backend as be
