@@ -37,7 +37,7 @@ EXPORTS = [
     "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
     "femcy_dofset_scatter", "femcy_loadset_create", "femcy_loadset_neumann", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
-    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_init", "femcy_iface_sum",
+    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_iface_sum",
 ]
 
 
@@ -109,7 +109,7 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_extrapolate": [p, cint, cint, p, p],
         "femcy_get_K_ell": [p, p, p], "femcy_get_K_bsr": [p, p, p, p], "femcy_get_gp_field": [p, cint, p],
         "femcy_timing": [p, C.POINTER(Timing)], "femcy_timing_reset": [p],
-        "femcy_comm_unique_id": [p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
+        "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
         "femcy_iface_sum": [p, cint],
     }
     for name, args in sig.items():
@@ -397,6 +397,17 @@ class Context:
         rc = lib.femcy_comm_unique_id(buf)
         if rc != 0:
             raise FemcyError(f"femcy_comm_unique_id -> {rc}: {lib.femcy_last_error().decode()}")
+        return buf.raw
+
+    @staticmethod
+    def comm_local_id() -> bytes:
+        """id of an in-process group: contexts driven by one thread each in this process (single-GPU verification
+        of the multi-rank path)."""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.femcy_comm_local_id(buf)
+        if rc != 0:
+            raise FemcyError(f"femcy_comm_local_id -> {rc}: {lib.femcy_last_error().decode()}")
         return buf.raw
 
     def comm_init(self, rank: int, nranks: int, uid: bytes, iface_local_dofs, iface_global_slot, niface_global: int,

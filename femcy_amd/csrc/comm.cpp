@@ -6,8 +6,18 @@
 //   2. all-gather of the per-rank (r.M.r over owned DOFs, max|r|) pair.
 // RCCL is bound with dlopen so that libfemcy_hip.so shares whatever librccl the host process already
 // loaded (PyTorch bundles its own copy with the same SONAME) and single-GPU users need none.
+//
+// A second transport, the in-process group, joins several contexts of ONE process (one host thread each, any
+// devices) through host staging buffers and a condition-variable rendezvous.  It exists so that the whole
+// multi-rank device path (sub-assembled K, interface pack / unpack, owner masks, the two collectives per
+// iteration) can be run and checked on a single GPU; ranks sum in rank order, so every rank gets the same bits.
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include "ctx.hpp"
 
 namespace femcy {
@@ -67,6 +77,110 @@ static int load_rccl() {
         }                                                                                      \
     } while (0)
 
+// ------------------------------------------------------------------------------ in-process group
+static const char LOCAL_MAGIC[8] = {'F', 'E', 'M', 'C', 'Y', 'L', 'O', 'C'};
+
+struct LocalGroup {
+    std::mutex m;
+    std::condition_variable cv;
+    int nranks = 0, arrived = 0, joined = 0, left = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    std::vector<std::vector<double>> stage;   // one buffer per rank
+};
+static std::mutex g_groups_m;
+static std::map<uint64_t, std::shared_ptr<LocalGroup>> g_groups;
+static uint64_t g_next_token = 1;
+
+int comm_local_id(void* id128) {
+    std::memset(id128, 0, 128);
+    std::memcpy(id128, LOCAL_MAGIC, 8);
+    std::lock_guard<std::mutex> lk(g_groups_m);
+    const uint64_t token = g_next_token++;
+    std::memcpy((char*)id128 + 8, &token, 8);
+    return FEMCY_OK;
+}
+
+// all ranks arrive or the call fails after 60 s (a rank that died must not hang the others)
+static int local_barrier(LocalGroup* g) {
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->broken) {
+        set_error("in-process group: a previous rendezvous failed");
+        return FEMCY_ECOMM;
+    }
+    const uint64_t gen0 = g->gen;
+    if (++g->arrived == g->nranks) {
+        g->arrived = 0;
+        ++g->gen;
+        g->cv.notify_all();
+        return FEMCY_OK;
+    }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->gen != gen0 || g->broken; }) || g->broken) {
+        g->broken = true;
+        g->cv.notify_all();
+        set_error("in-process group: rendezvous timed out (%d of %d ranks arrived)", g->arrived, g->nranks);
+        return FEMCY_ECOMM;
+    }
+    return FEMCY_OK;
+}
+
+static int local_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
+    uint64_t token;
+    std::memcpy(&token, (const char*)id128 + 8, 8);
+    std::shared_ptr<LocalGroup> g;
+    {
+        std::lock_guard<std::mutex> lk(g_groups_m);
+        auto& slot = g_groups[token];
+        if (!slot) {
+            slot = std::make_shared<LocalGroup>();
+            slot->nranks = nranks;
+            slot->stage.resize(nranks);
+        }
+        g = slot;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->nranks != nranks || g->joined >= nranks) {
+            set_error("in-process group: rank %d of %d does not fit the group (%d ranks, %d joined)", rank, nranks,
+                      g->nranks, g->joined);
+            return FEMCY_ECOMM;
+        }
+        ++g->joined;
+    }
+    c->comm = g.get();
+    c->comm_local = true;
+    c->comm_token = token;
+    c->rank = rank;
+    c->nranks = nranks;
+    return FEMCY_OK;
+}
+
+static int local_exchange(Ctx* c, const double* d_send, int64_t count, double* d_recv, bool gather) {
+    LocalGroup* g = (LocalGroup*)c->comm;
+    std::vector<double>& mine = g->stage[c->rank];
+    mine.resize((size_t)count);
+    FEMCY_HIP(hipMemcpyAsync(mine.data(), d_send, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    int rc = local_barrier(g);
+    if (rc) return rc;
+    std::vector<double> out((size_t)(gather ? count * g->nranks : count), 0.0);
+    for (int r = 0; r < g->nranks; ++r) {       // rank order: the same bits on every rank
+        if ((int64_t)g->stage[r].size() != count) {
+            set_error("in-process group: rank %d sent %zu values, rank %d sent %lld", r, g->stage[r].size(), c->rank,
+                      (long long)count);
+            return FEMCY_ECOMM;
+        }
+        if (gather)
+            std::memcpy(out.data() + (size_t)r * count, g->stage[r].data(), sizeof(double) * count);
+        else
+            for (int64_t i = 0; i < count; ++i) out[i] += g->stage[r][i];
+    }
+    if ((rc = local_barrier(g))) return rc;     // everyone has read every staging buffer
+    FEMCY_HIP(hipMemcpyAsync(d_recv, out.data(), sizeof(double) * out.size(), hipMemcpyHostToDevice, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+
 int comm_unique_id(void* id128) {
     int rc = load_rccl();
     if (rc) return rc;
@@ -77,6 +191,7 @@ int comm_unique_id(void* id128) {
 }
 
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
+    if (std::memcmp(id128, LOCAL_MAGIC, 8) == 0) return local_init(c, rank, nranks, id128);
     int rc = load_rccl();
     if (rc) return rc;
     nccl_uid id;
@@ -90,6 +205,7 @@ int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
 
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count) {
     if (!c->comm || count <= 0) return FEMCY_OK;
+    if (c->comm_local) return local_exchange(c, d_buf, count, d_buf, false);
     FEMCY_NCCL(R.allreduce(d_buf, d_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
     return FEMCY_OK;
 }
@@ -99,11 +215,27 @@ int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count) 
         FEMCY_HIP(hipMemcpyAsync(d_recv, d_send, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return FEMCY_OK;
     }
+    if (c->comm_local) return local_exchange(c, d_send, count, d_recv, true);
     FEMCY_NCCL(R.allgather(d_send, d_recv, (size_t)count, /*ncclFloat64*/ 8, c->comm, c->stream));
     return FEMCY_OK;
 }
 
 int comm_destroy(Ctx* c) {
+    if (c->comm && c->comm_local) {
+        LocalGroup* g = (LocalGroup*)c->comm;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            last = ++g->left == g->joined;
+        }
+        if (last) {
+            std::lock_guard<std::mutex> lk(g_groups_m);
+            g_groups.erase(c->comm_token);
+        }
+        c->comm = nullptr;
+        c->comm_local = false;
+        return FEMCY_OK;
+    }
     if (c->comm && R.destroy) R.destroy(c->comm);
     c->comm = nullptr;
     return FEMCY_OK;

@@ -166,7 +166,10 @@ struct Ctx {
 
     // ---- multi-rank
     int32_t rank = 0, nranks = 1;
-    void* comm = nullptr;             // ncclComm_t
+    int64_t n_global = 0;             // DOFs of the un-partitioned system (sum of owned DOFs over the ranks)
+    void* comm = nullptr;             // ncclComm_t, or the in-process group when comm_local
+    bool comm_local = false;
+    uint64_t comm_token = 0;
     int32_t niface_local = 0, niface_global = 0;
     int32_t* d_iface_dof = nullptr;
     int32_t* d_iface_slot = nullptr;
@@ -210,6 +213,7 @@ int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32
 int ensure_scratch(Ctx* c, int64_t k);
 // comm.cpp
 int comm_unique_id(void* id128);
+int comm_local_id(void* id128);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);

@@ -712,7 +712,8 @@ int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, i
     VEC_OR_FAIL(b_vec);
     VEC_OR_FAIL(x_vec);
     FEMCY_REQUIRE(b_vec != x_vec, "pcg: b and x must be different vectors");
-    if (maxit <= 0) maxit = (int32_t)std::min<int64_t>(c->n, INT32_MAX);   // reference: at most n iterations
+    // reference: at most n iterations -- n of the whole (un-partitioned) system, so that every rank stops at the same count
+    if (maxit <= 0) maxit = (int32_t)std::min<int64_t>(c->comm ? c->n_global : c->n, INT32_MAX);
     return pcg_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], eps, maxit, iters, rmax0, rmax);
 }
 
@@ -876,6 +877,14 @@ int femcy_comm_unique_id(void* id128) {
     return comm_unique_id(id128);
 }
 
+int femcy_comm_local_id(void* id128) {
+    if (!id128) {
+        set_error("null id buffer");
+        return FEMCY_EINVAL;
+    }
+    return comm_local_id(id128);
+}
+
 int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id128, int32_t niface_local,
                     const int32_t* iface_local_dofs, const int32_t* iface_global_slot, int32_t niface_global,
                     const uint8_t* owner) {
@@ -911,6 +920,14 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
         FEMCY_HIP(hipMemcpy(c->d_iface_slot, iface_global_slot, sizeof(int32_t) * niface_local, hipMemcpyHostToDevice));
     }
     FEMCY_HIP(hipMemcpy(c->d_owner, owner, (size_t)c->n, hipMemcpyHostToDevice));
+    // DOF count of the whole system = owned DOFs summed over the ranks (first collective of the new communicator)
+    double owned = 0.0;
+    for (int64_t i = 0; i < c->n; ++i) owned += owner[i] ? 1.0 : 0.0;
+    FEMCY_HIP(hipMemcpy(c->d_commbuf, &owned, sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = comm_allreduce_sum(c, c->d_commbuf, 1))) return rc;
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    FEMCY_HIP(hipMemcpy(&owned, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost));
+    c->n_global = (int64_t)(owned + 0.5);
     return FEMCY_OK;
 }
 

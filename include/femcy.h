@@ -218,6 +218,11 @@ int femcy_timing_reset(femcy_ctx* ctx);
 /* ------------------------------------------------------------------- multi-GPU (new work) */
 /* 128-byte ncclUniqueId produced on rank 0 and broadcast by the host program */
 int femcy_comm_unique_id(void* id128);
+/* 128-byte id of an in-process group instead: the contexts that pass it to femcy_comm_init are driven by one host
+ * thread each inside ONE process and exchange through host staging buffers (no RCCL; any devices, also all on
+ * one).  Same kernels and call sequence as the RCCL transport -- it is how the multi-rank path is verified on a
+ * single GPU.  A rendezvous that is not completed by all ranks within 60 s fails with FEMCY_ECOMM. */
+int femcy_comm_local_id(void* id128);
 /* element partition: this ctx holds one sub-mesh; iface_local_dofs[k] is the local scalar DOF that is
  * entry iface_global_slot[k] of the packed global interface vector (length niface_global), owner[i] = 1
  * if this rank counts local DOF i in dot products (exactly one rank per shared DOF). */

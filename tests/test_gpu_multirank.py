@@ -1,0 +1,176 @@
+"""-m gpu: the multi-rank device path on ONE GPU.  N contexts, one host thread each, joined by the in-process
+group transport (femcy_comm_local_id): sub-assembled K per rank, interface pack / all-reduce / unpack, owner
+masks in the dot products, the two collectives per CG iteration -- exactly the kernels and call sequence the RCCL
+transport runs with one process per GPU (bench.py --gpus N), checked against the single-context solve of the
+un-partitioned mesh and against the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import deck, oracle_material
+from oracle import femcy_oracle as orc
+from oracle.elements import elem_def
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(nranks, fn):
+    """fn(rank) on one thread per rank; re-raises the first failure."""
+    out, err = [None] * nranks, []
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:                      # noqa: BLE001 - reported below
+            err.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in threads), "a rank is still running"
+    if err:
+        raise err[0][1]
+    return out
+
+
+def setup_rank(be, part, inp, mat, uid):
+    ctx = be.Context(0)
+    ctx.set_mesh(part.nodes, part.elements)
+    ctx.set_element(inp.ELE)
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    ctx.comm_init(part.rank, part.nranks, uid, part.iface_local_dofs, part.iface_global_slot, part.niface_global,
+                  part.owner)
+    return ctx
+
+
+@pytest.mark.parametrize("name,nranks", [("twist_plate_C3D4.inp", 2), ("twist_plate_C3D4.inp", 4),
+                                         ("twist_C3D10_coarse.inp", 3), ("ellip_CPS8.inp", 2)])
+def test_partitioned_solve_equals_single_context(gpu_ctx_factory, name, nranks):
+    from femcy_amd import backend as be, partition
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    el = inp.eSets[et]
+    mat = list(inp.materials.values())[0]
+    dm = inp.nodes.shape[1]
+    n = inp.nodes.shape[0] * dm
+    axis = 2 if dm == 3 else 0
+    parts = partition.build_all_parts(inp.nodes, el, nranks, axis=axis)
+    assert all(p.niface_global > 0 for p in parts)
+
+    def smooth(nodes):
+        L = np.ptp(inp.nodes, axis=0).max()
+        x = nodes / L
+        return (0.02 * L * np.stack([np.sin(1.3 * x[:, 0] + 0.4), 0.5 * np.cos(2.1 * x[:, 1] - 0.2),
+                                     0.3 * np.sin(x.sum(axis=1))][:dm], axis=1)).ravel()
+
+    u_g = smooth(inp.nodes)
+    cons_nodes = [(np.asarray(b["node_set"]), b["dof"]) for b in inp.dirichlet_bc_info]
+    cons_g = np.unique(np.concatenate([ns * dm + d for ns, d in cons_nodes]))
+    rng = np.random.default_rng(5)
+    b_g = rng.standard_normal(n)
+    x_g = rng.standard_normal(n)
+
+    # ---- single context on the whole mesh
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(inp.nodes, el)
+    ctx.set_element(inp.ELE)
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    ctx.upload(be.VEC_DOF, u_g)
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f_ref = ctx.download(be.VEC_FORCE)
+    ctx.upload(be.VEC_TMP0, x_g)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    y_ref = ctx.download(be.VEC_TMP1)
+    ctx.upload(be.VEC_RESIDUAL, b_g)
+    ctx.dirichlet_newton(cons_g, be.VEC_RESIDUAL)
+    it_ref, r0_ref, rmax_ref = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+    sol_ref = ctx.download(be.VEC_X)
+    hist_ref = []
+    for maxit in (1, 7, 25):
+        hist_ref.append((ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=maxit), ctx.download(be.VEC_X)))
+
+    # ---- nranks contexts, one thread each
+    uid = be.Context.comm_local_id()
+
+    def rank_main(r):
+        p = parts[r]
+        c = setup_rank(be, p, inp, mat, uid)
+        try:
+            c.upload(be.VEC_DOF, p.scatter_global(u_g))
+            c.assemble_K(be.VEC_DOF)
+            c.internal_force(be.VEC_DOF, be.VEC_FORCE)       # sub-assembled forces ...
+            c.iface_sum(be.VEC_FORCE)                         # ... summed over the interface
+            f = c.download(be.VEC_FORCE)
+            c.upload(be.VEC_TMP0, p.scatter_global(x_g))
+            c.spmv(be.VEC_TMP0, be.VEC_TMP1)                  # includes the interface exchange
+            y = c.download(be.VEC_TMP1)
+            c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
+            cons = np.unique(np.concatenate([p.localize_nodes(ns) * dm + d for ns, d in cons_nodes]))
+            c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+            res = c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+            sol = c.download(be.VEC_X)
+            hist = []
+            for maxit in (1, 7, 25):
+                hist.append((c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=maxit), c.download(be.VEC_X)))
+            return f, y, res, sol, hist
+        finally:
+            c.close()
+
+    outs = run_ranks(nranks, rank_main)
+    scale_f, scale_y = np.abs(f_ref).max(), np.abs(y_ref).max()
+    for p, (f, y, res, sol, hist) in zip(parts, outs):
+        # replicated quantities agree with the global ones on every rank that holds the node
+        assert np.abs(f - p.scatter_global(f_ref)).max() < 1e-11 * scale_f
+        assert np.abs(y - p.scatter_global(y_ref)).max() < 1e-12 * scale_y
+        it, r0, rmax = res
+        assert abs(it - it_ref) <= max(2, it_ref // 50) and abs(r0 - r0_ref) <= 1e-12 * r0_ref
+        assert np.linalg.norm(sol - p.scatter_global(sol_ref)) <= 1e-6 * np.linalg.norm(sol_ref)
+        # fixed iteration counts: the same recurrence, iterate by iterate
+        for ((k, r0k, rmaxk), xk), ((kr, _, rmaxr), xr) in zip(hist, hist_ref):
+            assert k == kr
+            assert abs(rmaxk - rmaxr) <= 1e-8 * rmaxr
+            assert np.linalg.norm(xk - p.scatter_global(xr)) <= 1e-9 * np.linalg.norm(xr)
+    # all ranks got identical scalars (rank-ordered sums) and the gathered solution is the global one
+    assert len({o[2] for o in outs}) == 1
+    sol_g = partition.gather_owned(parts, [o[3] for o in outs], n)
+    assert np.linalg.norm(sol_g - sol_ref) <= 1e-6 * np.linalg.norm(sol_ref)
+    # ... and it solves the oracle's system
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    K = orc.assemble_K(topo, u_g, oracle_material(mat).C).tolil()
+    rhs = b_g.copy()
+    rhs[cons_g] = 0.0
+    K[cons_g, :] = 0.0
+    K[:, cons_g] = 0.0
+    K[cons_g, cons_g] = 1.0
+    resid = K.tocsr() @ sol_g - rhs
+    assert np.abs(resid).max() <= 1e-7 * np.abs(rhs).max()
+
+
+def test_rendezvous_failures_are_reported(gpu_ctx_factory):
+    """a rank that joins a full group, or a second group size, is an error, not a hang."""
+    from femcy_amd import backend as be, partition
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck("twist_plate_C3D4.inp"))
+    el = inp.eSets["C3D4"]
+    mat = list(inp.materials.values())[0]
+    parts = partition.build_all_parts(inp.nodes, el, 2)
+    uid = be.Context.comm_local_id()
+    a, b = run_ranks(2, lambda r: setup_rank(be, parts[r], inp, mat, uid))     # comm_init is collective
+    assert a.download(be.VEC_DOF).size + b.download(be.VEC_DOF).size > inp.nodes.size   # shared nodes are replicated
+    c = be.Context(0)
+    c.set_mesh(parts[0].nodes, parts[0].elements)
+    with pytest.raises(be.FemcyError):
+        c.comm_init(0, 2, uid, parts[0].iface_local_dofs, parts[0].iface_global_slot, parts[0].niface_global,
+                    parts[0].owner)                                  # the group is full
+    with pytest.raises(be.FemcyError):
+        c.comm_init(0, 3, uid, parts[0].iface_local_dofs, parts[0].iface_global_slot, parts[0].niface_global,
+                    parts[0].owner)                                  # wrong group size
+    for x in (a, b, c):
+        x.close()
