@@ -37,7 +37,7 @@ EXPORTS = [
     "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
     "femcy_dofset_scatter", "femcy_loadset_create", "femcy_loadset_neumann", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
-    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_iface_sum",
+    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_comm_info", "femcy_iface_sum",
 ]
 
 
@@ -109,7 +109,7 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_extrapolate": [p, cint, cint, p, p],
         "femcy_get_K_ell": [p, p, p], "femcy_get_K_bsr": [p, p, p, p], "femcy_get_gp_field": [p, cint, p],
         "femcy_timing": [p, C.POINTER(Timing)], "femcy_timing_reset": [p],
-        "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
+        "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_info": [p, p, p, p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
         "femcy_iface_sum": [p, cint],
     }
     for name, args in sig.items():
@@ -419,6 +419,9 @@ class Context:
         idbuf = C.create_string_buffer(uid, 128)
         self._call("femcy_comm_init", int(rank), int(nranks), idbuf, d.size, _ptr(d), _ptr(s), int(niface_global),
                    _ptr(ow))
+        ng = C.c_int64()
+        self._call("femcy_comm_info", None, None, C.byref(ng))
+        self.n_global = int(ng.value)
 
     def iface_sum(self, vec_id: int):
         self._call("femcy_iface_sum", int(vec_id))

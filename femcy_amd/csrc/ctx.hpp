@@ -219,6 +219,7 @@ int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
 int comm_destroy(Ctx* c);
 int iface_sum(Ctx* c, double* d_v);
+int scalar_across_ranks(Ctx* c, double* d_val, int mode, double* out);
 void pcg_graph_reset(Ctx* c);
 
 }  // namespace femcy

@@ -165,7 +165,7 @@ int femcy_ctx_create(int device, femcy_ctx** out) {
         return rc;
     }
     if (hipHostMalloc((void**)&c->h_state, sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_scalar, 64, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_scalar, 4096, hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         delete ctx;
         return FEMCY_ENOMEM;
@@ -452,7 +452,7 @@ int femcy_vec_norm(femcy_ctx* ctx, int vec, double* rms) {
     double ss = 0.0;
     int rc = vec_sumsq(c, c->d_vec[vec], &ss);
     if (rc) return rc;
-    *rms = std::sqrt(ss / (double)c->n);
+    *rms = std::sqrt(ss / (double)(c->comm ? c->n_global : c->n));   // RMS over the whole system
     return FEMCY_OK;
 }
 int femcy_vec_absmax(femcy_ctx* ctx, int vec, double* out) {
@@ -488,7 +488,8 @@ int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec) {
     VEC_OR_FAIL(f_vec);
     int rc = launch_geom(c, c->d_vec[u_vec], true);
     if (rc) return rc;
-    return launch_nodal_force(c, c->d_vec[f_vec]);
+    if ((rc = launch_nodal_force(c, c->d_vec[f_vec]))) return rc;
+    return iface_sum(c, c->d_vec[f_vec]);      // multi-rank: forces of the elements other ranks hold (no-op otherwise)
 }
 
 static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k) {
@@ -497,6 +498,7 @@ static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k
             set_error("constrained DOF %d out of range", dofs[i]);
             return FEMCY_EINVAL;
         }
+    if (k == 0) return FEMCY_OK;
     int rc = ensure_scratch(c, k);
     if (rc) return rc;
     FEMCY_HIP(hipMemcpyAsync(c->d_idx_scratch, dofs, sizeof(int32_t) * k, hipMemcpyHostToDevice, c->stream));
@@ -508,12 +510,14 @@ int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const doub
     CTX_OR_FAIL(ctx);
     READY_OR_FAIL();
     VEC_OR_FAIL(rhs_vec);
-    if (k == 0) return FEMCY_OK;
-    FEMCY_REQUIRE(dofs && vals && k > 0, "bad Dirichlet arguments");
+    if (k == 0 && !c->comm) return FEMCY_OK;
+    FEMCY_REQUIRE(k >= 0 && (k == 0 || (dofs && vals)), "bad Dirichlet arguments");
     FEMCY_REQUIRE(rhs_vec != FEMCY_VEC_TMP0 && rhs_vec != FEMCY_VEC_TMP1, "rhs may not alias the scratch vectors");
     int rc = stage_dofs(c, dofs, vals, k);
     if (rc) return rc;
-    bool any = false;
+    // multi-rank: the elimination below is collective (other ranks may hold prescribed values even if this one
+    // holds none), so it always runs
+    bool any = c->comm != nullptr;
     for (int32_t i = 0; i < k; ++i) any = any || (vals[i] != 0.0);
     if (any) {
         // rhs -= K s  (s = prescribed values, 0 elsewhere): column-wise elimination through one SpMV with
@@ -523,6 +527,7 @@ int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const doub
         if ((rc = vec_fill(c, s, 0.0, c->n))) return rc;
         if ((rc = vec_scatter(c, s, c->d_idx_scratch, c->d_val_scratch, k))) return rc;
         if ((rc = launch_spmv(c, s, Ks, nullptr, nullptr))) return rc;
+        if ((rc = iface_sum(c, Ks))) return rc;
         if ((rc = vec_sub(c, c->d_vec[rhs_vec], c->d_vec[rhs_vec], Ks))) return rc;
     }
     if ((rc = vec_scatter(c, c->d_vec[rhs_vec], c->d_idx_scratch, c->d_val_scratch, k))) return rc;
@@ -594,14 +599,15 @@ int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int 
     VEC_OR_FAIL(rhs_vec);
     DOFSET_OR_FAIL(id);
     FEMCY_REQUIRE(rhs_vec != FEMCY_VEC_TMP0 && rhs_vec != FEMCY_VEC_TMP1, "rhs may not alias the scratch vectors");
-    if (ds.k == 0) return FEMCY_OK;
+    if (ds.k == 0 && !c->comm) return FEMCY_OK;
     int rc;
-    if (value != 0.0) {   // rhs -= K s with s = value on the block's DOFs (see femcy_apply_dirichlet_linear)
+    if (value != 0.0) {   // rhs -= K s with s = value on the block's DOFs (see femcy_apply_dirichlet_linear); collective
         double* s = c->d_vec[FEMCY_VEC_TMP0];
         double* Ks = c->d_vec[FEMCY_VEC_TMP1];
         if ((rc = vec_fill(c, s, 0.0, c->n))) return rc;
         if ((rc = vec_scatter_const(c, s, ds.d_dofs, value, ds.k))) return rc;
         if ((rc = launch_spmv(c, s, Ks, nullptr, nullptr))) return rc;
+        if ((rc = iface_sum(c, Ks))) return rc;
         if ((rc = vec_sub(c, c->d_vec[rhs_vec], c->d_vec[rhs_vec], Ks))) return rc;
     }
     if ((rc = vec_scatter_const(c, c->d_vec[rhs_vec], ds.d_dofs, value, ds.k))) return rc;
@@ -690,7 +696,9 @@ int femcy_loadset_neumann(femcy_ctx* ctx, int32_t id, double traction, const dou
         FEMCY_HIP(hipMemcpyAsync(ls.d_dir, direction, sizeof(double) * c->dm, hipMemcpyHostToDevice, c->stream));
         FEMCY_HIP(hipStreamSynchronize(c->stream));   // the host buffer is only borrowed for the call
     }
-    return launch_neumann(c, ls, traction, direction == nullptr, c->d_vec[rhs_vec]);
+    int rc = launch_neumann(c, ls, traction, direction == nullptr, c->d_vec[rhs_vec]);
+    if (rc) return rc;
+    return iface_sum(c, c->d_vec[rhs_vec]);    // multi-rank: each rank loads the facets of its own elements
 }
 
 int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
@@ -890,7 +898,7 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
                     const uint8_t* owner) {
     CTX_OR_FAIL(ctx);
     FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
-    FEMCY_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && id128, "bad rank/nranks");
+    FEMCY_REQUIRE(nranks >= 1 && nranks <= 512 && rank >= 0 && rank < nranks && id128, "bad rank/nranks");
     FEMCY_REQUIRE(niface_local >= 0 && niface_global >= niface_local, "bad interface sizes");
     FEMCY_REQUIRE(owner, "owner mask required");
     for (int32_t i = 0; i < niface_local; ++i) {
@@ -928,6 +936,14 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     FEMCY_HIP(hipMemcpy(&owned, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost));
     c->n_global = (int64_t)(owned + 0.5);
+    return FEMCY_OK;
+}
+
+int femcy_comm_info(femcy_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* n_global) {
+    CTX_OR_FAIL(ctx);
+    if (rank) *rank = c->comm ? c->rank : 0;
+    if (nranks) *nranks = c->comm ? c->nranks : 1;
+    if (n_global) *n_global = c->comm ? c->n_global : c->n;
     return FEMCY_OK;
 }
 

@@ -916,6 +916,11 @@ int launch_energy_sum(Ctx* c, double* total) {
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     double s = 0.0;
     for (double v : h) s += v;
+    if (c->comm) {       // elements are held by exactly one rank: the total is the plain sum over the ranks
+        FEMCY_HIP(hipMemcpyAsync(c->d_part2, &s, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        return scalar_across_ranks(c, c->d_part2, 0, total);
+    }
     *total = s;
     return FEMCY_OK;
 }

@@ -434,10 +434,11 @@ __global__ void k_scatter_const(int32_t k, const int32_t* __restrict__ idx, doub
 }
 // mode 0: sum of squares, mode 1: max |.|; partials then a single-block finish into *out
 __global__ void __launch_bounds__(BS) k_reduce(int64_t n, const double* __restrict__ v, int mode,
-                                               double* __restrict__ part) {
+                                               const uint8_t* __restrict__ owner, double* __restrict__ part) {
     __shared__ double sm[BS / 64];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) {
+        if (owner && !owner[i]) continue;           // multi-rank: a shared DOF counts on its owner only
         const double t = v[i];
         acc = mode ? fmax(acc, nan_to_inf_abs(t)) : acc + t * t;
     }
@@ -489,15 +490,36 @@ int vec_scatter_const(Ctx* c, double* d, const int32_t* d_idx, double val, int32
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
 }
-static int vec_reduce(Ctx* c, const double* d, int mode, double* out) {
-    const int g = ew_grid(c, c->n);
-    hipLaunchKernelGGL(k_reduce, dim3(g), dim3(BS), 0, c->stream, c->n, d, mode, c->d_part1);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part1, mode, c->d_part2);
-    FEMCY_HIP(hipGetLastError());
-    FEMCY_HIP(hipMemcpyAsync(c->h_scalar, c->d_part2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+// the scalar at d_val (device) -> host; multi-rank: summed (mode 0) or maximised (mode 1) over the ranks first.
+// Collective when a communicator is attached: every rank must make the same call.
+int scalar_across_ranks(Ctx* c, double* d_val, int mode, double* out) {
+    if (c->comm && mode == 0) {
+        int rc = comm_allreduce_sum(c, d_val, 1);
+        if (rc) return rc;
+    }
+    if (c->comm && mode == 1) {
+        int rc = comm_allgather(c, d_val, c->d_gather, 1);
+        if (rc) return rc;
+        FEMCY_HIP(hipMemcpyAsync(c->h_scalar, c->d_gather, sizeof(double) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        double m = 0.0;
+        for (int r = 0; r < c->nranks; ++r) m = std::fmax(m, c->h_scalar[r]);
+        *out = m;
+        return FEMCY_OK;
+    }
+    FEMCY_HIP(hipMemcpyAsync(c->h_scalar, d_val, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     *out = c->h_scalar[0];
     return FEMCY_OK;
+}
+
+static int vec_reduce(Ctx* c, const double* d, int mode, double* out) {
+    const int g = ew_grid(c, c->n);
+    hipLaunchKernelGGL(k_reduce, dim3(g), dim3(BS), 0, c->stream, c->n, d, mode,
+                       (const uint8_t*)(c->comm ? c->d_owner : nullptr), c->d_part1);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, g, c->d_part1, mode, c->d_part2);
+    FEMCY_HIP(hipGetLastError());
+    return scalar_across_ranks(c, c->d_part2, mode, out);
 }
 int vec_sumsq(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 0, out); }
 int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1, out); }

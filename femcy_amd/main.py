@@ -18,10 +18,13 @@ from .tiGadgets import field_abs_max
 
 
 def run(fileName: str, device: int = 0, verbose: bool = True):
+    from . import distributed
     inp = InpInfo(fileName)
     nodes, eSets = inp.nodes, inp.eSets
-    body = Body(nodes=nodes, elements=list(eSets.values())[0], ELE=inp.ELE)
     material = list(inp.materials.values())[0]
+    if distributed.wanted():       # launched by torch.distributed.run: one rank per GPU, one element partition each
+        return run_partitioned(inp, material, verbose)
+    body = Body(nodes=nodes, elements=list(eSets.values())[0], ELE=inp.ELE)
     system = System_of_equations(body, material, inp.geometric_nonlinear, device=device, verbose=verbose)
     time0 = time.time()
     system.solve(inp, show_newton_steps=True, save2path=None)
@@ -41,6 +44,28 @@ def run(fileName: str, device: int = 0, verbose: bool = True):
     return inp, system
 
 
+def run_partitioned(inp, material, verbose: bool = True):
+    """the same solve with the mesh split by element over the ranks of the job (femcy_amd/distributed.py).
+    Rank 0 prints; `system.dof_global` holds the gathered displacements there (None on other ranks)."""
+    from . import distributed
+    system, local_deck, part = distributed.partitioned_system(inp, material, verbose)
+    say = print if part.rank == 0 else (lambda *a, **k: None)
+    time0 = time.time()
+    system.solve(local_deck, show_newton_steps=True, save2path=None)
+    system.ctx.sync()
+    time1 = time.time()
+    system.dof_global = distributed.gather_dof(part, system.dof.to_numpy(), inp.nodes.size)
+    say(f"\033[40;33;1m {part.nranks} ranks, {system.ctx.n_global} DOF: time for finite element computing is "
+        f"{time1 - time0} s \033[0m")
+    system.get_elasEng()                                  # collective: every rank makes the call
+    say(f"total elastic energy is {system.elsEng}")
+    system.compute_strain_stress()
+    umax = field_abs_max(system.dof)
+    say(f"\033[40;33;1m max dof (disp) = {umax} \033[0m")
+    say(f" solver statistics: {system.stats}")
+    return inp, system
+
+
 def main(argv=None):
     os.system("")
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -51,6 +76,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
     fileName = args.inp or input("\033[32;1m please give the .inp format's input file path and name: \033[0m")
     inp, system = run(fileName, device=args.device, verbose=not args.quiet)
+    if getattr(system, "part", None) is not None:
+        if args.save and system.part.rank == 0:
+            np.savez(args.save, nodes=inp.nodes, dof=system.dof_global)
+        return
     if args.save:
         if args.save.endswith(".vtk"):
             from .vtk_out import write_vtk

@@ -109,3 +109,29 @@ def gather_owned(parts: List[Part], local_vectors: List[np.ndarray], n_global: i
         sel = p.owner.astype(bool)
         out[gd[sel]] = np.asarray(v)[sel]
     return out
+
+
+class LocalDeck:
+    """what `System_of_equations.solve` reads from an `InpInfo` (dirichlet_bc_info, neumann_bc_info, time_incs),
+    restricted to one rank's sub-mesh: node sets become local node ids (nodes the rank does not hold are
+    dropped), face sets keep the facets of elements this rank holds, as local sorted node tuples."""
+
+    def __init__(self, inp, part: Part, body):
+        self.time_incs = inp.time_incs
+        self.geometric_nonlinear = inp.geometric_nonlinear
+        self.materials = inp.materials
+        self.ELE = inp.ELE
+        self.nodes = part.nodes
+        self.dirichlet_bc_info = [dict(bc, node_set=part.localize_nodes(np.asarray(bc["node_set"])))
+                                  for bc in inp.dirichlet_bc_info]
+        g2l = {int(g): i for i, g in enumerate(part.l2g)}
+        boundary = body.get_boundary() if inp.neumann_bc_info else {}
+        self.neumann_bc_info = []
+        for nb in inp.neumann_bc_info:
+            faces = set()
+            for f in nb["face_set"]:
+                if all(int(v) in g2l for v in f):
+                    lf = tuple(sorted(g2l[int(v)] for v in f))
+                    if lf in boundary:
+                        faces.add(lf)
+            self.neumann_bc_info.append(dict(nb, face_set=faces))

@@ -37,7 +37,11 @@ class System_of_equations:
     """K(dof) . du = rhs / residual on one MI355X."""
 
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
-                 direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None):
+                 direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
+                 part=None, comm_uid: bytes = None):
+        """part / comm_uid: this process (or thread) holds one element partition of the mesh
+        (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
+        `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
         self.dm = body.dm
         self.geometric_nonlinear = geometric_nonlinear
         self.body = body
@@ -55,6 +59,11 @@ class System_of_equations:
         self.ctx.set_element(self.ELE)
         self.ctx.set_material(material)
         self.pattern = self.ctx.build_pattern()
+        self.part = part
+        if part is not None:
+            self.ctx.comm_init(part.rank, part.nranks, comm_uid, part.iface_local_dofs, part.iface_global_slot,
+                               part.niface_global, part.owner)
+            self.verbose = verbose and part.rank == 0
         self._say("\033[32;1m pattern: {} DOF, {} blocks of {}x{}, ELL width {} ({:.3f} s) \033[0m".format(
             self.pattern.n, self.pattern.nnzb, self.dm, self.dm, self.pattern.ell_width, time.time() - t0))
 
@@ -80,6 +89,10 @@ class System_of_equations:
         self._dofsets = {}
         self._loadsets = {}
         self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0}
+
+    @property
+    def n_system(self) -> int:
+        return self.dof.shape[0] if self.part is None else self.ctx.n_global
 
     def _say(self, msg):
         if self.verbose:
@@ -128,7 +141,7 @@ class System_of_equations:
         return self.solve_by_CG(eps=self.direct_eps)
 
     def solve_dof(self):
-        if self.dof.shape[0] < 1e5:
+        if self.n_system < 1e5:                        # DOFs of the whole system (all ranks take the same branch)
             return self.solve_by_scipy()
         return self.solve_by_CG()
 
@@ -175,6 +188,9 @@ class System_of_equations:
         if key not in self._loadsets:
             boundary = self.body.get_boundary()
             facets = [tuple(f) for f in load_facets]
+            if not facets:       # a rank of a partitioned run that holds none of the loaded facets
+                self._loadsets[key] = (self.ctx.loadset(self.ELE, np.zeros(0, np.int32), np.zeros(0, np.int32)), load_facets)
+                return self._loadsets[key][0]
             elem = np.fromiter((boundary[f] for f in facets), dtype=np.int64, count=len(facets))
             fnodes = np.asarray(facets, dtype=np.int64).reshape(len(facets), -1)
             conn = self.body.np_elements[elem]                                            # [nf, npe]

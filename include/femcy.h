@@ -229,7 +229,15 @@ int femcy_comm_local_id(void* id128);
 int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id128,
                     int32_t niface_local, const int32_t* iface_local_dofs, const int32_t* iface_global_slot,
                     int32_t niface_global, const uint8_t* owner /*[n]*/);
-/* sum a sub-assembled vector over the ranks sharing each interface DOF (forces, diag(K)) */
+/* With a communicator attached every vector the API hands back is the assembled / replicated one: femcy_spmv,
+ * femcy_internal_force and femcy_loadset_neumann sum their sub-assembled result over the interface, femcy_vec_norm
+ * (RMS over the DOFs of the whole system) and femcy_vec_absmax count each shared DOF once and reduce over the
+ * ranks, femcy_elastic_energy sums over the ranks, femcy_pcg's default iteration cap is the global DOF count.
+ * These calls are therefore collective: every rank makes the same sequence of them.
+ * femcy_comm_info: rank, ranks and the DOF count of the whole system (owned DOFs summed over the ranks; n and 1
+ * rank without a communicator).
+ * femcy_iface_sum: sum any other sub-assembled vector over the ranks sharing each interface DOF */
+int femcy_comm_info(femcy_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* n_global);
 int femcy_iface_sum(femcy_ctx* ctx, int vec);
 
 #ifdef __cplusplus

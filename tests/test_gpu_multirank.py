@@ -105,8 +105,7 @@ def test_partitioned_solve_equals_single_context(gpu_ctx_factory, name, nranks):
         try:
             c.upload(be.VEC_DOF, p.scatter_global(u_g))
             c.assemble_K(be.VEC_DOF)
-            c.internal_force(be.VEC_DOF, be.VEC_FORCE)       # sub-assembled forces ...
-            c.iface_sum(be.VEC_FORCE)                         # ... summed over the interface
+            c.internal_force(be.VEC_DOF, be.VEC_FORCE)       # sub-assembled forces, summed over the interface
             f = c.download(be.VEC_FORCE)
             c.upload(be.VEC_TMP0, p.scatter_global(x_g))
             c.spmv(be.VEC_TMP0, be.VEC_TMP1)                  # includes the interface exchange
@@ -174,3 +173,76 @@ def test_rendezvous_failures_are_reported(gpu_ctx_factory):
                     parts[0].owner)                                  # wrong group size
     for x in (a, b, c):
         x.close()
+
+
+@pytest.mark.parametrize("name,nranks,axis", [("twist_plate_C3D4.inp", 2, 2),                 # nlgeom, *Boundary user
+                                              ("cook_3d_linearEl_largeDef.inp", 3, 0),        # neo-Hookean + *Dsload
+                                              ("ellip_CPS8.inp", 2, 0),                       # linear: 0/1 elimination
+                                              ("beamDeflec_quadPSE_largeD_load800.inp", 2, 0)])   # CPS6 + load, cut-backs
+def test_partitioned_deck_solve_equals_single_context(name, nranks, axis):
+    """the whole driver (increments, modified Newton, line searches, cut-backs) with the mesh split over `nranks`
+    contexts: every rank runs the reference's control flow on collective scalars, so all ranks take the same
+    decisions as the un-partitioned run -- same increments, same Newton counts, same displacements."""
+    from femcy_amd import backend as be, partition
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    inp = InpInfo(deck(name))
+    el = list(inp.eSets.values())[0]
+    mat = list(inp.materials.values())[0]
+    n = inp.nodes.size
+
+    ref = System_of_equations(Body(inp.nodes, el, inp.ELE), mat, inp.geometric_nonlinear, verbose=False)
+    ref.solve(inp)
+    u_ref = ref.dof.to_numpy()
+    e_ref = ref.get_elasEng()
+    umax_ref = ref.ctx.vec_absmax(be.VEC_DOF)
+
+    parts = partition.build_all_parts(inp.nodes, el, nranks, axis=axis)
+    uid = be.Context.comm_local_id()
+
+    def rank_main(r):
+        p = parts[r]
+        body = Body(p.nodes, p.elements, inp.ELE)
+        system = System_of_equations(body, mat, inp.geometric_nonlinear, verbose=False, part=p, comm_uid=uid)
+        try:
+            system.solve(partition.LocalDeck(inp, p, body))
+            return (system.dof.to_numpy(), system.increments, dict(system.stats), system.get_elasEng(),
+                    system.ctx.vec_absmax(be.VEC_DOF))
+        finally:
+            system.ctx.close()
+
+    outs = run_ranks(nranks, rank_main)
+    for u, incs, stats, energy, umax in outs:
+        key = lambda i: (i["converged"], i["newton_loop"])
+        assert [key(i) for i in incs] == [key(i) for i in ref.increments]
+        assert stats["linear_solves"] == ref.stats["linear_solves"]
+        assert abs(energy - e_ref) <= 1e-7 * abs(e_ref) and abs(umax - umax_ref) <= 1e-8 * umax_ref
+    u = partition.gather_owned(parts, [o[0] for o in outs], n)
+    assert np.linalg.norm(u - u_ref) <= 1e-7 * np.linalg.norm(u_ref)
+    for p, o in zip(parts, outs):                 # replicated interface values agree with the owner's
+        assert np.linalg.norm(o[0] - p.scatter_global(u)) <= 1e-9 * np.linalg.norm(u)
+
+
+def test_main_as_one_rank_rccl_job(tmp_path):
+    """`python -m femcy_amd.main` launched the way torch.distributed.run launches it (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_* in the environment), forced through the partitioned path with a 1-rank RCCL communicator: process
+    group, unique-id broadcast, femcy_comm_init over RCCL, collective norms, gathered result -- everything an
+    N-GPU job does except talking to a second GPU.  Same displacements as the plain single-context run."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    name = deck("beam_CPS3_disp_meshSize5.inp")
+    out_a, out_b = str(tmp_path / "plain.npz"), str(tmp_path / "job.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run([sys.executable, "-m", "femcy_amd.main", name, "--quiet", "--save", out_a], check=True, env=env,
+                   cwd=ROOT, timeout=600, stdout=subprocess.DEVNULL)
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+               FEMCY_FORCE_PARTITION="1")
+    r = subprocess.run([sys.executable, "-m", "femcy_amd.main", name, "--quiet", "--save", out_b], env=env, cwd=ROOT,
+                       timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "1 ranks" in r.stdout
+    a, b = np.load(out_a)["dof"], np.load(out_b)["dof"]
+    assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(a)
