@@ -70,7 +70,7 @@ def main(argv=None):
     os.system("")
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("inp", nargs="?", default=None)
-    ap.add_argument("--save", default=None, help="write results to this .npz, or a legacy .vtk (mesh + displacement + Mises) for ParaView")
+    ap.add_argument("--save", default=None, help="write results to this .npz, a legacy .vtk (mesh + displacement + Mises) for ParaView, or a .png picture of the deformed mesh coloured by von Mises stress")
     ap.add_argument("--device", type=int, default=int(os.environ.get("FEMCY_DEVICE", "0")))
     ap.add_argument("--quiet", action="store_true")
     args = ap.parse_args(argv)
@@ -84,6 +84,9 @@ def main(argv=None):
         if args.save.endswith(".vtk"):
             from .vtk_out import write_vtk
             write_vtk(args.save, system)
+        elif args.save.endswith(".png"):
+            from .png_out import write_png
+            write_png(args.save, system)
         else:
             np.savez(args.save, nodes=inp.nodes, dof=system.dof.to_numpy(),
                      cauchy_stress=system.cauchy_stress.to_numpy(), mises_stress=system.mises_stress.to_numpy())

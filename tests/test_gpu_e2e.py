@@ -88,6 +88,9 @@ def test_readme_known_answer_end_to_end(tmp_path):
     from femcy_amd.vtk_out import write_vtk
     write_vtk(str(tmp_path / "out.vtk"), system)
     assert (tmp_path / "out.vtk").read_text().count("CELL_TYPES") == 1
+    from femcy_amd.png_out import write_png
+    write_png(str(tmp_path / "out.png"), system)                 # deformed mesh coloured by nodal von Mises stress
+    assert (tmp_path / "out.png").read_bytes()[:4] == b"\x89PNG" and (tmp_path / "out.png").stat().st_size > 20000
     system.ctx.close()
     system, u = run_keep("ellip_membrane_linEle_localVeryFine")
     system.compute_strain_stress()

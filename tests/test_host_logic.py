@@ -182,6 +182,30 @@ def test_body_topology_matches_oracle():
     assert ij.shape == (969, np.diff(topo.adj_ptr).max() * 3 + 1) and (ij[:, 0] % 3 == 0).all()
 
 
+def test_png_renderer(tmp_path):
+    """headless picture of a result: valid PNG, coloured pixels, 2-D and 3-D meshes."""
+    import struct
+    import zlib
+    from femcy_amd import png_out
+    for name in ("ellip_CPS8.inp", "twist_plate_C3D4.inp"):
+        inp = InpInfo(deck(name))
+        el = list(inp.eSets.values())[0]
+        tris = (np.concatenate([el[:, list(t)] for t in inp.ELE._tri_split]) if inp.nodes.shape[1] == 2
+                else inp.ELE.getMesh(el)[2])
+        path = str(tmp_path / (name + ".png"))
+        png_out.render_png(path, inp.nodes, tris, np.linalg.norm(inp.nodes, axis=1), label="r", dpi=50)
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        w, h = struct.unpack(">II", raw[16:24])
+        assert (w, h) == (400, 300)
+        idat = b"".join(raw[m.start() + 4:m.start() + 4 + struct.unpack(">I", raw[m.start() - 4:m.start()])[0]]
+                        for m in re.finditer(b"IDAT", raw))
+        px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, -1)[:, 1:].reshape(h, w, -1)[..., :3]
+        assert (np.ptp(px.astype(int), axis=2) > 60).mean() > 0.05        # a good share of saturated (jet) pixels
+    vals = png_out.nodal_average(np.array([[0, 1, 2], [1, 2, 3]]), np.array([[1., 2., 3.], [4., 5., 6.]]), 5)
+    assert np.allclose(vals, [1., 3., 4., 6., 0.])
+
+
 def test_meshgen_twist_plate():
     m = meshgen.twist_plate_k(1)
     assert m["nodes"].shape == (9 * 2 * 13, 3) and m["elements"].shape == (6 * 8 * 12, 4)
