@@ -82,6 +82,7 @@ struct Ctx {
     double* d_C = nullptr;
     int32_t mat_kind = -1;
     double mat_params[4] = {0, 0, 0, 0};
+    double h_C[36] = {0};             // host copy of C (the consistent tangent reads lambda, mu from it)
     bool have_mesh = false, have_element = false, have_material = false, have_pattern = false;
 
     // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
@@ -153,6 +154,7 @@ struct Ctx {
 
     // ---- options / timing
     int opt_assembly = FEMCY_ASM_AUTO;
+    int opt_tangent = 0;              // FEMCY_OPT_TANGENT
     int opt_poll = 32;
     int opt_timing = 0;               // 0 off, 1 every launch, k > 1: every k-th SpMV launch
     int64_t spmv_count = 0;

@@ -243,6 +243,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 spmv_split(c);
             }
             break;
+        case FEMCY_OPT_TANGENT:
+            FEMCY_REQUIRE(value == 0 || value == 1, "tangent: 0 (reference) or 1 (consistent)");
+            c->opt_tangent = (int)value;
+            break;
         case 102:   /* test knob: SpMV matrix loads non-temporal (-1 auto: matrix larger than the Infinity Cache) */
             FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
             c->opt_spmv_nt = (int)value;
@@ -355,6 +359,7 @@ int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C, const doub
     int rc;
     if ((rc = dev_alloc(&c->d_C, (size_t)s * s, false))) return rc;
     FEMCY_HIP(hipMemcpy(c->d_C, C, sizeof(double) * s * s, hipMemcpyHostToDevice));
+    for (int i = 0; i < s * s; ++i) c->h_C[i] = C[i];
     c->mat_kind = kind;
     for (int i = 0; i < 4; ++i) c->mat_params[i] = (i < nparams) ? params[i] : 0.0;
     c->have_material = true;
@@ -476,7 +481,8 @@ int femcy_assemble_K(femcy_ctx* ctx, int u_vec) {
         VEC_OR_FAIL(u_vec);
         du = c->d_vec[u_vec];
     }
-    int rc = launch_geom(c, du, false);
+    // the consistent tangent needs F and sigma of this state: the element pass then also evaluates the material
+    int rc = launch_geom(c, du, c->opt_tangent == 1);
     if (rc) return rc;
     return launch_assemble(c);
 }

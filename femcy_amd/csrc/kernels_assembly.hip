@@ -314,6 +314,112 @@ __device__ __forceinline__ void kblock_add<2>(const double* __restrict__ ga, con
     }
 }
 
+// consistent tangent block (FEMCY_OPT_TANGENT = 1), updated-Lagrangian form:
+//   K_ab[i][k] = vol * ( gradN_a[j] c_ijkl gradN_b[l]  +  delta_ik gradN_a . sigma . gradN_b )
+// with the spatial elasticity tensor c = (1/J) push-forward of dS/dE:
+//   StVK (S = C:E, isotropic lambda, mu):  c_ijkl = (lambda b_ij b_kl + mu (b_ik b_jl + b_il b_jk)) / J,  b = F F^T
+//   neo-Hookean of neo_hookean.py:66-77 (sigma = 2 C1/J (b - I) + 2 D1 (J-1) I):
+//                                          c_ijkl = lambda' d_ij d_kl + mu' (d_ik d_jl + d_il d_jk),
+//                                          mu' = 2 C1/J - 2 D1 (J-1),  lambda' = 2 D1 (2J-1)
+// checked against central differences of femcy_internal_force (tests/test_gpu_tangent.py).
+template <int DM>
+__device__ __forceinline__ void kblock_consistent(const double* __restrict__ ga, const double* __restrict__ gb,
+                                                  const double* __restrict__ Fp, const double* __restrict__ Sp,
+                                                  bool neo, double lam, double mu, double p0, double p1, double v,
+                                                  double (&acc)[DM * DM]) {
+    double F[DM][DM];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) F[i][j] = Fp[i * DM + j];
+    double J;
+    if constexpr (DM == 3) J = det3(F);
+    else J = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+    double geo = 0.0;                       // gradN_a . sigma . gradN_b
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j) geo += ga[i] * Sp[i * DM + j] * gb[j];
+    if (neo) {
+        const double mu_s = 2.0 * p0 / J - 2.0 * p1 * (J - 1.0), lam_s = 2.0 * p1 * (2.0 * J - 1.0);
+        double ab = 0.0;
+#pragma unroll
+        for (int i = 0; i < DM; ++i) ab += ga[i] * gb[i];
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                acc[i * DM + k] += v * (lam_s * ga[i] * gb[k] + mu_s * gb[i] * ga[k] + (i == k ? mu_s * ab + geo : 0.0));
+    } else {
+        double b[DM][DM], bga[DM], bgb[DM];
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int j = 0; j < DM; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int m = 0; m < DM; ++m) t += F[i][m] * F[j][m];
+                b[i][j] = t;
+            }
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < DM; ++i) {
+            double ta = 0.0, tb = 0.0;
+#pragma unroll
+            for (int j = 0; j < DM; ++j) {
+                ta += b[i][j] * ga[j];
+                tb += b[i][j] * gb[j];
+            }
+            bga[i] = ta;
+            bgb[i] = tb;
+        }
+#pragma unroll
+        for (int i = 0; i < DM; ++i) s += ga[i] * bgb[i];
+        const double vj = v / J;
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                acc[i * DM + k] += vj * (lam * bga[i] * bgb[k] + mu * (s * b[i][k] + bgb[i] * bga[k])) + (i == k ? v * geo : 0.0);
+    }
+}
+
+// owner-computes assembly of the consistent tangent: the per-block gather with F and sigma of each contributing
+// Gauss point (an opt-in extension; the fast paths below assemble the reference's matrix)
+template <int DM>
+__global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos, int32_t npe, int32_t nGP,
+                                                                    const int32_t* __restrict__ ctr_ptr,
+                                                                    const int32_t* __restrict__ ctr,
+                                                                    const double* __restrict__ dsdx,
+                                                                    const double* __restrict__ vol,
+                                                                    const double* __restrict__ Fg,
+                                                                    const double* __restrict__ Sg, bool neo,
+                                                                    double lam, double mu, double p0, double p1,
+                                                                    double* __restrict__ Kvals) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    double acc[DM * DM];
+#pragma unroll
+    for (int k = 0; k < DM * DM; ++k) acc[k] = 0.0;
+    for (int32_t c = ctr_ptr[p]; c < ctr_ptr[p + 1]; ++c) {
+        const int32_t code = ctr[c];
+        const int32_t lb = code % npe;
+        const int32_t t = code / npe;
+        const int32_t la = t % npe;
+        const int64_t e = t / npe;
+        for (int g = 0; g < nGP; ++g) {
+            const int64_t gp = e * nGP + g;
+            const int64_t base = gp * npe;
+            kblock_consistent<DM>(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, Fg + gp * DM * DM, Sg + gp * DM * DM,
+                                  neo, lam, mu, p0, p1, vol[gp], acc);
+        }
+    }
+    const int64_t row = p >> 6;
+    const int lane = (int)(p & 63);
+#pragma unroll
+    for (int k = 0; k < DM * DM; ++k) Kvals[kv_index<DM>(row, k, lane)] = acc[k];
+}
+
 // owner-computes assembly: lane p = stored block (row = p / 64, lane = p % 64).
 // (A variant with the element arity as a template parameter -- constant-divisor decode of the packed
 // contribution code -- measured 28 % slower on gfx950 for C3D4 and equal for C3D10: the kernel is bound by
@@ -968,6 +1074,25 @@ int launch_assemble(Ctx* c) {
     size_t th = timing_begin(c, T_ASM);
     int mode = c->opt_assembly;
     if (mode == FEMCY_ASM_AUTO) mode = (c->npe > 4) ? FEMCY_ASM_ROWS : FEMCY_ASM_GATHER;
+    if (c->opt_tangent == 1) {
+        FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
+        const bool neo = c->mat_kind == FEMCY_MAT_NEOHOOKE;
+        const int s = c->dm == 3 ? 6 : 3;
+        const double lam = c->h_C[0 * s + 1], mu = c->h_C[(s - 1) * s + (s - 1)];     // isotropic C: C01, C(shear,shear)
+        const int64_t npos = c->stored_rows * SLICE;
+        const int grid = (int)((npos + bs - 1) / bs);
+        if (c->dm == 3)
+            hipLaunchKernelGGL((k_assemble_gather_consistent<3>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
+                               c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_F, c->d_sigma, neo, lam, mu,
+                               c->mat_params[0], c->mat_params[1], c->d_Kvals);
+        else
+            hipLaunchKernelGGL((k_assemble_gather_consistent<2>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
+                               c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_F, c->d_sigma, neo, lam, mu,
+                               c->mat_params[0], c->mat_params[1], c->d_Kvals);
+        timing_end(c, th);
+        FEMCY_HIP(hipGetLastError());
+        return FEMCY_OK;
+    }
     if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);

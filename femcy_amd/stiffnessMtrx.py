@@ -38,7 +38,7 @@ class System_of_equations:
 
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
-                 part=None, comm_uid: bytes = None):
+                 part=None, comm_uid: bytes = None, tangent: str = "reference"):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -59,6 +59,12 @@ class System_of_equations:
         self.ctx.set_element(self.ELE)
         self.ctx.set_material(material)
         self.pattern = self.ctx.build_pattern()
+        # "reference": K = B^T C B on the current configuration with the constant C, as the reference assembles it
+        # (modified Newton).  "consistent": material tangent at F + geometric stiffness (extension, outside parity).
+        if tangent not in ("reference", "consistent"):
+            raise ValueError("tangent must be 'reference' or 'consistent'")
+        self.tangent = tangent
+        self.ctx.set_option(be.OPT_TANGENT, 1 if tangent == "consistent" and geometric_nonlinear else 0)
         self.part = part
         if part is not None:
             self.ctx.comm_init(part.rank, part.nranks, comm_uid, part.iface_local_dofs, part.iface_global_slot,

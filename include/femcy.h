@@ -92,8 +92,16 @@ enum femcy_option {
     FEMCY_OPT_EW_GRID = 4,      /* cap on workgroups of the element-wise PCG kernels (tuning)   */
     FEMCY_OPT_SELL_SIGMA = 6,   /* rows are sorted by length inside windows of this many nodes before slicing
                                    (SELL-C-sigma, default 4096; 64 = natural order); set before build_pattern */
-    FEMCY_OPT_PCG_GRAPH = 5     /* hipGraph replay of poll-bursts of PCG iterations: 0 off, 1 auto (default:
+    FEMCY_OPT_PCG_GRAPH = 5,    /* hipGraph replay of poll-bursts of PCG iterations: 0 off, 1 auto (default:
                                    below 2e5 DOF, where the loop is launch-bound), 2 always             */
+    FEMCY_OPT_TANGENT = 7       /* what femcy_assemble_K assembles.  0 (default) = the reference's matrix: B^T C B
+                                   on the current configuration with the constant C (stiffnessMtrx.py:124-186).
+                                   1 = the consistent tangent of femcy_internal_force: spatial elasticity tensor of
+                                   the material at F (the updates the reference left commented out,
+                                   neo_hookean.py:62-64, 79-81) + geometric stiffness (grad N_a . sigma . grad N_b) I.
+                                   An EXTENSION outside the parity runs: Newton iterates differ from the
+                                   reference's (they converge quadratically).  Isotropic 3-D, plane-strain and
+                                   neo-Hookean materials; not available for plane stress. */
 };
 
 typedef struct femcy_pattern_info {
