@@ -27,7 +27,7 @@ GP_DSDX, GP_VOL, GP_F, GP_SIGMA, GP_STRAIN, GP_MISES, GP_ENERGY = range(7)
 # enum femcy_option
 OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT, OPT_EW_GRID, OPT_PCG_GRAPH, OPT_SELL_SIGMA = range(7)
 OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent tangent (extension)
-ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO = 0, 1, 2, 3
+ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "femcy_ctx_create", "femcy_ctx_destroy", "femcy_last_error", "femcy_version", "femcy_set_option", "femcy_sync",

@@ -109,6 +109,8 @@ struct Ctx {
     uint16_t* d_slotj = nullptr;      // [ne*npe*npe] element-local (a,b) -> slot j in row of node a
     int32_t* d_ctr_ptr = nullptr;     // [stored_rows*64+1] contributions per stored block
     int32_t* d_ctr = nullptr;         // [ne*npe*npe] packed (e*npe+la)*npe+lb
+    int32_t* d_tpos = nullptr;        // [stored_rows*64] position of the transposed block (b,a) if a < b; p on the
+                                      // diagonal; -2 if a > b (the mirror lane stores it); -1 padding
     int32_t* d_ne_ptr = nullptr;      // [nn+1] node -> incident elements
     int32_t* d_ne_idx = nullptr;      // [ne*npe] packed e*npe+la
 

@@ -424,15 +424,26 @@ __global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos
 // (A variant with the element arity as a template parameter -- constant-divisor decode of the packed
 // contribution code -- measured 28 % slower on gfx950 for C3D4 and equal for C3D10: the kernel is bound by
 // L1 line throughput of the 24-byte dsdx gathers, not by the integer decode.)
-template <int DM>
+// SYM: K is symmetric block-wise, K_ba = K_ab^T (C is symmetric).  Only the lanes of the diagonal and of the
+// blocks with column node > row node evaluate their contributions; they also store the transpose at tpos[p],
+// the position of block (b, a).  tpos = -2 marks the mirrored (skipped) lanes, -1 padding.  Halves the dsdx
+// gathers that bound this kernel; the mirrored stores of a wavefront land in one block row of the neighbouring
+// slice on structured numberings, i.e. they stay coalesced.  K comes out exactly symmetric.
+template <int DM, bool SYM>
 __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t npe, int32_t nGP,
                                                          const int32_t* __restrict__ ctr_ptr,
                                                          const int32_t* __restrict__ ctr,
+                                                         const int32_t* __restrict__ tpos,
                                                          const double* __restrict__ dsdx,
                                                          const double* __restrict__ vol, const double* __restrict__ C,
                                                          double* __restrict__ Kvals) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npos) return;
+    int32_t tp = -1;
+    if (SYM) {
+        tp = tpos[p];
+        if (tp == -2) return;
+    }
     double acc[DM * DM];
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) acc[k] = 0.0;
@@ -471,6 +482,14 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
     const int lane = (int)(p & 63);
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) Kvals[kv_index<DM>(row, k, lane)] = acc[k];
+    if (SYM && tp >= 0 && tp != (int32_t)p) {
+        const int64_t trow = tp >> 6;
+        const int tlane = tp & 63;
+#pragma unroll
+        for (int r = 0; r < DM; ++r)
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(trow, cc * DM + r, tlane)] = acc[r * DM + cc];
+    }
 }
 
 // row-centric assembly: one wavefront per node (matrix block row).  Lanes are the (incident element, local
@@ -1073,7 +1092,7 @@ int launch_assemble(Ctx* c) {
     const int bs = 256;
     size_t th = timing_begin(c, T_ASM);
     int mode = c->opt_assembly;
-    if (mode == FEMCY_ASM_AUTO) mode = (c->npe > 4) ? FEMCY_ASM_ROWS : FEMCY_ASM_GATHER;
+    if (mode == FEMCY_ASM_AUTO) mode = (c->npe > 4) ? FEMCY_ASM_ROWS : FEMCY_ASM_GATHER_SYM;
     if (c->opt_tangent == 1) {
         FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
         const bool neo = c->mat_kind == FEMCY_MAT_NEOHOOKE;
@@ -1118,12 +1137,13 @@ int launch_assemble(Ctx* c) {
     } else {
         const int64_t npos = c->stored_rows * SLICE;
         const int grid = (int)((npos + bs - 1) / bs);
-        if (c->dm == 3)
-            hipLaunchKernelGGL((k_assemble_gather<3>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
-                               c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
-        else
-            hipLaunchKernelGGL((k_assemble_gather<2>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
-                               c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals);
+#define FEMCY_GATHER(DM_, SYM_)                                                                                   \
+    hipLaunchKernelGGL((k_assemble_gather<DM_, SYM_>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP, \
+                       c->d_ctr_ptr, c->d_ctr, c->d_tpos, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals)
+        const bool sym = mode == FEMCY_ASM_GATHER_SYM;
+        if (c->dm == 3) { if (sym) FEMCY_GATHER(3, true); else FEMCY_GATHER(3, false); }
+        else            { if (sym) FEMCY_GATHER(2, true); else FEMCY_GATHER(2, false); }
+#undef FEMCY_GATHER
     }
     timing_end(c, th);
     FEMCY_HIP(hipGetLastError());

@@ -224,6 +224,25 @@ int build_pattern(Ctx* c) {
         }
     }
 
+    // ---- transposed-block map for the symmetric gather assembly
+    std::vector<int32_t> tpos((size_t)stored_rows * SLICE, -1);
+    parallel_for(nn, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t a = lo; a < hi; ++a) {
+            const int32_t* row = adj.data() + adj_ptr[a];
+            tpos[block_pos((int32_t)a, 0)] = (int32_t)block_pos((int32_t)a, 0);
+            for (int32_t j = 1; j < rowlen[a]; ++j) {
+                const int32_t b = row[j];
+                if (b < a) {
+                    tpos[block_pos((int32_t)a, j)] = -2;
+                } else {
+                    const int32_t* rb = adj.data() + adj_ptr[b];
+                    const int32_t jb = (int32_t)(std::lower_bound(rb + 1, rb + rowlen[b], (int32_t)a) - rb);
+                    tpos[block_pos((int32_t)a, j)] = (int32_t)block_pos(b, jb);
+                }
+            }
+        }
+    });
+
     // ---- commit to the context
     c->nslices = nslices;
     c->stored_rows = stored_rows;
@@ -247,6 +266,7 @@ int build_pattern(Ctx* c) {
     if ((rc = upload(&c->d_slotj, slotj))) return rc;
     if ((rc = upload(&c->d_ctr_ptr, ctr_cnt))) return rc;
     if ((rc = upload(&c->d_ctr, ctr))) return rc;
+    if ((rc = upload(&c->d_tpos, tpos))) return rc;
     if ((rc = upload(&c->d_ne_ptr, ne_ptr))) return rc;
     if ((rc = upload(&c->d_ne_idx, ne_idx))) return rc;
 

@@ -59,7 +59,7 @@ def smooth_disp(nodes, scale):
 
 
 @pytest.mark.parametrize("name", DECKS)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_assemble_K(gpu_ctx_factory, name, mode):
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
@@ -427,7 +427,7 @@ def test_single_element_against_golden_vectors(gpu_ctx_factory, name, etype):
     ctx.set_material(mat)
     info = ctx.build_pattern()
     assert info.nnzb == ids.size ** 2 and info.nslices == 1
-    for mode in (be.ASM_GATHER, be.ASM_ROWS, be.ASM_ATOMIC):
+    for mode in (be.ASM_GATHER, be.ASM_ROWS, be.ASM_ATOMIC, be.ASM_GATHER_SYM):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(-1)
         K = ctx.get_K_bsr().toarray()
