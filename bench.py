@@ -143,10 +143,23 @@ def main():
         return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
 
     # untimed pre-warm on top of the W warmup steps: a fresh box needs ~1 s of load before the GPU sits at its
-    # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work)
+    # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work).  A step
+    # holds collectives, so the ranks must agree on the number of pre-warm steps: the stop test uses the MAX of the
+    # elapsed time over the ranks.
+    def agreed_elapsed(t0):
+        dt = time.perf_counter() - t0
+        if use_dist:
+            box = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(box, op=dist.ReduceOp.MAX)
+            dt = float(box.item())
+        return dt
+
     t_warm = time.perf_counter()
-    while args.warmup > 0 and time.perf_counter() - t_warm < 1.5:
+    while args.warmup > 0:
         step()
+        ctx.sync()
+        if agreed_elapsed(t_warm) >= 1.5:
+            break
     ctx.set_option(be.OPT_TIMING, args.sample)    # HIP events on the ctx stream; every k-th SpMV launch is sampled
     for _ in range(args.warmup):
         step()

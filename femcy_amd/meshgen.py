@@ -51,11 +51,12 @@ def plate_grid(nx: int, ny: int, nz: int, box: Tuple[float, float, float] = BOX)
     nodes = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
     sx, sy, sz = 1, nx + 1, (nx + 1) * (ny + 1)
     iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    base = (ix * sx + iy * sy + iz * sz).ravel()                       # cell origin node, cells x-fastest
-    corner_off = np.array([(c & 1) * sx + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz for c in range(8)])
+    idt = np.int32 if nodes.shape[0] < 2 ** 31 else np.int64
+    base = (ix * sx + iy * sy + iz * sz).ravel().astype(idt)           # cell origin node, cells x-fastest
+    corner_off = np.array([(c & 1) * sx + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz for c in range(8)], dtype=idt)
     local = _kuhn_local()                                              # [6,4] corner ids
     tets = base[:, None, None] + corner_off[local][None, :, :]         # [ncell,6,4]
-    return nodes, tets.reshape(-1, 4).astype(np.int32)
+    return nodes, tets.reshape(-1, 4).astype(np.int32, copy=False)
 
 
 def to_quadratic(nodes: np.ndarray, tets: np.ndarray):

@@ -54,7 +54,8 @@ def element_ranks(nodes: np.ndarray, elements: np.ndarray, nranks: int, axis: in
     """rank of every element: equal-count slabs ordered by centroid coordinate along `axis`
     (stable, so structured meshes split exactly on cell layers)."""
     ne = elements.shape[0]
-    cen = nodes[elements[:, :4] if elements.shape[1] > 4 else elements][:, :, axis].mean(axis=1)
+    corners = elements[:, :4] if elements.shape[1] > 4 else elements
+    cen = np.ascontiguousarray(nodes[:, axis])[corners].mean(axis=1)      # one coordinate only: 3x less traffic
     order = np.argsort(np.round(cen, 9), kind="stable")
     rank_of = np.empty(ne, dtype=np.int32)
     rank_of[order] = (np.arange(ne, dtype=np.int64) * nranks // ne).astype(np.int32)
