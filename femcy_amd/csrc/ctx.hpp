@@ -91,6 +91,8 @@ struct Ctx {
     int32_t spmv_grid = 0;            // 8 * max blocks per XCD
     int32_t spmv_wps = 1;             // wavefronts per slice (1, 2 or 4)
     bool spmv_nt = false;             // matrix stream with non-temporal loads (matrix larger than the Infinity Cache)
+    bool vec_nt = false;              // PCG vector kernels with non-temporal accesses
+    int opt_vec_nt = -1;              // -1 auto (same rule as the matrix stream), 0 / 1 forced (test knob 103)
     int opt_spmv_nt = -1;             // -1 auto, 0 / 1 forced (test knob 102)
     int32_t spmv_bpx_cap = 256;       // SpMV workgroups per XCD (larger slice ranges are looped in the kernel)
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)

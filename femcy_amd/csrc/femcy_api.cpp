@@ -247,6 +247,14 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || value == 1, "tangent: 0 (reference) or 1 (consistent)");
             c->opt_tangent = (int)value;
             break;
+        case 103:   /* test knob: PCG vector kernels with non-temporal loads / stores */
+            FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
+            c->opt_vec_nt = (int)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
+            break;
         case 102:   /* test knob: SpMV matrix loads non-temporal (-1 auto: matrix larger than the Infinity Cache) */
             FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
             c->opt_spmv_nt = (int)value;

@@ -255,6 +255,30 @@ __global__ void __launch_bounds__(BS) k_pcg_init_final(int np, const double* __r
 }
 
 // x += alpha d; r -= alpha Ad; partials (r.M.r, max|r|)
+// streaming accesses of the PCG vector kernels; NT = non-temporal (keeps the Infinity-Cache-resident matrix from being
+// displaced by vectors that are re-read at most once per iteration)
+typedef double femcy_d2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld2(const double2* p) {
+    if (NT) {
+        const femcy_d2v t = __builtin_nontemporal_load(reinterpret_cast<const femcy_d2v*>(p));
+        return make_double2(t.x, t.y);
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(double2* p, double2 v) {
+    if (NT) {
+        femcy_d2v t;
+        t.x = v.x;
+        t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<femcy_d2v*>(p));
+    } else {
+        *p = v;
+    }
+}
+
+template <bool NT>
 __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const double* __restrict__ part1,
                                                   const double* __restrict__ dAd_reduced, PcgState* st,
                                                   const double2* __restrict__ d, const double2* __restrict__ Ad,
@@ -269,11 +293,11 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
     const double2 z2 = make_double2(0.0, 0.0);
     double2 dv = z2, av = z2, mv = z2, xv = z2, rv = z2;
     if (i < n2) {
-        dv = d[i];
-        av = Ad[i];
-        mv = M[i];
-        xv = x[i];
-        rv = r[i];
+        dv = ld2<NT>(d + i);
+        av = ld2<NT>(Ad + i);
+        mv = ld2<NT>(M + i);
+        xv = ld2<NT>(x + i);
+        rv = ld2<NT>(r + i);
     }
     const int it = st->iters;                       // stable: written by the previous iteration's k_update_d
     if (blockIdx.x == 0 && threadIdx.x == 0) st->it_k3 = it;
@@ -285,8 +309,8 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
         xv.y = xv.y + alpha * dv.y;
         rv.x = rv.x - alpha * av.x;
         rv.y = rv.y - alpha * av.y;
-        x[i] = xv;
-        r[i] = rv;
+        st2<NT>(x + i, xv);
+        st2<NT>(r + i, rv);
         double w0 = 1.0, w1 = 1.0;
         if (owner) {
             w0 = owner[2 * i];
@@ -296,11 +320,11 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
         rm = fmax(rm, fmax(nan_to_inf_abs(rv.x), nan_to_inf_abs(rv.y)));
         i += stride;
         if (i < n2) {
-            dv = d[i];
-            av = Ad[i];
-            mv = M[i];
-            xv = x[i];
-            rv = r[i];
+            dv = ld2<NT>(d + i);
+            av = ld2<NT>(Ad + i);
+            mv = ld2<NT>(M + i);
+            xv = ld2<NT>(x + i);
+            rv = ld2<NT>(r + i);
         }
     }
     const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
@@ -311,6 +335,7 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
 }
 
 // d = M r + beta d; publish scalars and the stopping decision
+template <bool NT>
 __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const double* __restrict__ part2,
                                                  const double* __restrict__ gathered, int nranks, PcgState* st, const double2* __restrict__ r,
                                                  const double2* __restrict__ M, double2* __restrict__ d) {
@@ -321,9 +346,9 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     const double2 z2 = make_double2(0.0, 0.0);
     double2 rv = z2, mv = z2, dv = z2;
     if (i < n2) {           // first tile in flight while the scalars are reduced
-        rv = r[i];
-        mv = M[i];
-        dv = d[i];
+        rv = ld2<NT>(r + i);
+        mv = ld2<NT>(M + i);
+        dv = ld2<NT>(d + i);
     }
     double s = 0.0, m = 0.0;
     if (gathered) {
@@ -347,12 +372,12 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     while (i < n2) {
         dv.x = mv.x * rv.x + beta * dv.x;
         dv.y = mv.y * rv.y + beta * dv.y;
-        d[i] = dv;
+        st2<NT>(d + i, dv);
         i += stride;
         if (i < n2) {
-            rv = r[i];
-            mv = M[i];
-            dv = d[i];
+            rv = ld2<NT>(r + i);
+            mv = ld2<NT>(M + i);
+            dv = ld2<NT>(d + i);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -648,17 +673,23 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
                                    c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
             dAd_red = slot;
         }
-        hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red, c->d_state,
-                           (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)d_x,
-                           (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2);
+#define FEMCY_XR(NT_)                                                                                              \
+    hipLaunchKernelGGL(k_update_xr<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red, c->d_state, \
+                       (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)d_x,     \
+                       (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
+        if (c->vec_nt) FEMCY_XR(true); else FEMCY_XR(false);
+#undef FEMCY_XR
         if (multi) {
             double* pair = c->d_commbuf + c->niface_global + 2;
             hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, pair);
             if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
         }
-        hipLaunchKernelGGL(k_update_d, dim3(g), dim3(BS), 0, c->stream, n2, g, c->d_part2,
-                           (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state,
-                           (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d);
+#define FEMCY_UD(NT_)                                                                              \
+    hipLaunchKernelGGL(k_update_d<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, g, c->d_part2,         \
+                       (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state, \
+                       (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d)
+        if (c->vec_nt) FEMCY_UD(true); else FEMCY_UD(false);
+#undef FEMCY_UD
         return FEMCY_OK;
     };
 

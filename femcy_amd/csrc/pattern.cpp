@@ -60,7 +60,11 @@ void spmv_split(Ctx* c) {
     // iteration from the 256 MiB Infinity Cache and non-temporal loads cost 16 % (33.1 -> 38.4 us); a 1.55 GB
     // matrix (8 M elements) streams from HBM and non-temporal loads gain 4 % (288 -> 277 us).
     const int64_t matrix_bytes = stored_rows * SLICE * ((int64_t)c->dm * c->dm * 8 + 4);
-    c->spmv_nt = c->opt_spmv_nt < 0 ? matrix_bytes > (int64_t)256 * 1024 * 1024 : c->opt_spmv_nt != 0;
+    const bool beyond_mall = matrix_bytes > (int64_t)256 * 1024 * 1024;
+    c->spmv_nt = c->opt_spmv_nt < 0 ? beyond_mall : c->opt_spmv_nt != 0;
+    // the PCG vector kernels likewise: 44.7 -> 47.3 us per iteration at 1 M elements (vectors are re-read from the
+    // cache there), 332.8 -> 312.2 us at 8 M
+    c->vec_nt = c->opt_vec_nt < 0 ? beyond_mall : c->opt_vec_nt != 0;
     const int spb = WAVES / wps;   // slices per workgroup
     int32_t s = 0;
     c->xcd.start[0] = 0;

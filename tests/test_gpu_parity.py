@@ -318,6 +318,13 @@ def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
         it_p, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
         assert it_p == it_g and np.array_equal(ctx.download(be.VEC_X), x_g)
     ctx.set_option(be.OPT_PCG_GRAPH, 1)
+    # the streaming cache policies used beyond 256 MiB of matrix (non-temporal matrix and vector accesses) change no bit
+    ctx.set_option(102, 1)
+    ctx.set_option(103, 1)
+    it_p, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+    assert it_p == it_g and np.array_equal(ctx.download(be.VEC_X), x_g)
+    ctx.set_option(102, -1)
+    ctx.set_option(103, -1)
     # maxit honoured, poll interval irrelevant to the result
     ctx.set_option(be.OPT_PCG_POLL, 3)
     it5, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=5)
