@@ -297,6 +297,8 @@ int femcy_sync(femcy_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------- problem definition
+static void loadset_free(Ctx::LoadSet& ls);
+
 int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, int32_t ne, int32_t npe,
                    const int32_t* elems) {
     CTX_OR_FAIL(ctx);
@@ -307,7 +309,17 @@ int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, 
     for (int64_t k = 0; k < (int64_t)ne * npe; ++k)
         FEMCY_REQUIRE(elems[k] >= 0 && elems[k] < nn, "element %lld references node %d outside [0,%d)",
                       (long long)(k / npe), elems[k], nn);
+    FEMCY_REQUIRE(!c->comm, "the mesh of a context cannot change once a communicator is attached");
     FEMCY_HIP(hipStreamSynchronize(c->stream));
+    // a new mesh invalidates everything that was defined on the old one
+    for (auto& ds : c->dofsets) {
+        if (ds.d_dofs) (void)hipFree(ds.d_dofs);
+        if (ds.d_vals) (void)hipFree(ds.d_vals);
+    }
+    c->dofsets.clear();
+    for (auto& ls : c->loadsets) loadset_free(ls);
+    c->loadsets.clear();
+    c->have_material = false;
     c->nn = nn; c->dm = dm; c->ne = ne; c->npe = npe;
     c->n = (int64_t)nn * dm;
     c->h_elems.assign(elems, elems + (int64_t)ne * npe);

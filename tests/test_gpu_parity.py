@@ -363,6 +363,23 @@ def test_errors_are_reported_not_fatal(gpu_ctx_factory):
         ctx.set_mesh(np.zeros((3, 3)), np.array([[0, 1, 2, 7]]))    # node id out of range
     with pytest.raises(be.FemcyError):
         be.Context(99)
+    # a context can be re-used for another mesh: everything defined on the old one is invalidated, not left dangling
+    inp, et, el, mat = load("twist_plate_C3D4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ds = ctx.dofset(np.array([0, 1, 2], np.int32))
+    inp2, et2, el2, mat2 = load("ellip_CPS4.inp")
+    ctx.set_mesh(inp2.nodes, el2)
+    with pytest.raises(be.FemcyError):
+        ctx.dofset_fill(ds, be.VEC_DOF, 1.0)       # the old DOF list is gone
+    with pytest.raises(be.FemcyError):
+        ctx.assemble_K(-1)                          # element / material / pattern must be given again
+    ctx.set_element(inp2.ELE)
+    ctx.set_material(mat2)
+    ctx.build_pattern()
+    ctx.assemble_K(-1)
+    K = ctx.get_K_bsr().tocsr()
+    Ko = orc.assemble_K(orc.Topology(inp2.nodes, el2, elem_def(et2)), np.zeros(ctx.n), oracle_material(mat2).C)
+    assert abs(K - Ko).max() / abs(Ko).max() < 1e-12
 
 
 @pytest.mark.parametrize("name", DECKS)
