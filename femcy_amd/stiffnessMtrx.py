@@ -125,13 +125,14 @@ class System_of_equations:
         self.ctx.internal_force(be.VEC_DOF, be.VEC_TMP0)      # F and sigma are by-products of the element pass
 
     # ------------------------------------------------------------------------ linear solve
-    def solve_by_CG(self, eps=None):
+    def solve_by_CG(self, eps=None, maxit=None):
         if not hasattr(self, "PCG"):
             b = self.rhs if not self.geometric_nonlinear else self.residual_nodal_force
             self.PCG = CG(spm=self.sparseMtrx_rowMajor, sparseIJ=self.sparseIJ, b=b, eps=self.cg_eps)
         self.PCG.eps = self.cg_eps if eps is None else eps
         self.PCG.re_init()
-        it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps, maxit=self.PCG.maxit)
+        it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps,
+                                    maxit=self.PCG.maxit if maxit is None else maxit)
         self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
         self.stats["linear_solves"] += 1
         self.stats["cg_iterations"] += it
@@ -144,7 +145,9 @@ class System_of_equations:
 
     def solve_by_scipy(self):
         """name kept for compatibility: the "direct" branch is a tight device PCG (module docstring)."""
-        return self.solve_by_CG(eps=self.direct_eps)
+        # standing in for a direct solve: CG in floating point can need more than n iterations on an ill-conditioned
+        # K (nu -> 0.5), so the cap is 10 n here instead of the reference CG's n
+        return self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
 
     def solve_dof(self):
         if self.n_system < 1e5:                        # DOFs of the whole system (all ranks take the same branch)

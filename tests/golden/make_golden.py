@@ -28,6 +28,12 @@ SOLVE_DECKS = [
     "cookMembrane_2d_linearEl_smallDef.inp", "beam_CPS3_disp_meshSize5.inp", "cook_3d_linearEl_largeDef.inp",
     "beamDeflec_quadPSE_largeD_load800.inp", "twist_plate_C3D4.inp", "twist_C3D10_coarse.inp",
     "cookMembrane_2d_linearEl_largeDef.inp",
+    # second batch of reference decks (tests/golden/decks/SOURCES.md): quadratic plane-strain triangles (CPE6), large
+    # deformation at two load levels, nu = 0.4999, a free-end traction beam, the fixX beam variant, the densest
+    # linear CPS6 deck (29 252 DOF) and a small-deformation C3D10 deck with a surface load
+    "cookMembrane_CPE6_largeDef.inp", "cookMembrane_CPE6_largeDef_5MPa.inp", "cookMembrane_CPE6_smallDef_nu0d4999.inp",
+    "beamFreeDeflect_CPS6_load_mesh4.inp", "beamDeflec_quadPSE_largeD_load800_fixX.inp", "ellip_dense_CPS6_0d04.inp",
+    "cook_3d_quadEl_smallDef.inp",
     # generated decks (femcy_amd.meshgen.beam_quad8, written by write_generated_decks() below):
     # BASELINE configs[1] asks for a CPE8 large-deformation beam, which the reference does not ship
     "gen_beam_CPE8_tip4.inp",       # plane strain StVK, 20 x 2 quad8, converges in 4 increments

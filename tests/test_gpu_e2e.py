@@ -24,6 +24,13 @@ CASES = [  # (deck, tolerance)
     ("twist_plate_C3D4", 1e-6),                           # 180 degree twist, user Dirichlet BC, 186 solves
     ("cookMembrane_2d_linearEl_largeDef", 1e-6),          # CPE3 plane strain large deformation, 670 solves
     ("twist_C3D10_coarse", 1e-6),                         # C3D10 twist (BASELINE configs[4] element), 1184 solves
+    ("cookMembrane_CPE6_largeDef", 1e-6),                 # CPE6 plane strain large deformation, 190 solves
+    ("cookMembrane_CPE6_largeDef_5MPa", 1e-6),            # same at a higher load: 213 solves
+    ("cookMembrane_CPE6_smallDef_nu0d4999", 1e-6),        # nearly incompressible (nu = 0.4999), linear
+    ("beamFreeDeflect_CPS6_load_mesh4", 1e-6),            # free-end traction, 68 solves
+    ("beamDeflec_quadPSE_largeD_load800_fixX", 1e-6),     # fixX variant of the load-800 beam
+    ("ellip_dense_CPS6_0d04", 1e-6),                      # densest linear deck of the reference: 29 252 DOF
+    ("cook_3d_quadEl_smallDef", 1e-6),                    # C3D10 small deformation with a surface load
     ("gen_beam_CPE8_tip4", 1e-6),                         # BASELINE configs[1] stand-in: CPE8 large deformation
     ("gen_beam_CPS8_tip8", 1e-6),                         # CPS8 with 3 increment cut-backs (dt/4 + restore)
 ]

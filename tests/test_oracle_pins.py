@@ -220,7 +220,9 @@ def test_pcg_reference_solves_and_counts():
 FAST = ["ellip_membrane_linEle_localVeryFine", "ellip_membrane_quadritic_trig_neumann", "ellip_CPS4", "ellip_CPS8",
         "ellip_membrane_3d_linearEl", "ellip_membrane_3d", "ellip_membrane_localFine_dirichlet",
         "ellip_localVeryFine_directional_force", "cookMembrane_2d_linearEl_smallDef", "beam_CPS3_disp_meshSize5",
-        "cook_3d_linearEl_largeDef", "gen_beam_CPE8_tip4", "gen_beam_CPS8_tip8"]
+        "cook_3d_linearEl_largeDef", "gen_beam_CPE8_tip4", "gen_beam_CPS8_tip8",
+        "cookMembrane_CPE6_smallDef_nu0d4999", "beamFreeDeflect_CPS6_load_mesh4", "ellip_dense_CPS6_0d04",
+        "cook_3d_quadEl_smallDef"]
 
 
 @pytest.mark.parametrize("name", FAST)
