@@ -50,6 +50,7 @@ struct PcgState {
     double r0;       // max|r0|
     double rmax;     // max|r| after the last completed iteration
     double dAd;      // multi-rank: reduced d.Ad
+    double alpha;    // step length of the running iteration (k_update_xr -> k_update_d)
     double eps;      // stopping tolerance of this solve (kept on the device so that kernel arguments are
                      // solve-independent and a burst of iterations can be replayed from a hipGraph)
     int32_t iters;   // completed iterations (written by k_update_d, read by k_update_xr of the next iteration)

@@ -278,11 +278,13 @@ __device__ __forceinline__ void st2(double2* p, double2 v) {
     }
 }
 
+// r -= alpha Ad with alpha = r.M.r / d.Ad, partials of (r.M.r, max|r|) of the new r; alpha is published for k_update_d,
+// which applies x += alpha d in the pass where it reads d anyway (x would otherwise be the only reason for this
+// kernel to load d: 8 n bytes per iteration)
 template <bool NT>
 __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const double* __restrict__ part1,
                                                   const double* __restrict__ dAd_reduced, PcgState* st,
-                                                  const double2* __restrict__ d, const double2* __restrict__ Ad,
-                                                  const double2* __restrict__ M, double2* __restrict__ x,
+                                                  const double2* __restrict__ Ad, const double2* __restrict__ M,
                                                   double2* __restrict__ r, const uint8_t* __restrict__ owner,
                                                   double* __restrict__ part2) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
@@ -291,25 +293,23 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
     int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * BS;
     const double2 z2 = make_double2(0.0, 0.0);
-    double2 dv = z2, av = z2, mv = z2, xv = z2, rv = z2;
+    double2 av = z2, mv = z2, rv = z2;
     if (i < n2) {
-        dv = ld2<NT>(d + i);
         av = ld2<NT>(Ad + i);
         mv = ld2<NT>(M + i);
-        xv = ld2<NT>(x + i);
         rv = ld2<NT>(r + i);
     }
     const int it = st->iters;                       // stable: written by the previous iteration's k_update_d
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->it_k3 = it;
     const double dAd = dAd_reduced ? *dAd_reduced : reduce_partials_sum(part1, np1, sm1);
     const double alpha = st->rMr[it & 1] / dAd;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->it_k3 = it;
+        st->alpha = alpha;
+    }
     double rMr = 0.0, rm = 0.0;
     while (i < n2) {
-        xv.x = xv.x + alpha * dv.x;
-        xv.y = xv.y + alpha * dv.y;
         rv.x = rv.x - alpha * av.x;
         rv.y = rv.y - alpha * av.y;
-        st2<NT>(x + i, xv);
         st2<NT>(r + i, rv);
         double w0 = 1.0, w1 = 1.0;
         if (owner) {
@@ -320,10 +320,8 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
         rm = fmax(rm, fmax(nan_to_inf_abs(rv.x), nan_to_inf_abs(rv.y)));
         i += stride;
         if (i < n2) {
-            dv = ld2<NT>(d + i);
             av = ld2<NT>(Ad + i);
             mv = ld2<NT>(M + i);
-            xv = ld2<NT>(x + i);
             rv = ld2<NT>(r + i);
         }
     }
@@ -334,21 +332,23 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
     }
 }
 
-// d = M r + beta d; publish scalars and the stopping decision
+// x += alpha d (this iteration's alpha, old d), then d = M r + beta d; publish scalars and the stopping decision
 template <bool NT>
 __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const double* __restrict__ part2,
                                                  const double* __restrict__ gathered, int nranks, PcgState* st, const double2* __restrict__ r,
-                                                 const double2* __restrict__ M, double2* __restrict__ d) {
+                                                 const double2* __restrict__ M, double2* __restrict__ d,
+                                                 double2* __restrict__ x) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->done) return;
     int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * BS;
     const double2 z2 = make_double2(0.0, 0.0);
-    double2 rv = z2, mv = z2, dv = z2;
+    double2 rv = z2, mv = z2, dv = z2, xv = z2;
     if (i < n2) {           // first tile in flight while the scalars are reduced
         rv = ld2<NT>(r + i);
         mv = ld2<NT>(M + i);
         dv = ld2<NT>(d + i);
+        xv = ld2<NT>(x + i);
     }
     double s = 0.0, m = 0.0;
     if (gathered) {
@@ -365,19 +365,24 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     const double rMr_new = block_sum(s, sm1);
     const double rmax = block_max(m, sm2);
     const int it = st->it_k3;                       // stable: written by this iteration's k_update_xr
+    const double alpha = st->alpha;                 // likewise
     const double eps = st->eps;
     const double rMr_old = st->rMr[it & 1];
     const double r0 = st->r0;
     const double beta = rMr_new / rMr_old;
     while (i < n2) {
+        xv.x = xv.x + alpha * dv.x;
+        xv.y = xv.y + alpha * dv.y;
         dv.x = mv.x * rv.x + beta * dv.x;
         dv.y = mv.y * rv.y + beta * dv.y;
+        st2<NT>(x + i, xv);
         st2<NT>(d + i, dv);
         i += stride;
         if (i < n2) {
             rv = ld2<NT>(r + i);
             mv = ld2<NT>(M + i);
             dv = ld2<NT>(d + i);
+            xv = ld2<NT>(x + i);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -675,8 +680,8 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         }
 #define FEMCY_XR(NT_)                                                                                              \
     hipLaunchKernelGGL(k_update_xr<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red, c->d_state, \
-                       (const double2*)c->d_d, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)d_x,     \
-                       (double2*)c->d_r, (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
+                       (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                            \
+                       (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
         if (c->vec_nt) FEMCY_XR(true); else FEMCY_XR(false);
 #undef FEMCY_XR
         if (multi) {
@@ -687,7 +692,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
 #define FEMCY_UD(NT_)                                                                              \
     hipLaunchKernelGGL(k_update_d<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, g, c->d_part2,         \
                        (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state, \
-                       (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d)
+                       (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d, (double2*)d_x)
         if (c->vec_nt) FEMCY_UD(true); else FEMCY_UD(false);
 #undef FEMCY_UD
         return FEMCY_OK;
