@@ -1,12 +1,13 @@
-"""element plugins: same class names as the reference's element_zoo/__init__.py:3-8."""
-from .element_base import ElementBase, VOIGT_2D, VOIGT_3D
-from .element_linear_quadrilateral import Element_linear_quadrilateral
-from .element_linear_tetrahedral import Element_linear_tetrahedral
-from .element_linear_triangular import Element_linear_triangular
-from .element_quadratic_quadrilateral import Element_quadratic_quadrilateral
-from .element_quadratic_tetrahedral import Element_quadratic_tetrahedral
-from .element_quadratic_triangular import Element_quadratic_triangular
+"""element plugins.  The package exposes the class names the reference's element_zoo exposes
+(element_zoo/__init__.py:3-8) -- `Element_<order>_<shape>`, one module each -- plus the plugin base class."""
+from importlib import import_module
 
-__all__ = ["ElementBase", "VOIGT_2D", "VOIGT_3D", "Element_linear_quadrilateral",
-           "Element_linear_tetrahedral", "Element_linear_triangular", "Element_quadratic_quadrilateral",
-           "Element_quadratic_tetrahedral", "Element_quadratic_triangular"]
+from .element_base import ElementBase, VOIGT_2D, VOIGT_3D
+
+__all__ = ["ElementBase", "VOIGT_2D", "VOIGT_3D"]
+for _order in ("linear", "quadratic"):
+    for _shape in ("triangular", "quadrilateral", "tetrahedral"):
+        _name = f"Element_{_order}_{_shape}"
+        globals()[_name] = getattr(import_module(f"{__name__}.{_name.lower()}"), _name)
+        __all__.append(_name)
+del _order, _shape, _name
