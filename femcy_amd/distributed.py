@@ -37,7 +37,7 @@ def init_process_group():
     return rank, nranks, local, box[0]
 
 
-def partitioned_system(inp, material, verbose=True):
+def partitioned_system(inp, material, verbose=True, tangent="reference"):
     """-> (system, local deck, part): this rank's share of the deck, ready for `system.solve(local_deck)`."""
     from .stiffnessMtrx import System_of_equations
     rank, nranks, local, uid = init_process_group()
@@ -46,7 +46,7 @@ def partitioned_system(inp, material, verbose=True):
     part = partition.build_part(inp.nodes, el, nranks, rank, axis=axis)
     body = Body(part.nodes, part.elements, inp.ELE)
     system = System_of_equations(body, material, inp.geometric_nonlinear, device=local, verbose=verbose, part=part,
-                                 comm_uid=uid)
+                                 comm_uid=uid, tangent=tangent)
     return system, partition.LocalDeck(inp, part, body), part
 
 

@@ -17,15 +17,16 @@ from .stiffnessMtrx import System_of_equations
 from .tiGadgets import field_abs_max
 
 
-def run(fileName: str, device: int = 0, verbose: bool = True):
+def run(fileName: str, device: int = 0, verbose: bool = True, tangent: str = "reference"):
     from . import distributed
     inp = InpInfo(fileName)
     nodes, eSets = inp.nodes, inp.eSets
     material = list(inp.materials.values())[0]
     if distributed.wanted():       # launched by torch.distributed.run: one rank per GPU, one element partition each
-        return run_partitioned(inp, material, verbose)
+        return run_partitioned(inp, material, verbose, tangent)
     body = Body(nodes=nodes, elements=list(eSets.values())[0], ELE=inp.ELE)
-    system = System_of_equations(body, material, inp.geometric_nonlinear, device=device, verbose=verbose)
+    system = System_of_equations(body, material, inp.geometric_nonlinear, device=device, verbose=verbose,
+                                 tangent=tangent)
     time0 = time.time()
     system.solve(inp, show_newton_steps=True, save2path=None)
     system.ctx.sync()
@@ -44,11 +45,11 @@ def run(fileName: str, device: int = 0, verbose: bool = True):
     return inp, system
 
 
-def run_partitioned(inp, material, verbose: bool = True):
+def run_partitioned(inp, material, verbose: bool = True, tangent: str = "reference"):
     """the same solve with the mesh split by element over the ranks of the job (femcy_amd/distributed.py).
     Rank 0 prints; `system.dof_global` holds the gathered displacements there (None on other ranks)."""
     from . import distributed
-    system, local_deck, part = distributed.partitioned_system(inp, material, verbose)
+    system, local_deck, part = distributed.partitioned_system(inp, material, verbose, tangent)
     say = print if part.rank == 0 else (lambda *a, **k: None)
     time0 = time.time()
     system.solve(local_deck, show_newton_steps=True, save2path=None)
@@ -73,9 +74,12 @@ def main(argv=None):
     ap.add_argument("--save", default=None, help="write results to this .npz, a legacy .vtk (mesh + displacement + Mises) for ParaView, or a .png picture of the deformed mesh coloured by von Mises stress")
     ap.add_argument("--device", type=int, default=int(os.environ.get("FEMCY_DEVICE", "0")))
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--tangent", choices=("reference", "consistent"), default="reference",
+                    help="matrix of the Newton iterations: the reference's B^T C B with the constant C (default; parity "
+                         "with FEMcy), or the consistent tangent (extension: far fewer linear solves, different iterates)")
     args = ap.parse_args(argv)
     fileName = args.inp or input("\033[32;1m please give the .inp format's input file path and name: \033[0m")
-    inp, system = run(fileName, device=args.device, verbose=not args.quiet)
+    inp, system = run(fileName, device=args.device, verbose=not args.quiet, tangent=args.tangent)
     if getattr(system, "part", None) is not None:
         if args.save and system.part.rank == 0:
             np.savez(args.save, nodes=inp.nodes, dof=system.dof_global)
