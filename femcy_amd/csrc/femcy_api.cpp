@@ -371,8 +371,9 @@ int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C, const doub
     FEMCY_REQUIRE(c->have_mesh, "femcy_set_mesh must come first");
     FEMCY_REQUIRE(C, "null C");
     FEMCY_REQUIRE(kind >= FEMCY_MAT_LIN3D && kind <= FEMCY_MAT_NEOHOOKE, "unknown material kind %d", kind);
-    const bool is3d = (kind == FEMCY_MAT_LIN3D || kind == FEMCY_MAT_NEOHOOKE);
-    FEMCY_REQUIRE(is3d == (c->dm == 3), "material kind %d does not match dm=%d", kind, c->dm);
+    // neo-Hookean exists for dm = 3 (the reference's) and, as an extension, for dm = 2 (plane strain)
+    const bool ok_dm = kind == FEMCY_MAT_NEOHOOKE || ((kind == FEMCY_MAT_LIN3D) == (c->dm == 3));
+    FEMCY_REQUIRE(ok_dm, "material kind %d does not match dm=%d", kind, c->dm);
     FEMCY_REQUIRE(nparams >= 2 && params, "material needs 2 parameters");
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     const int s = (c->dm == 2) ? 3 : 6;

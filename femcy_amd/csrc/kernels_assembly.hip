@@ -133,7 +133,19 @@ __device__ __forceinline__ void cauchy_large<3>(int kind, const double* __restri
 template <>
 __device__ __forceinline__ void cauchy_large<2>(int kind, const double* __restrict__ C, double p0, double p1,
                                                 const double (&F)[2][2], double (&sig)[2][2]) {
-    if (kind == FEMCY_MAT_PSTRESS) {
+    if (kind == FEMCY_MAT_NEOHOOKE) {
+        // plane-strain neo-Hookean (extension: the reference has the 3-D form only, neo_hookean.py:66-77, and its
+        // reader rejects it on 2-D elements): F33 = 1, so the in-plane part of the 3-D expression with J = det F
+        const double J = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double B = F[i][0] * F[j][0] + F[i][1] * F[j][1];
+                const double eye = (i == j) ? 1.0 : 0.0;
+                sig[i][j] = 2.0 * p0 / J * (B - eye) + 2.0 * p1 * (J - 1.0) * eye;
+            }
+    } else if (kind == FEMCY_MAT_PSTRESS) {
         // F embedded in 3-D with F33 = 1 - nu/(1-nu) (F00 + F11 - 2); uses C_6x6, not ddsdde
         const double E = p0, nu = p1;
         double F3[3][3] = {{F[0][0], F[0][1], 0.0}, {F[1][0], F[1][1], 0.0}, {0.0, 0.0, 0.0}};
@@ -715,7 +727,9 @@ __device__ __forceinline__ void cauchy_small<3>(int kind, const double* __restri
 template <>
 __device__ __forceinline__ void cauchy_small<2>(int kind, const double* __restrict__ C, double p0, double p1,
                                                 const double (&F)[2][2], double (&sig)[2][2]) {
-    if (kind == FEMCY_MAT_PSTRESS) {
+    if (kind == FEMCY_MAT_NEOHOOKE) {
+        cauchy_large<2>(kind, C, p0, p1, F, sig);   // as in 3-D: the same expression for small and large deformation
+    } else if (kind == FEMCY_MAT_PSTRESS) {
         const double E_ = p0, nu = p1;
         const double F33 = -nu / (1.0 - nu) * (F[0][0] + F[1][1] - 2.0) + 1.0;   // E33 = F33 - 1 multiplies zeros of C_6x6
         (void)F33;
@@ -764,6 +778,7 @@ __device__ __forceinline__ double energy_density(int kind, const double* __restr
 #pragma unroll
         for (int j = 0; j < DM; ++j) F3[i][j] = F[i][j];
     if (kind == FEMCY_MAT_NEOHOOKE) {
+        if (DM == 2) F3[2][2] = 1.0;                 // plane strain
         const double J = det3(F3);
         double trB = 0.0;
 #pragma unroll
@@ -837,6 +852,8 @@ __global__ void __launch_bounds__(256) k_post(int64_t ngp, int large, int kind, 
 #pragma unroll
         for (int j = 0; j < DM; ++j) s3[i][j] = sig[i][j];
     if (kind == FEMCY_MAT_PSTRAIN) s3[2][2] = p1 * (sig[0][0] + sig[1][1]);   // nu (s_xx + s_yy) (:475-489)
+    if (DM == 2 && kind == FEMCY_MAT_NEOHOOKE)      // plane-strain neo-Hookean: b33 = 1 leaves the volumetric part
+        s3[2][2] = 2.0 * p1 * (F[0][0] * F[1][1] - F[0][1] * F[1][0] - 1.0);
     const double tr = (s3[0][0] + s3[1][1] + s3[2][2]) / 3.0;
     double ss = 0.0;
 #pragma unroll

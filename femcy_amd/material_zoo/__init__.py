@@ -12,3 +12,5 @@ for _name in ("LinearIsotropic", "LinearIsotropicPlaneStrain", "LinearIsotropicP
     globals()[_name] = getattr(import_module(f"{__name__}.{_module}"), _name)
     __all__.append(_name)
 del _name, _module
+from .neo_hookean import NeoHookeanPlaneStrain          # extension (no counterpart in the reference)
+__all__.append("NeoHookeanPlaneStrain")
