@@ -17,9 +17,10 @@ from .stiffnessMtrx import System_of_equations
 from .tiGadgets import field_abs_max
 
 
-def run(fileName: str, device: int = 0, verbose: bool = True, tangent: str = "reference"):
+def run(fileName: str, device: int = 0, verbose: bool = True, tangent: str = "reference",
+        allow_2d_hyperelastic: bool = False):
     from . import distributed
-    inp = InpInfo(fileName)
+    inp = InpInfo(fileName, allow_2d_hyperelastic=allow_2d_hyperelastic)
     nodes, eSets = inp.nodes, inp.eSets
     material = list(inp.materials.values())[0]
     if distributed.wanted():       # launched by torch.distributed.run: one rank per GPU, one element partition each
@@ -74,12 +75,16 @@ def main(argv=None):
     ap.add_argument("--save", default=None, help="write results to this .npz, a legacy .vtk (mesh + displacement + Mises) for ParaView, or a .png picture of the deformed mesh coloured by von Mises stress")
     ap.add_argument("--device", type=int, default=int(os.environ.get("FEMCY_DEVICE", "0")))
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--allow-2d-neo-hookean", action="store_true",
+                    help="accept *Hyperelastic, neo hooke on CPE elements (plane-strain extension; the reference "
+                         "rejects it)")
     ap.add_argument("--tangent", choices=("reference", "consistent"), default="reference",
                     help="matrix of the Newton iterations: the reference's B^T C B with the constant C (default; parity "
                          "with FEMcy), or the consistent tangent (extension: far fewer linear solves, different iterates)")
     args = ap.parse_args(argv)
     fileName = args.inp or input("\033[32;1m please give the .inp format's input file path and name: \033[0m")
-    inp, system = run(fileName, device=args.device, verbose=not args.quiet, tangent=args.tangent)
+    inp, system = run(fileName, device=args.device, verbose=not args.quiet, tangent=args.tangent,
+                      allow_2d_hyperelastic=args.allow_2d_neo_hookean)
     if getattr(system, "part", None) is not None:
         if args.save and system.part.rank == 0:
             np.savez(args.save, nodes=inp.nodes, dof=system.dof_global)

@@ -166,7 +166,11 @@ def write_inp(path: str, mesh: Dict, part: str = "Part-1"):
             ids1 = (np.asarray(ids) + 1).tolist()
             for s in range(0, len(ids1), 16):
                 f.write(", ".join(str(v) for v in ids1[s:s + 16]) + "\n")
-        f.write("*End Assembly\n*Material, name=Material-1\n*Elastic\n%.17g, %.17g\n" % mesh["elastic"])
+        if "neo_hookean" in mesh:      # (C1, D1): Abaqus writes C10 and the inverse of D1 (reader: D1 = 1 / value)
+            c1, d1 = mesh["neo_hookean"]
+            f.write("*End Assembly\n*Material, name=Material-1\n*Hyperelastic, neo hooke\n%.17g, %.17g\n" % (c1, 1. / d1))
+        else:
+            f.write("*End Assembly\n*Material, name=Material-1\n*Elastic\n%.17g, %.17g\n" % mesh["elastic"])
         f.write("*Step, name=Step-1, nlgeom=%s\n*Static\n" % ("YES" if mesh["geometric_nonlinear"] else "NO"))
         t = mesh["time_incs"]
         f.write("%.17g, %.17g, %.17g, %.17g\n" % (t["ini_inc"], t["max_time"], t["min_inc"], t["max_inc"]))

@@ -108,7 +108,11 @@ def _is_comment(line):
 
 class InpInfo(InpInfoBase):
 
-    def __init__(self, file) -> None:
+    def __init__(self, file, allow_2d_hyperelastic: bool = False) -> None:
+        """allow_2d_hyperelastic: accept `*Hyperelastic, neo hooke` on CPE elements (plane-strain neo-Hookean, an
+        extension of this build).  Off by default: the reference rejects any non-`*Elastic` material on 2-D elements
+        (:296-299) and so does this reader."""
+        self.allow_2d_hyperelastic = allow_2d_hyperelastic
         self.nodes, self.eSets = self.read_node_element(file)
         self.node_sets, self.ele_sets = self.read_set(file)
         self.face_sets = self.read_face_set(file)
@@ -268,7 +272,10 @@ class InpInfo(InpInfoBase):
         family = ele_type[0:3]
         materials = {}
         for key, vals in raw.items():
-            if family in ("CPS", "CPE"):
+            if family == "CPE" and "neo hooke" in key and getattr(self, "allow_2d_hyperelastic", False):
+                from ..material_zoo import NeoHookeanPlaneStrain
+                materials[key] = NeoHookeanPlaneStrain(C1=vals[0], D1=1. / vals[1])
+            elif family in ("CPS", "CPE"):
                 if key != "Elastic":
                     raise ValueError("only support linear elastic material for 2d element now.")
                 cls = LinearIsotropicPlaneStress if family == "CPS" else LinearIsotropicPlaneStrain

@@ -127,6 +127,12 @@ def test_reader_quirks(tmp_path):
     p.write_text(base.replace("*Elastic", "*Hyperelastic, neo hooke"))
     with pytest.raises(ValueError):
         InpInfo(str(p))
+    # ... unless the plane-strain neo-Hookean extension is asked for, and then only on CPE
+    with pytest.raises(ValueError):
+        InpInfo(str(p), allow_2d_hyperelastic=True)                   # this deck is CPS3
+    p.write_text(base.replace("*Elastic", "*Hyperelastic, neo hooke").replace("type=CPS3", "type=CPE3"))
+    m, = InpInfo(str(p), allow_2d_hyperelastic=True).materials.values()
+    assert type(m).__name__ == "NeoHookeanPlaneStrain" and m.dm == 2 and m.C.shape == (3, 3)
     # generate expands start, stop, step inclusively
     p.write_text(base.replace("*End Assembly", "*Nset, nset=gen, instance=x, generate\n 3, 9, 3\n*End Assembly"))
     assert InpInfo(str(p)).node_sets["gen"].tolist() == [2, 5, 8]
