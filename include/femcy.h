@@ -34,7 +34,7 @@ enum femcy_status {
     FEMCY_EHIP = -2,       /* a HIP runtime call failed */
     FEMCY_ENOKERNEL = -3,  /* no kernel instantiation for this (npe, dm, nGP) / material */
     FEMCY_ENUMERIC = -4,   /* NaN/breakdown detected by a solver */
-    FEMCY_ECOMM = -5,      /* RCCL failure */
+    FEMCY_ECOMM = -5,      /* RCCL failure / a rendezvous of the in-process group that did not complete */
     FEMCY_ENOMEM = -6
 };
 
@@ -61,7 +61,8 @@ enum femcy_material {
     FEMCY_MAT_LIN3D = 0,    /* linear_isotropic.py            params = {E, nu}  */
     FEMCY_MAT_PSTRAIN = 1,  /* linear_isotropic_plane_strain  params = {E, nu}  */
     FEMCY_MAT_PSTRESS = 2,  /* linear_isotropic_plane_stress  params = {E, nu}  */
-    FEMCY_MAT_NEOHOOKE = 3  /* neo_hookean.py                 params = {C1, D1} */
+    FEMCY_MAT_NEOHOOKE = 3  /* neo_hookean.py                 params = {C1, D1}; with dm = 2: plane strain
+                               (extension, the reference has the 3-D form only)                          */
 };
 
 /* Gauss-point fields that can be downloaded for checking (stiffnessMtrx.py:40-61) */
@@ -134,7 +135,8 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value);
 int femcy_sync(femcy_ctx* ctx);                                   /* hipStreamSynchronize */
 
 /* ----------------------------------------------------------------------- problem definition */
-/* Body + System_of_equations.__init__ state (body.py:13-17, stiffnessMtrx.py:26-121) */
+/* Body + System_of_equations.__init__ state (body.py:13-17, stiffnessMtrx.py:26-121).  Calling it again on a used
+ * ctx starts over: element tables, material, pattern, DOF lists and load sets of the old mesh are dropped. */
 int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes /*[nn*dm]*/,
                    int32_t ne, int32_t npe, const int32_t* elems /*[ne*npe]*/);
 /* table-driven element plugin: ELE.gaussPoints/gaussWeights/dshape_dnat (element_zoo modules) */
@@ -162,7 +164,8 @@ int femcy_vec_norm(femcy_ctx* ctx, int vec, double* rms);                  /* ti
 int femcy_vec_absmax(femcy_ctx* ctx, int vec, double* out);                /* tiGadgets.py:19-25    */
 
 /* --------------------------------------------------------------------------- the hot path */
-/* get_dsdx_and_vol + assemble_stiffnessMtrx (stiffnessMtrx.py:132-150, 161-186) at x = X + vec[u] */
+/* get_dsdx_and_vol + assemble_stiffnessMtrx (stiffnessMtrx.py:132-150, 161-186) at x = X + vec[u];
+ * u_vec = -1: the undeformed configuration (u = 0) */
 int femcy_assemble_K(femcy_ctx* ctx, int u_vec);
 /* assemble_nodal_force_GN (stiffnessMtrx.py:609-644): F (ref. config), sigma(F), dsdx/vol (current
  * config), node-parallel gather of dsdx . sigma * vol */
