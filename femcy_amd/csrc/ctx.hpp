@@ -125,6 +125,7 @@ struct Ctx {
     double* d_strain = nullptr;
     double* d_mises = nullptr;
     double* d_energy = nullptr;
+    double* d_fe = nullptr;           // [ne][npe][dm] per-element nodal forces of the last femcy_internal_force
 
     // ---- vectors
     double* d_vec[FEMCY_VEC_COUNT] = {nullptr};
@@ -197,7 +198,8 @@ void timing_collect(Ctx* c);
 int build_pattern(Ctx* c);
 void spmv_split(Ctx* c);
 // kernels_*.hip (host launchers)
-int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom = true, bool write_sigma = true);
+int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom = true, bool write_sigma = true,
+                bool write_fe = false);
 int launch_post(Ctx* c, int large);
 int launch_energy(Ctx* c);
 int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int width, int comp, double* d_out);

@@ -187,7 +187,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
     dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
-    dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy);
+    dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
     for (auto& v : c->d_vec) dev_free(&v);
     dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad);
     dev_free(&c->d_part1); dev_free(&c->d_part2); dev_free(&c->d_state);
@@ -360,6 +360,7 @@ int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN, const doubl
     if ((rc = dev_alloc(&c->d_dsdx, ngp * c->npe * c->dm)) || (rc = dev_alloc(&c->d_vol, ngp)) ||
         (rc = dev_alloc(&c->d_F, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_sigma, ngp * c->dm * c->dm)) ||
         (rc = dev_alloc(&c->d_strain, ngp * c->dm * c->dm)) || (rc = dev_alloc(&c->d_mises, ngp)) ||
+        (rc = dev_alloc(&c->d_fe, (size_t)c->ne * c->npe * c->dm)) ||
         (rc = dev_alloc(&c->d_energy, ngp)))
         return rc;
     c->have_element = true;
@@ -513,7 +514,7 @@ int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec) {
     READY_OR_FAIL();
     VEC_OR_FAIL(u_vec);
     VEC_OR_FAIL(f_vec);
-    int rc = launch_geom(c, c->d_vec[u_vec], true);
+    int rc = launch_geom(c, c->d_vec[u_vec], true, true, true, true);
     if (rc) return rc;
     if ((rc = launch_nodal_force(c, c->d_vec[f_vec]))) return rc;
     return iface_sum(c, c->d_vec[f_vec]);      // multi-rank: forces of the elements other ranks hold (no-op otherwise)

@@ -195,10 +195,20 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                                               const double* __restrict__ dN, const double* __restrict__ w,
                                               int mat_kind, const double* __restrict__ C, double p0, double p1,
                                               double* __restrict__ dsdx, double* __restrict__ vol,
-                                              double* __restrict__ Fout, double* __restrict__ Sout) {
+                                              double* __restrict__ Fout, double* __restrict__ Sout,
+                                              double* __restrict__ fe) {
     const int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ne) return;
     double X[NPE][DM], U[NPE][DM];
+    // per-element nodal forces fe[a][:] = sum_g gradN_a . sigma * vol (internal force only): the node gather then
+    // reads dm doubles per incident element instead of a gradient row, a stress tensor and a weight
+    double facc[STRESS ? NPE : 1][DM];
+    if (STRESS) {
+#pragma unroll
+        for (int a = 0; a < NPE; ++a)
+#pragma unroll
+            for (int i = 0; i < DM; ++i) facc[a][i] = 0.0;
+    }
 #pragma unroll
     for (int a = 0; a < NPE; ++a) {
         const int32_t nd = elems[(int64_t)e * NPE + a];
@@ -280,8 +290,36 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                 for (int i = 0; i < DM; ++i)
 #pragma unroll
                     for (int j = 0; j < DM; ++j) so[i * DM + j] = sig[i][j];
+                if (fe) {
+                    const double vg = det * w[g];
+#pragma unroll
+                    for (int a = 0; a < NPE; ++a) {
+                        double ga[DM];
+#pragma unroll
+                        for (int j = 0; j < DM; ++j) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int k = 0; k < DM; ++k) acc += dNg[a * DM + k] * inv[k][j];
+                            ga[j] = acc;
+                        }
+#pragma unroll
+                        for (int i = 0; i < DM; ++i) {
+                            double d = 0.0;
+#pragma unroll
+                            for (int j = 0; j < DM; ++j) d += ga[j] * sig[j][i];
+                            facc[STRESS ? a : 0][i] += d * vg;
+                        }
+                    }
+                }
             }
         }
+    }
+    if (STRESS && fe) {
+        double* out = fe + (int64_t)e * NPE * DM;
+#pragma unroll
+        for (int a = 0; a < NPE; ++a)
+#pragma unroll
+            for (int i = 0; i < DM; ++i) out[a * DM + i] = facc[STRESS ? a : 0][i];
     }
 }
 
@@ -597,15 +635,14 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
 
 // ----------------------------------------------------------------------------- nodal force gather
 // assemble_nodal_force_GN_kernel (stiffnessMtrx.py:620-644) is node-parallel with a serial loop over the padded
-// nodeEles row.  Here half a wavefront (32 lanes) owns a node and the lanes are its incident elements, so the
-// ~24 dependent (code -> dsdx row, sigma, vol) load chains of a row run side by side instead of one after the
-// other; the dm partial sums are combined by a fixed xor-shuffle tree (deterministic) and lane 0 stores.
+// nodeEles row that reads a gradient row, a stress tensor and a weight per (element, Gauss point).  Here the element
+// pass (k_geom) leaves fe[e][a][:] = sum_g gradN_a . sigma * vol, half a wavefront (32 lanes) owns a node and the lanes
+// are its incident elements: one dm-double load each, side by side instead of ~24 dependent load chains one after
+// the other; the dm partial sums are combined by a fixed xor-shuffle tree (deterministic) and lane 0 stores.
 template <int DM>
-__global__ void __launch_bounds__(256) k_nodal_force(int32_t nn, int32_t npe, int32_t nGP,
-                                                     const int32_t* __restrict__ ne_ptr,
+__global__ void __launch_bounds__(256) k_nodal_force(int32_t nn, const int32_t* __restrict__ ne_ptr,
                                                      const int32_t* __restrict__ ne_idx,
-                                                     const double* __restrict__ dsdx, const double* __restrict__ sigma,
-                                                     const double* __restrict__ vol, double* __restrict__ f) {
+                                                     const double* __restrict__ fe, double* __restrict__ f) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t a = (int32_t)(t >> 5);
     const int sub = (int)(t & 31);
@@ -615,21 +652,9 @@ __global__ void __launch_bounds__(256) k_nodal_force(int32_t nn, int32_t npe, in
     if (a < nn) {
         const int32_t k1 = ne_ptr[a + 1];
         for (int32_t k = ne_ptr[a] + sub; k < k1; k += 32) {
-            const int32_t code = ne_idx[k];
-            const int64_t e = code / npe;
-            const int32_t la = code % npe;
-            for (int g = 0; g < nGP; ++g) {
-                const double* __restrict__ gr = dsdx + ((e * nGP + g) * npe + la) * DM;
-                const double* __restrict__ sg = sigma + (e * nGP + g) * DM * DM;
-                const double v = vol[e * nGP + g];
+            const double* __restrict__ row = fe + (int64_t)ne_idx[k] * DM;      // ne_idx = e*npe + la: the row of fe
 #pragma unroll
-                for (int i = 0; i < DM; ++i) {
-                    double d = 0.0;
-#pragma unroll
-                    for (int j = 0; j < DM; ++j) d += gr[j] * sg[j * DM + i];
-                    acc[i] = acc[i] + d * v;
-                }
-            }
+            for (int i = 0; i < DM; ++i) acc[i] += row[i];
         }
     }
 #pragma unroll
@@ -1075,7 +1100,7 @@ int launch_energy_sum(Ctx* c, double* total) {
         launched = true;                                                 \
     }
 
-int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bool write_sigma) {
+int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bool write_sigma, bool write_fe) {
     const int bs = 256, grid = (c->ne + bs - 1) / bs;
     bool launched = false;
     size_t th = timing_begin(c, T_GEOM);
@@ -1084,11 +1109,11 @@ int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bo
         hipLaunchKernelGGL((k_geom<NPE, DM, true>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes,  \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \
                            c->mat_params[1], write_geom ? c->d_dsdx : nullptr, c->d_vol, c->d_F,                  \
-                           write_sigma ? c->d_sigma : nullptr);                                                     \
+                           write_sigma ? c->d_sigma : nullptr, (write_fe && write_sigma) ? c->d_fe : nullptr);      \
     else                                                                                                            \
         hipLaunchKernelGGL((k_geom<NPE, DM, false>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes, \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \
-                           c->mat_params[1], c->d_dsdx, c->d_vol, c->d_F, c->d_sigma)
+                           c->mat_params[1], c->d_dsdx, c->d_vol, c->d_F, c->d_sigma, (double*)nullptr)
     FEMCY_DISPATCH_ELEMENT(3, 2, GEOM_CALL)
     FEMCY_DISPATCH_ELEMENT(4, 2, GEOM_CALL)
     FEMCY_DISPATCH_ELEMENT(6, 2, GEOM_CALL)
@@ -1172,11 +1197,11 @@ int launch_nodal_force(Ctx* c, double* d_f) {
     const int grid = (int)(((int64_t)c->nn * 32 + bs - 1) / bs);   // 32 lanes per node
     size_t th = timing_begin(c, T_FORCE);
     if (c->dm == 3)
-        hipLaunchKernelGGL((k_nodal_force<3>), dim3(grid), dim3(bs), 0, c->stream, c->nn, c->npe, c->nGP, c->d_ne_ptr,
-                           c->d_ne_idx, c->d_dsdx, c->d_sigma, c->d_vol, d_f);
+        hipLaunchKernelGGL((k_nodal_force<3>), dim3(grid), dim3(bs), 0, c->stream, c->nn, c->d_ne_ptr, c->d_ne_idx,
+                           c->d_fe, d_f);
     else
-        hipLaunchKernelGGL((k_nodal_force<2>), dim3(grid), dim3(bs), 0, c->stream, c->nn, c->npe, c->nGP, c->d_ne_ptr,
-                           c->d_ne_idx, c->d_dsdx, c->d_sigma, c->d_vol, d_f);
+        hipLaunchKernelGGL((k_nodal_force<2>), dim3(grid), dim3(bs), 0, c->stream, c->nn, c->d_ne_ptr, c->d_ne_idx,
+                           c->d_fe, d_f);
     timing_end(c, th);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
