@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still create the torch.distributed (nccl) group and use its barrier / broadcast / all-reduce (exercises the N>1 host code on one GPU)")
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="auto",
+                    help="N>1: interface exchange per CG iteration (auto = measured at start-up)")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
     args = ap.parse_args()
 
@@ -114,6 +116,18 @@ def main():
         if use_dist:
             dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
+        # interface exchange: measure the packed all-reduce against send/recv with the slab neighbours and keep the
+        # faster one (all ranks decide alike from the maximum over the ranks); --exchange pins it
+        exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None}
+        if hasattr(ctx, "comm_set_neighbours"):
+            ctx.comm_set_neighbours(part)
+            if args.exchange == "auto":
+                exchange = ctx.comm_tune(20)
+            else:
+                ctx.set_option(be.OPT_EXCHANGE, 1 if args.exchange == "neighbour" else 0)
+                exchange["exchange"] = args.exchange
+    else:
+        exchange = None
     n, ne = ctx.n, ctx.ne
     if rank == 0:
         log(f"[bench] cells {nx}x{ny}x{nz}: {ne_global} elements / {n_global} DOF global, {ne} elements / {n} DOF "
@@ -216,7 +230,8 @@ def main():
                                f"(BASELINE configs[2] at N=1, configs[3] at N=8), state S1 (t=0.05), "
                                f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
                    "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters,
-                   "parallelism": f"element z-slabs x{N}" if N > 1 else "single GPU"},
+                   "parallelism": f"element z-slabs x{N}" if N > 1 else "single GPU",
+                   "interface_exchange": exchange},
         "cg_iters_per_s": cg_only * scale,
         "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,

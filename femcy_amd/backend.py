@@ -27,6 +27,7 @@ GP_DSDX, GP_VOL, GP_F, GP_SIGMA, GP_STRAIN, GP_MISES, GP_ENERGY = range(7)
 # enum femcy_option
 OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT, OPT_EW_GRID, OPT_PCG_GRAPH, OPT_SELL_SIGMA = range(7)
 OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent tangent (extension)
+OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neighbour send/recv
 ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM = 0, 1, 2, 3, 4
 
 EXPORTS = [
@@ -38,7 +39,8 @@ EXPORTS = [
     "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
     "femcy_dofset_scatter", "femcy_loadset_create", "femcy_loadset_neumann", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
-    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_comm_info", "femcy_iface_sum",
+    "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_comm_info", "femcy_comm_set_neighbours",
+    "femcy_comm_tune", "femcy_iface_sum",
 ]
 
 
@@ -110,7 +112,8 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_extrapolate": [p, cint, cint, p, p],
         "femcy_get_K_ell": [p, p, p], "femcy_get_K_bsr": [p, p, p, p], "femcy_get_gp_field": [p, cint, p],
         "femcy_timing": [p, C.POINTER(Timing)], "femcy_timing_reset": [p],
-        "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_info": [p, p, p, p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
+        "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_info": [p, p, p, p],
+        "femcy_comm_set_neighbours": [p, i32, p, p, p], "femcy_comm_tune": [p, i32, C.POINTER(i32), p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
         "femcy_iface_sum": [p, cint],
     }
     for name, args in sig.items():
@@ -423,6 +426,17 @@ class Context:
         ng = C.c_int64()
         self._call("femcy_comm_info", None, None, C.byref(ng))
         self.n_global = int(ng.value)
+
+    def comm_set_neighbours(self, part):
+        """part: a `femcy_amd.partition.Part` (nb_ranks / nb_ptr / nb_dofs)."""
+        r, q, d = _i32(part.nb_ranks).ravel(), _i32(part.nb_ptr).ravel(), _i32(part.nb_dofs).ravel()
+        self._call("femcy_comm_set_neighbours", r.size, _ptr(r), _ptr(q), _ptr(d))
+
+    def comm_tune(self, iters: int = 20) -> dict:
+        """collective: measure both interface exchanges, keep the faster one on every rank."""
+        chosen, us = C.c_int32(), (C.c_double * 2)()
+        self._call("femcy_comm_tune", int(iters), C.byref(chosen), C.cast(us, C.c_void_p))
+        return {"exchange": "neighbour" if chosen.value == 1 else "allreduce", "allreduce_us": us[0], "neighbour_us": us[1]}
 
     def iface_sum(self, vec_id: int):
         self._call("femcy_iface_sum", int(vec_id))

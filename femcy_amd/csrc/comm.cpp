@@ -27,6 +27,8 @@ typedef int (*fn_get_uid)(nccl_uid*);
 typedef int (*fn_init_rank)(void**, int, nccl_uid, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_sendrecv)(void*, size_t, int, int, void*, hipStream_t);   // ncclSend (const void*) / ncclRecv
+typedef int (*fn_group)(void);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 
@@ -36,6 +38,8 @@ static struct {
     fn_init_rank init_rank = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_allgather allgather = nullptr;
+    fn_sendrecv send = nullptr, recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
 } R;
@@ -59,6 +63,10 @@ static int load_rccl() {
     R.init_rank = (fn_init_rank)dlsym(R.lib, "ncclCommInitRank");
     R.allreduce = (fn_allreduce)dlsym(R.lib, "ncclAllReduce");
     R.allgather = (fn_allgather)dlsym(R.lib, "ncclAllGather");
+    R.send = (fn_sendrecv)dlsym(R.lib, "ncclSend");
+    R.recv = (fn_sendrecv)dlsym(R.lib, "ncclRecv");
+    R.group_start = (fn_group)dlsym(R.lib, "ncclGroupStart");
+    R.group_end = (fn_group)dlsym(R.lib, "ncclGroupEnd");
     R.destroy = (fn_destroy)dlsym(R.lib, "ncclCommDestroy");
     R.errstr = (fn_errstr)dlsym(R.lib, "ncclGetErrorString");
     if (!R.get_uid || !R.init_rank || !R.allreduce || !R.allgather || !R.destroy) {
@@ -87,6 +95,7 @@ struct LocalGroup {
     uint64_t gen = 0;
     bool broken = false;
     std::vector<std::vector<double>> stage;   // one buffer per rank
+    std::vector<std::vector<int32_t>> nb_rank, nb_ptr;   // per rank: its neighbour segment table (neighbour exchange)
 };
 static std::mutex g_groups_m;
 static std::map<uint64_t, std::shared_ptr<LocalGroup>> g_groups;
@@ -135,6 +144,8 @@ static int local_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
             slot = std::make_shared<LocalGroup>();
             slot->nranks = nranks;
             slot->stage.resize(nranks);
+            slot->nb_rank.resize(nranks);
+            slot->nb_ptr.resize(nranks);
         }
         g = slot;
     }
@@ -217,6 +228,62 @@ int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count) 
     }
     if (c->comm_local) return local_exchange(c, d_send, count, d_recv, true);
     FEMCY_NCCL(R.allgather(d_send, d_recv, (size_t)count, /*ncclFloat64*/ 8, c->comm, c->stream));
+    return FEMCY_OK;
+}
+
+int comm_register_neighbours(Ctx* c) {
+    if (!c->comm || !c->comm_local) return FEMCY_OK;
+    LocalGroup* g = (LocalGroup*)c->comm;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->nb_rank[c->rank] = c->h_nb_rank;
+    g->nb_ptr[c->rank] = c->h_nb_ptr;
+    return FEMCY_OK;
+}
+
+// every rank sends segment k of d_nb_send to neighbour h_nb_rank[k] and receives that neighbour's segment for it
+// into segment k of d_nb_recv (the two sides list the shared DOFs in the same order)
+int comm_neighbour_exchange(Ctx* c) {
+    if (!c->comm) return FEMCY_OK;
+    const int nnb = (int)c->h_nb_rank.size();
+    if (c->comm_local) {
+        LocalGroup* g = (LocalGroup*)c->comm;
+        const int64_t total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
+        std::vector<double>& mine = g->stage[c->rank];
+        mine.resize((size_t)total);
+        if (total) FEMCY_HIP(hipMemcpyAsync(mine.data(), c->d_nb_send, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        int rc = local_barrier(g);
+        if (rc) return rc;
+        std::vector<double> in((size_t)total);
+        for (int k = 0; k < nnb; ++k) {
+            const int q = c->h_nb_rank[k];
+            const int32_t cnt = c->h_nb_ptr[k + 1] - c->h_nb_ptr[k];
+            const std::vector<int32_t>& qr = g->nb_rank[q];
+            int kq = -1;
+            for (size_t t = 0; t < qr.size(); ++t)
+                if (qr[t] == c->rank) kq = (int)t;
+            if (kq < 0 || g->nb_ptr[q][kq + 1] - g->nb_ptr[q][kq] != cnt) {
+                set_error("in-process group: ranks %d and %d disagree on their shared DOFs", c->rank, q);
+                return FEMCY_ECOMM;
+            }
+            std::memcpy(in.data() + c->h_nb_ptr[k], g->stage[q].data() + g->nb_ptr[q][kq], sizeof(double) * cnt);
+        }
+        if ((rc = local_barrier(g))) return rc;
+        if (total) FEMCY_HIP(hipMemcpyAsync(c->d_nb_recv, in.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        return FEMCY_OK;
+    }
+    if (!R.send || !R.recv || !R.group_start || !R.group_end) {
+        set_error("librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        return FEMCY_ECOMM;
+    }
+    FEMCY_NCCL(R.group_start());
+    for (int k = 0; k < nnb; ++k) {
+        const size_t cnt = (size_t)(c->h_nb_ptr[k + 1] - c->h_nb_ptr[k]);
+        FEMCY_NCCL(R.send(c->d_nb_send + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, c->stream));
+        FEMCY_NCCL(R.recv(c->d_nb_recv + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, c->stream));
+    }
+    FEMCY_NCCL(R.group_end());
     return FEMCY_OK;
 }
 

@@ -185,6 +185,15 @@ struct Ctx {
     uint8_t* d_owner = nullptr;
     double* d_commbuf = nullptr;      // [niface_global + 8]
     double* d_gather = nullptr;       // [nranks*2]
+
+    // ---- neighbour exchange (femcy_comm_set_neighbours): the alternative to the packed all-reduce
+    int exchange = 0;                 // FEMCY_OPT_EXCHANGE: 0 packed all-reduce, 1 neighbour send/recv
+    std::vector<int32_t> h_nb_rank, h_nb_ptr;   // neighbours (ascending) and their segments of the send / recv buffers
+    int32_t* d_nb_dofs = nullptr;     // [nb_total] local DOF of every send entry
+    double* d_nb_send = nullptr;      // [nb_total]
+    double* d_nb_recv = nullptr;      // [nb_total]
+    int32_t* d_if_ptr = nullptr;      // [niface_local+1] per local interface DOF (order of d_iface_dof): its
+    int32_t* d_if_src = nullptr;      //   contributions in ascending rank order; src = recv index, -1 = own value
 };
 
 // timing classes
@@ -226,6 +235,8 @@ int comm_local_id(void* id128);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
+int comm_neighbour_exchange(Ctx* c);   // d_nb_send segments -> neighbours, their segments -> d_nb_recv
+int comm_register_neighbours(Ctx* c);  // in-process transport: publish this rank's segment table
 int comm_destroy(Ctx* c);
 int iface_sum(Ctx* c, double* d_v);
 int scalar_across_ranks(Ctx* c, double* d_val, int mode, double* out);

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include "ctx.hpp"
@@ -194,6 +195,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_idx_scratch); dev_free(&c->d_val_scratch);
     dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_slot2dof); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
     dev_free(&c->d_gather);
+    dev_free(&c->d_nb_dofs); dev_free(&c->d_nb_send); dev_free(&c->d_nb_recv); dev_free(&c->d_if_ptr); dev_free(&c->d_if_src);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     for (auto& ds : c->dofsets) {
@@ -242,6 +244,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 pcg_graph_reset(c);
                 spmv_split(c);
             }
+            break;
+        case FEMCY_OPT_EXCHANGE:
+            FEMCY_REQUIRE(value == 0 || value == 1, "exchange: 0 (all-reduce) or 1 (neighbour send/recv)");
+            FEMCY_REQUIRE(value == 0 || c->d_if_ptr, "femcy_comm_set_neighbours must come first");
+            c->exchange = (int)value;
             break;
         case FEMCY_OPT_TANGENT:
             FEMCY_REQUIRE(value == 0 || value == 1, "tangent: 0 (reference) or 1 (consistent)");
@@ -972,6 +979,117 @@ int femcy_comm_info(femcy_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* n_g
     if (rank) *rank = c->comm ? c->rank : 0;
     if (nranks) *nranks = c->comm ? c->nranks : 1;
     if (n_global) *n_global = c->comm ? c->n_global : c->n;
+    return FEMCY_OK;
+}
+
+int femcy_comm_set_neighbours(femcy_ctx* ctx, int32_t nnb, const int32_t* nb_rank, const int32_t* nb_ptr,
+                              const int32_t* nb_dofs) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->comm, "femcy_comm_init must come first");
+    FEMCY_REQUIRE(nnb >= 0 && (nnb == 0 || (nb_rank && nb_ptr && nb_dofs)), "bad neighbour lists");
+    const int32_t total = nnb ? nb_ptr[nnb] : 0;
+    for (int32_t k = 0; k < nnb; ++k) {
+        FEMCY_REQUIRE(nb_rank[k] >= 0 && nb_rank[k] < c->nranks && nb_rank[k] != c->rank, "neighbour %d out of range", nb_rank[k]);
+        FEMCY_REQUIRE(k == 0 || nb_rank[k] > nb_rank[k - 1], "neighbours must be listed in ascending rank order");
+        FEMCY_REQUIRE(nb_ptr[k + 1] >= nb_ptr[k] && nb_ptr[0] == 0, "neighbour segments must be contiguous");
+    }
+    // per local interface DOF (in the order of iface_local_dofs): own value + one received value per sharing
+    // neighbour, sorted by rank
+    std::vector<int32_t> h_dof((size_t)std::max(c->niface_local, 1));
+    if (c->niface_local) FEMCY_HIP(hipMemcpy(h_dof.data(), c->d_iface_dof, sizeof(int32_t) * c->niface_local, hipMemcpyDeviceToHost));
+    std::vector<int32_t> where((size_t)c->n, -1);
+    for (int32_t i = 0; i < c->niface_local; ++i) where[h_dof[i]] = i;
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> lists((size_t)c->niface_local);   // (rank, recv index)
+    for (int32_t i = 0; i < c->niface_local; ++i) lists[i].push_back({c->rank, -1});
+    for (int32_t k = 0; k < nnb; ++k)
+        for (int32_t j = nb_ptr[k]; j < nb_ptr[k + 1]; ++j) {
+            FEMCY_REQUIRE(nb_dofs[j] >= 0 && nb_dofs[j] < c->n && where[nb_dofs[j]] >= 0,
+                          "DOF %d shared with rank %d is not an interface DOF of femcy_comm_init", nb_dofs[j], nb_rank[k]);
+            lists[where[nb_dofs[j]]].push_back({nb_rank[k], j});
+        }
+    std::vector<int32_t> ptr((size_t)c->niface_local + 1, 0), src;
+    for (int32_t i = 0; i < c->niface_local; ++i) {
+        FEMCY_REQUIRE(lists[i].size() >= 2, "interface DOF %d is shared with no neighbour", h_dof[i]);
+        std::sort(lists[i].begin(), lists[i].end());
+        for (auto& pr : lists[i]) src.push_back(pr.second);
+        ptr[i + 1] = (int32_t)src.size();
+    }
+    int rc;
+    if ((rc = dev_alloc(&c->d_nb_dofs, (size_t)std::max(total, 1), false)) ||
+        (rc = dev_alloc(&c->d_nb_send, (size_t)std::max(total, 1))) ||
+        (rc = dev_alloc(&c->d_nb_recv, (size_t)std::max(total, 1))) || (rc = dev_alloc(&c->d_if_ptr, ptr.size(), false)) ||
+        (rc = dev_alloc(&c->d_if_src, std::max<size_t>(src.size(), 1), false)))
+        return rc;
+    if (total) FEMCY_HIP(hipMemcpy(c->d_nb_dofs, nb_dofs, sizeof(int32_t) * total, hipMemcpyHostToDevice));
+    FEMCY_HIP(hipMemcpy(c->d_if_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
+    if (!src.empty()) FEMCY_HIP(hipMemcpy(c->d_if_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice));
+    c->h_nb_rank.assign(nb_rank, nb_rank + nnb);
+    c->h_nb_ptr.assign(nb_ptr, nb_ptr + nnb + (nnb ? 1 : 0));
+    if (c->h_nb_ptr.empty()) c->h_nb_ptr.push_back(0);
+    return comm_register_neighbours(c);
+}
+
+int femcy_comm_tune(femcy_ctx* ctx, int32_t iters, int32_t* chosen, double* us) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->comm && c->d_if_ptr, "femcy_comm_init and femcy_comm_set_neighbours must come first");
+    FEMCY_REQUIRE(iters >= 1 && chosen && us, "bad arguments");
+    double* v = c->d_vec[FEMCY_VEC_TMP1];
+    double* keep = c->d_vec[FEMCY_VEC_TMP0];
+    const int saved = c->exchange;
+    int rc;
+    // cross-check on a non-trivial vector: v[i] = 1 + (i mod 7) / 8 on both paths
+    std::vector<double> h((size_t)c->n), a((size_t)c->n), b((size_t)c->n);
+    for (int64_t i = 0; i < c->n; ++i) h[i] = 1.0 + (double)(i % 7) / 8.0;
+    FEMCY_HIP(hipMemcpy(keep, h.data(), sizeof(double) * c->n, hipMemcpyHostToDevice));
+    bool same = true;
+    for (int method = 0; method < 2; ++method) {
+        c->exchange = method;
+        FEMCY_HIP(hipMemcpyAsync(v, keep, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = iface_sum(c, v))) { c->exchange = saved; return rc; }
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        FEMCY_HIP(hipMemcpy(method ? b.data() : a.data(), v, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+    }
+    for (int64_t i = 0; i < c->n; ++i) same = same && std::fabs(a[i] - b[i]) <= 1e-12 * std::fabs(a[i]);
+    // timing on a zero vector (sums stay zero)
+    double t_us[2] = {0.0, 0.0};
+    double* slot = c->d_commbuf + c->niface_global;
+    for (int method = 0; method < 2; ++method) {
+        c->exchange = method;
+        if ((rc = vec_fill(c, v, 0.0, c->n))) { c->exchange = saved; return rc; }
+        FEMCY_HIP(hipMemsetAsync(slot, 0, sizeof(double), c->stream));
+        for (int pass = 0; pass < 2; ++pass) {           // pass 0 warms the connections up
+            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int32_t k = 0; k < (pass ? iters : 3); ++k) {
+                if ((rc = iface_sum(c, v))) { c->exchange = saved; return rc; }
+                if (method == 1 && (rc = comm_allreduce_sum(c, slot, 1))) { c->exchange = saved; return rc; }
+            }
+            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            if (pass) t_us[method] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+        }
+    }
+    c->exchange = saved;
+    // agree: maximum over the ranks of each time, and of the "differs" flag
+    double pack[3] = {t_us[0], t_us[1], same ? 0.0 : 1.0};
+    std::vector<double> all((size_t)c->nranks * 3);
+    FEMCY_HIP(hipMemcpy(c->d_commbuf, pack, sizeof(pack), hipMemcpyHostToDevice));
+    double* d_all = nullptr;
+    FEMCY_HIP(hipMalloc((void**)&d_all, sizeof(double) * all.size()));
+    rc = comm_allgather(c, c->d_commbuf, d_all, 3);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = FEMCY_EHIP;
+    if (!rc && hipMemcpy(all.data(), d_all, sizeof(double) * all.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = FEMCY_EHIP;
+    (void)hipFree(d_all);
+    if (rc) return rc;
+    double m0 = 0.0, m1 = 0.0, bad = 0.0;
+    for (int r = 0; r < c->nranks; ++r) {
+        m0 = std::max(m0, all[3 * r]);
+        m1 = std::max(m1, all[3 * r + 1]);
+        bad = std::max(bad, all[3 * r + 2]);
+    }
+    us[0] = m0;
+    us[1] = bad > 0.0 ? -1.0 : m1;
+    c->exchange = (bad == 0.0 && m1 < m0) ? 1 : 0;
+    *chosen = c->exchange;
     return FEMCY_OK;
 }
 

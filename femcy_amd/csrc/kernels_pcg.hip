@@ -437,6 +437,28 @@ __global__ void k_iface_unpack(int32_t k, const int32_t* __restrict__ dof, const
     if (i < k) v[dof[i]] = buf[slot[i]];
 }
 
+// neighbour exchange: send[j] = v[nb_dofs[j]]; after the exchange every local interface DOF sums its own value and
+// the received ones in ascending RANK order -- all ranks holding the DOF add the same numbers in the same order, so
+// the replicas stay bit-identical
+__global__ void k_p2p_pack(int32_t total, const int32_t* __restrict__ nb_dofs, const double* __restrict__ v,
+                           double* __restrict__ send) {
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < total) send[j] = v[nb_dofs[j]];
+}
+__global__ void k_p2p_sum(int32_t k, const int32_t* __restrict__ dof, const int32_t* __restrict__ ptr,
+                          const int32_t* __restrict__ src, const double* __restrict__ recv, double* __restrict__ v) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int32_t d = dof[i];
+    const double own = v[d];
+    double s = 0.0;
+    for (int32_t t = ptr[i]; t < ptr[i + 1]; ++t) {
+        const int32_t q = src[t];
+        s += q < 0 ? own : recv[q];
+    }
+    v[d] = s;
+}
+
 // ------------------------------------------------------------------------------- vector helpers
 __global__ void __launch_bounds__(BS) k_fill(int64_t n, double* __restrict__ v, double val) {
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) v[i] = val;
@@ -608,8 +630,23 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 }
 
 // sum a sub-assembled vector over the ranks that share each interface DOF
+static int iface_sum_p2p(Ctx* c, double* d_v) {
+    const int32_t total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
+    if (total > 0)
+        hipLaunchKernelGGL(k_p2p_pack, dim3((total + BS - 1) / BS), dim3(BS), 0, c->stream, total, c->d_nb_dofs,
+                           (const double*)d_v, c->d_nb_send);
+    int rc = comm_neighbour_exchange(c);
+    if (rc) return rc;
+    if (c->niface_local > 0)
+        hipLaunchKernelGGL(k_p2p_sum, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream, c->niface_local,
+                           c->d_iface_dof, c->d_if_ptr, c->d_if_src, (const double*)c->d_nb_recv, d_v);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
 int iface_sum(Ctx* c, double* d_v) {
     if (!c->comm) return FEMCY_OK;
+    if (c->exchange == 1) return iface_sum_p2p(c, d_v);
     hipLaunchKernelGGL(k_iface_pack_all, dim3((c->niface_global + BS - 1) / BS + 1), dim3(BS), 0, c->stream,
                        c->niface_global, c->d_slot2dof, d_v, c->d_commbuf, 0, (const double*)nullptr);
     int rc = comm_allreduce_sum(c, c->d_commbuf, c->niface_global);
@@ -667,7 +704,14 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         int rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1);
         if (rc) return rc;
         const double* dAd_red = nullptr;
-        if (multi) {
+        if (multi && c->exchange == 1) {
+            // neighbour send/recv of the interface entries of Ad, then the scalar d.Ad by an 8-byte all-reduce
+            double* slot = c->d_commbuf + c->niface_global;
+            if ((rc = iface_sum_p2p(c, c->d_Ad))) return rc;
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, np1, (const double*)c->d_part1, 0, slot);
+            if ((rc = comm_allreduce_sum(c, slot, 1))) return rc;
+            dAd_red = slot;
+        } else if (multi) {
             // interface rows of Ad hold partial sums: pack them + the local d.Ad, all-reduce, unpack
             double* slot = c->d_commbuf + c->niface_global;
             hipLaunchKernelGGL(k_iface_pack_all, dim3((c->niface_global + BS - 1) / BS + 1), dim3(BS), 0, c->stream,

@@ -33,6 +33,12 @@ class Part:
     niface_global: int
     owner: np.ndarray              # uint8[n_local]
     dm: int
+    # neighbour exchange (alternative to the packed all-reduce): the ranks this one shares nodes with, ascending, and
+    # for neighbour q the local DOFs shared with it in ascending GLOBAL DOF order -- rank q lists the same DOFs in the
+    # same order, so the two sides of a send / recv pair line up entry by entry
+    nb_ranks: np.ndarray = None    # int32[nnb]
+    nb_ptr: np.ndarray = None      # int32[nnb + 1]
+    nb_dofs: np.ndarray = None     # int32[nb_ptr[-1]]
 
     @property
     def n_local(self):
@@ -92,9 +98,21 @@ def build_part(nodes: np.ndarray, elements: np.ndarray, nranks: int, rank: int, 
     iface_local_dofs = (loc_iface[:, None] * dm + comp[None, :]).ravel().astype(np.int32)
     iface_global_slot = (slot_of_node[l2g[loc_iface]][:, None] * dm + comp[None, :]).ravel().astype(np.int32)
     owner = np.repeat((owner_rank[l2g] == rank).astype(np.uint8), dm)
+    nb_ranks, nb_ptr, nb_dofs = [], [0], []
+    mine_if = touched[l2g[loc_iface]]                              # [n_iface_local, nranks]
+    for q in range(nranks):
+        if q == rank:
+            continue
+        shared = loc_iface[mine_if[:, q]]                          # local node ids, ascending local = ascending global
+        if shared.size:
+            nb_ranks.append(q)
+            nb_dofs.append((shared[:, None] * dm + comp[None, :]).ravel())
+            nb_ptr.append(nb_ptr[-1] + shared.size * dm)
     return Part(rank=rank, nranks=nranks, elem_ids=mine, l2g=l2g, nodes=np.ascontiguousarray(nodes[l2g]),
                 elements=loc_el, iface_local_dofs=iface_local_dofs, iface_global_slot=iface_global_slot,
-                niface_global=int(iface_nodes.size * dm), owner=owner, dm=dm)
+                niface_global=int(iface_nodes.size * dm), owner=owner, dm=dm,
+                nb_ranks=np.asarray(nb_ranks, dtype=np.int32), nb_ptr=np.asarray(nb_ptr, dtype=np.int32),
+                nb_dofs=(np.concatenate(nb_dofs) if nb_dofs else np.zeros(0)).astype(np.int32))
 
 
 def build_all_parts(nodes, elements, nranks, axis=2) -> List[Part]:

@@ -38,7 +38,7 @@ class System_of_equations:
 
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
-                 part=None, comm_uid: bytes = None, tangent: str = "reference"):
+                 part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce"):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -70,6 +70,14 @@ class System_of_equations:
             self.ctx.comm_init(part.rank, part.nranks, comm_uid, part.iface_local_dofs, part.iface_global_slot,
                                part.niface_global, part.owner)
             self.verbose = verbose and part.rank == 0
+            # interface exchange per CG iteration: "allreduce" (packed global interface vector), "neighbour"
+            # (send/recv with the ranks sharing nodes) or "auto" (femcy_comm_tune measures both at start-up)
+            self.ctx.comm_set_neighbours(part)
+            if exchange == "auto":
+                self.exchange = self.ctx.comm_tune(20)
+            else:
+                self.ctx.set_option(be.OPT_EXCHANGE, 1 if exchange == "neighbour" else 0)
+                self.exchange = {"exchange": exchange}
         self._say("\033[32;1m pattern: {} DOF, {} blocks of {}x{}, ELL width {} ({:.3f} s) \033[0m".format(
             self.pattern.n, self.pattern.nnzb, self.dm, self.dm, self.pattern.ell_width, time.time() - t0))
 

@@ -96,6 +96,9 @@ enum femcy_option {
                                    (SELL-C-sigma, default 4096; 64 = natural order); set before build_pattern */
     FEMCY_OPT_PCG_GRAPH = 5,    /* hipGraph replay of poll-bursts of PCG iterations: 0 off, 1 auto (default:
                                    below 2e5 DOF, where the loop is launch-bound), 2 always             */
+    FEMCY_OPT_EXCHANGE = 8,     /* multi-rank interface exchange: 0 = all-reduce of the packed global interface vector
+                                   (default), 1 = send/recv with the neighbouring ranks (needs
+                                   femcy_comm_set_neighbours); femcy_comm_tune measures both and sets it */
     FEMCY_OPT_TANGENT = 7       /* what femcy_assemble_K assembles.  0 (default) = the reference's matrix: B^T C B
                                    on the current configuration with the constant C (stiffnessMtrx.py:124-186).
                                    1 = the consistent tangent of femcy_internal_force: spatial elasticity tensor of
@@ -250,6 +253,18 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
  * rank without a communicator).
  * femcy_iface_sum: sum any other sub-assembled vector over the ranks sharing each interface DOF */
 int femcy_comm_info(femcy_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* n_global);
+/* Neighbour exchange, the alternative to the packed all-reduce: nb_rank[k] (ascending) shares the local DOFs
+ * nb_dofs[nb_ptr[k] .. nb_ptr[k+1]) with this rank, listed in ascending GLOBAL DOF order on both sides.  Per exchange
+ * each pair swaps its segment (ncclSend / ncclRecv in one group) and every interface DOF is summed in ascending rank
+ * order, so all replicas get the same bits; d.Ad then travels in an 8-byte all-reduce of its own.  The z-slab
+ * partitions have <= 2 neighbours per rank: 2 x 116 KB per exchange at 8 M elements instead of a 0.8 MB all-reduce. */
+int femcy_comm_set_neighbours(femcy_ctx* ctx, int32_t nnb, const int32_t* nb_rank, const int32_t* nb_ptr,
+                              const int32_t* nb_dofs);
+/* collective: times `iters` interface exchanges with each method (the neighbour form including its extra scalar
+ * all-reduce), checks that both give the same sums, takes the maximum over the ranks and selects the faster one
+ * (FEMCY_OPT_EXCHANGE) on every rank alike.  us[0] / us[1] = microseconds per exchange (all-reduce / neighbour);
+ * a failed cross-check keeps the all-reduce and reports us[1] = -1. */
+int femcy_comm_tune(femcy_ctx* ctx, int32_t iters, int32_t* chosen, double* us /*[2]*/);
 int femcy_iface_sum(femcy_ctx* ctx, int vec);
 
 #ifdef __cplusplus

@@ -175,11 +175,12 @@ def test_rendezvous_failures_are_reported(gpu_ctx_factory):
         x.close()
 
 
-@pytest.mark.parametrize("name,nranks,axis", [("twist_plate_C3D4.inp", 2, 2),                 # nlgeom, *Boundary user
-                                              ("cook_3d_linearEl_largeDef.inp", 3, 0),        # neo-Hookean + *Dsload
-                                              ("ellip_CPS8.inp", 2, 0),                       # linear: 0/1 elimination
-                                              ("beamDeflec_quadPSE_largeD_load800.inp", 2, 0)])   # CPS6 + load, cut-backs
-def test_partitioned_deck_solve_equals_single_context(name, nranks, axis):
+@pytest.mark.parametrize("name,nranks,axis,exchange", [
+    ("twist_plate_C3D4.inp", 2, 2, "allreduce"),                     # nlgeom, *Boundary user
+    ("cook_3d_linearEl_largeDef.inp", 3, 0, "neighbour"),            # neo-Hookean + *Dsload, send/recv exchange
+    ("ellip_CPS8.inp", 2, 0, "auto"),                                # linear: 0/1 elimination; tuned exchange
+    ("beamDeflec_quadPSE_largeD_load800.inp", 2, 0, "neighbour")])   # CPS6 + load, cut-backs
+def test_partitioned_deck_solve_equals_single_context(name, nranks, axis, exchange):
     """the whole driver (increments, modified Newton, line searches, cut-backs) with the mesh split over `nranks`
     contexts: every rank runs the reference's control flow on collective scalars, so all ranks take the same
     decisions as the un-partitioned run -- same increments, same Newton counts, same displacements."""
@@ -204,7 +205,8 @@ def test_partitioned_deck_solve_equals_single_context(name, nranks, axis):
     def rank_main(r):
         p = parts[r]
         body = Body(p.nodes, p.elements, inp.ELE)
-        system = System_of_equations(body, mat, inp.geometric_nonlinear, verbose=False, part=p, comm_uid=uid)
+        system = System_of_equations(body, mat, inp.geometric_nonlinear, verbose=False, part=p, comm_uid=uid,
+                                     exchange=exchange)
         try:
             system.solve(partition.LocalDeck(inp, p, body))
             return (system.dof.to_numpy(), system.increments, dict(system.stats), system.get_elasEng(),
@@ -246,3 +248,60 @@ def test_main_as_one_rank_rccl_job(tmp_path):
     assert "1 ranks" in r.stdout
     a, b = np.load(out_a)["dof"], np.load(out_b)["dof"]
     assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(a)
+
+
+@pytest.mark.parametrize("name,nranks,axis", [("twist_plate_C3D4.inp", 4, 2), ("twist_C3D10_coarse.inp", 3, 2),
+                                              ("ellip_CPS8.inp", 2, 0)])
+def test_neighbour_exchange_equals_allreduce(name, nranks, axis):
+    """the two interface exchanges (packed all-reduce / send-recv with the neighbouring ranks + 8-byte all-reduce of
+    d.Ad) run the same PCG: same iteration counts, iterates equal to rounding, and every replica of an interface DOF
+    holds the same bits under the neighbour form (rank-ordered sums).  femcy_comm_tune measures both and all ranks
+    choose alike."""
+    from femcy_amd import backend as be, partition
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    el = list(inp.eSets.values())[0]
+    mat = list(inp.materials.values())[0]
+    dm = inp.nodes.shape[1]
+    n = inp.nodes.size
+    parts = partition.build_all_parts(inp.nodes, el, nranks, axis=axis)
+    cons_nodes = [(np.asarray(b["node_set"]), b["dof"]) for b in inp.dirichlet_bc_info]
+    b_g = np.random.default_rng(11).standard_normal(n)
+    uid = be.Context.comm_local_id()
+
+    def rank_main(r):
+        p = parts[r]
+        c = setup_rank(be, p, inp, mat, uid)
+        try:
+            c.comm_set_neighbours(p)
+            c.assemble_K(-1)
+            cons = np.unique(np.concatenate([p.localize_nodes(ns) * dm + d for ns, d in cons_nodes]))
+            out = {}
+            for mode in (0, 1):
+                c.set_option(be.OPT_EXCHANGE, mode)
+                c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
+                c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+                c.upload(be.VEC_TMP0, p.scatter_global(b_g))
+                c.spmv(be.VEC_TMP0, be.VEC_TMP1)
+                y = c.download(be.VEC_TMP1)
+                res = c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=40)
+                out[mode] = (y, res, c.download(be.VEC_X))
+            tune = c.comm_tune(5)
+            return out, tune
+        finally:
+            c.close()
+
+    outs = run_ranks(nranks, rank_main)
+    for p, (out, tune) in zip(parts, outs):
+        (y0, r0, x0), (y1, r1, x1) = out[0], out[1]
+        assert np.abs(y1 - y0).max() <= 1e-13 * np.abs(y0).max()
+        assert r0[0] == r1[0] == 40 and abs(r0[2] - r1[2]) <= 1e-9 * r0[2]
+        assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(x0)
+        assert tune["allreduce_us"] > 0 and tune["neighbour_us"] > 0          # cross-check passed on every rank
+    assert len({o[1]["exchange"] for o in outs}) == 1                          # one decision for the whole job
+    # replicas of shared DOFs are bit-identical under the neighbour exchange
+    y_glob = {}
+    for p, (out, _) in zip(parts, outs):
+        gd = (p.l2g[:, None] * dm + np.arange(dm)[None, :]).ravel()
+        for g, v in zip(gd[p.iface_local_dofs], out[1][0][p.iface_local_dofs]):
+            assert y_glob.setdefault(int(g), v) == v
