@@ -52,8 +52,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still create the torch.distributed (nccl) group and use its barrier / broadcast / all-reduce (exercises the N>1 host code on one GPU)")
-    ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="auto",
-                    help="N>1: interface exchange per CG iteration (auto = measured at start-up)")
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="allreduce",
+                    help="N>1: interface exchange per CG iteration.  allreduce = the packed global interface vector "
+                         "(default: the form verified with a live RCCL communicator); neighbour = send/recv with the "
+                         "slab neighbours; auto = measure both at start-up (femcy_comm_tune) and keep the faster")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
     args = ap.parse_args()
 

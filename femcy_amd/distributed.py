@@ -46,7 +46,8 @@ def partitioned_system(inp, material, verbose=True, tangent="reference"):
     part = partition.build_part(inp.nodes, el, nranks, rank, axis=axis)
     body = Body(part.nodes, part.elements, inp.ELE)
     system = System_of_equations(body, material, inp.geometric_nonlinear, device=local, verbose=verbose, part=part,
-                                 comm_uid=uid, tangent=tangent, exchange="auto")
+                                 comm_uid=uid, tangent=tangent,
+                                 exchange=os.environ.get("FEMCY_EXCHANGE", "allreduce"))   # or "neighbour" / "auto"
     return system, partition.LocalDeck(inp, part, body), part
 
 
