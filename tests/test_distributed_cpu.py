@@ -123,3 +123,28 @@ def test_distributed_pcg_gloo_world2(tmp_path):
     for p, r in zip(parts, res):
         gd = (p.l2g[:, None] * 3 + np.arange(3)).ravel()
         assert np.abs(r["x"] - x[gd]).max() < 1e-9 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("nranks,axis", [(2, 2), (4, 2), (8, 2), (3, 0)])
+def test_neighbour_lists_pair_up(nranks, axis):
+    """the send / recv segments of the neighbour exchange: rank r lists q iff q lists r, with the same global DOFs in
+    the same order (what makes an ncclSend on one side meet the ncclRecv of the other entry by entry); their union
+    is the rank's interface."""
+    from femcy_amd import meshgen, partition
+    m = meshgen.twist_plate(6, 3, 16)
+    parts = partition.build_all_parts(m["nodes"], m["elements"], nranks, axis=axis)
+    for p in parts:
+        gd = (p.l2g[:, None] * 3 + np.arange(3)).ravel()
+        assert list(p.nb_ranks) == sorted(p.nb_ranks) and p.rank not in p.nb_ranks and p.nb_ptr[0] == 0
+        union = set()
+        for k, q in enumerate(p.nb_ranks):
+            mine = gd[p.nb_dofs[p.nb_ptr[k]:p.nb_ptr[k + 1]]]
+            assert mine.size and np.all(np.diff(mine) > 0)
+            o = parts[q]
+            ko = list(o.nb_ranks).index(p.rank)
+            theirs = (o.l2g[:, None] * 3 + np.arange(3)).ravel()[o.nb_dofs[o.nb_ptr[ko]:o.nb_ptr[ko + 1]]]
+            assert np.array_equal(mine, theirs)
+            union.update(p.nb_dofs[p.nb_ptr[k]:p.nb_ptr[k + 1]].tolist())
+        assert union == set(p.iface_local_dofs.tolist())
+        if axis == 2:
+            assert len(p.nb_ranks) <= 2                      # slabs: at most the ranks below and above
