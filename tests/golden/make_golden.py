@@ -48,6 +48,7 @@ SOLVE_DECKS = [
     "beamDeflec_quadPSE_smallD_load100_fixX.inp", "beamDeflec_quadPSE_smallD_load800_freeEnd.inp",
     "cookMembrane_CPE6_smallDef.inp", "cookMembrane_CPE6_smallDef_3d5MPa.inp",
     "cookMembrane_CPE6_largeDef_3d5MPa.inp",
+    "ellip_dense_CPS3_0d04.inp",      # densest CPS3 deck (NAFEMS LE1 convergence series of the README)
     # generated decks (femcy_amd.meshgen.beam_quad8, written by write_generated_decks() below):
     # BASELINE configs[1] asks for a CPE8 large-deformation beam, which the reference does not ship
     "gen_beam_CPE8_tip4.inp",       # plane strain StVK, 20 x 2 quad8, converges in 4 increments

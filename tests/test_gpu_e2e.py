@@ -30,6 +30,7 @@ CASES = [  # (deck, tolerance)
     ("beamFreeDeflect_CPS6_load_mesh4", 1e-6),            # free-end traction, 68 solves
     ("beamDeflec_quadPSE_largeD_load800_fixX", 1e-6),     # fixX variant of the load-800 beam
     ("ellip_dense_CPS6_0d04", 1e-6),                      # densest linear deck of the reference: 29 252 DOF
+    ("ellip_dense_CPS3_0d04", 1e-6),                      # its CPS3 sibling
     ("cook_3d_quadEl_smallDef", 1e-6),                    # C3D10 small deformation with a surface load
     # the rest of the reference's small decks: mesh-size series of both beams (three runs end with "allowable minimum
     # dt is reached" -- the failure path), small-deformation variants, nu = 0.4999 with CPE3, CPE6 at 3.5 MPa
@@ -133,6 +134,20 @@ def test_readme_known_answer_end_to_end(tmp_path):
     e0 = system.get_elasEng()
     rhs_work = 0.5 * float(system.rhs.to_numpy() @ u)      # linear elasticity: W = 1/2 f.u (Dirichlet values are 0)
     assert e0 > 0 and abs(e0 - rhs_work) < 1e-3 * e0       # Green strain in the energy: equal up to O(|grad u|)
+    system.ctx.close()
+
+
+def test_nafems_le1_target_on_the_dense_deck():
+    """a reference-independent known answer: the elliptic membrane is NAFEMS LE1, target sigma_yy at D = 92.7 MPa
+    (README.md:46).  The reference's densest CPS6 deck, solved and post-processed on the device, gives 92.72."""
+    system, u = run_keep("ellip_dense_CPS6_0d04")
+    system.compute_strain_stress()
+    nodal = system.ELE.extrapolate(system.cauchy_stress, None, comp=3)          # sigma_yy
+    nodes, el = system.body.np_nodes, system.body.np_elements
+    nD = int(np.argmin(np.linalg.norm(nodes - np.array([2., 0.]), axis=1)))
+    e, a = np.where(el == nD)
+    assert np.allclose(nodes[nD], [2., 0.]) and e.size == 1
+    assert abs(nodal[e[0], a[0]] - 92.7) < 0.05 and abs(nodal[e[0], a[0]] - 92.71796) < 1e-4
     system.ctx.close()
 
 
