@@ -85,6 +85,7 @@ struct Ctx {
     double mat_params[4] = {0, 0, 0, 0};
     double h_C[36] = {0};             // host copy of C (the consistent tangent reads lambda, mu from it)
     bool have_mesh = false, have_element = false, have_material = false, have_pattern = false;
+    bool dN_sums_to_zero = false;     // element tables satisfy sum_a dN_a = 0 (partition of unity)
 
     // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
     int32_t nslices = 0;

@@ -221,7 +221,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
     CTX_OR_FAIL(ctx);
     switch (option) {
         case FEMCY_OPT_ASSEMBLY:
-            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_GATHER_SYM, "bad assembly mode %lld", (long long)value);
+            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_GATHER_SYM_ROWSUM, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
         case FEMCY_OPT_PCG_POLL:
@@ -357,6 +357,19 @@ int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN, const doubl
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     c->nGP = nGP;
     c->voigt = voigt_kind;
+    // partition of unity of the plugin's shape functions, as far as the kernels see it: sum_a dN_a = 0 at every Gauss
+    // point (enables the row-sum diagonal of the assembly; a plugin that violates it keeps the plain sum)
+    c->dN_sums_to_zero = true;
+    for (int32_t g = 0; g < nGP; ++g)
+        for (int32_t d = 0; d < c->dm; ++d) {
+            double sum = 0.0, mag = 0.0;
+            for (int32_t a = 0; a < c->npe; ++a) {
+                const double v = dN[((size_t)g * c->npe + a) * c->dm + d];
+                sum += v;
+                mag += std::fabs(v);
+            }
+            if (std::fabs(sum) > 1e-13 * std::max(mag, 1e-300)) c->dN_sums_to_zero = false;
+        }
     c->s = (c->dm == 2) ? 3 : 6;
     int rc;
     if ((rc = dev_alloc(&c->d_dN, (size_t)nGP * c->npe * c->dm, false))) return rc;

@@ -81,8 +81,10 @@ enum femcy_assembly {
     FEMCY_ASM_GATHER = 0, /* owner-computes: one lane per stored block, deterministic            */
     FEMCY_ASM_ATOMIC = 1, /* element scatter with f64 HW atomics (comparison / race check)        */
     FEMCY_ASM_ROWS = 2,   /* one wavefront per matrix row, LDS reduction, deterministic           */
-    FEMCY_ASM_AUTO = 3,   /* default: ROWS for npe > 4 (measured 1.8x on C3D10), GATHER_SYM otherwise */
-    FEMCY_ASM_GATHER_SYM = 4 /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
+    FEMCY_ASM_AUTO = 3,   /* default: ROWS for npe > 4 (measured 1.8x on C3D10), GATHER_SYM(_ROWSUM) otherwise */
+    FEMCY_ASM_GATHER_SYM = 4, /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
+    FEMCY_ASM_GATHER_SYM_ROWSUM = 5 /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
+                                unity, checked on the element tables); AUTO picks it for npe <= 4 */
 };
 
 enum femcy_option {

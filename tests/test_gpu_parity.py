@@ -59,7 +59,7 @@ def smooth_disp(nodes, scale):
 
 
 @pytest.mark.parametrize("name", DECKS)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_assemble_K(gpu_ctx_factory, name, mode):
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
@@ -194,6 +194,38 @@ def test_user_defined_element_plugins(gpu_ctx_factory):
             ctx2.upload(be.VEC_DOF, u)
             ctx2.assemble_K(be.VEC_DOF)
             assert abs(ctx2.get_K_bsr().tocsr() - K).max() > 1e-6 * abs(Ko).max()
+
+
+def test_rowsum_diagonal_needs_partition_of_unity(gpu_ctx_factory):
+    """the default C3D4 / CPS3 / CPS4 assembly takes the diagonal block from K_aa = -sum_b K_ab, which holds when the
+    plugin's shape functions sum to one.  A plugin that breaks it (here: a perturbed derivative table) is detected in
+    femcy_set_element: AUTO falls back to the summed diagonal, the explicit mode is refused."""
+    from femcy_amd import backend as be
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+
+    class Broken(Element_linear_tetrahedral):
+        def tables(self):
+            t = dict(super().tables())
+            t["dN"] = t["dN"].copy()
+            t["dN"][0, 0, 0] += 1e-3                     # sum_a dN_a != 0
+            return t
+
+    inp, et, el, mat = load("twist_plate_C3D4.inp")
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(inp.nodes, el)
+    ctx.set_element(Broken())
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    ctx.assemble_K(-1)                                   # AUTO
+    K_auto = ctx.get_K_bsr().tocsr()
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_GATHER)
+    ctx.assemble_K(-1)
+    assert abs(ctx.get_K_bsr().tocsr() - K_auto).max() <= 1e-12 * abs(K_auto).max()
+    assert np.isfinite(K_auto.data).all()
+    assert abs(K_auto @ np.ones(ctx.n)).max() > 1e-6 * abs(K_auto).max()      # rows do not sum to zero here
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_GATHER_SYM_ROWSUM)
+    with pytest.raises(be.FemcyError, match="sum_a dN_a"):
+        ctx.assemble_K(-1)
 
 
 @pytest.mark.parametrize("name", DECKS)
@@ -451,7 +483,7 @@ def test_single_element_against_golden_vectors(gpu_ctx_factory, name, etype):
     ctx.set_material(mat)
     info = ctx.build_pattern()
     assert info.nnzb == ids.size ** 2 and info.nslices == 1
-    for mode in (be.ASM_GATHER, be.ASM_ROWS, be.ASM_ATOMIC, be.ASM_GATHER_SYM):
+    for mode in (be.ASM_GATHER, be.ASM_ROWS, be.ASM_ATOMIC, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(-1)
         K = ctx.get_K_bsr().toarray()

@@ -46,7 +46,7 @@ def main():
     for d in range(3):
         user_api.user_dirichletBC_values(u, tw, 3, d, m["nodes"], 0.05)
     ctx.upload(be.VEC_DOF, u)
-    for mode, nm in ((be.ASM_GATHER, "gather"), (be.ASM_GATHER_SYM, "gather-sym"), (be.ASM_ROWS, "rows"),
+    for mode, nm in ((be.ASM_GATHER, "gather"), (be.ASM_GATHER_SYM, "gather-sym"), (be.ASM_GATHER_SYM_ROWSUM, "gather-sym-rowsum"), (be.ASM_ROWS, "rows"),
                      (be.ASM_ATOMIC, "atomic")):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         t = timeit(lambda: ctx.assemble_K(be.VEC_DOF), 20)
