@@ -445,9 +445,14 @@ __global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos
                                                                     const double* __restrict__ Fg,
                                                                     const double* __restrict__ Sg, bool neo,
                                                                     double lam, double mu, double p0, double p1,
+                                                                    const int32_t* __restrict__ tpos, int skip_diag,
                                                                     double* __restrict__ Kvals) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npos) return;
+    // the tangent is symmetric and its rows sum to zero as well (sum_b gradN_b = 0 in the material and in the
+    // geometric part): upper blocks only, mirrored stores, diagonal from k_diag_from_rowsum -- see k_assemble_gather
+    const int32_t tp = tpos[p];
+    if (tp == -2 || (skip_diag && tp == (int32_t)p)) return;
     double acc[DM * DM];
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) acc[k] = 0.0;
@@ -468,6 +473,14 @@ __global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos
     const int lane = (int)(p & 63);
 #pragma unroll
     for (int k = 0; k < DM * DM; ++k) Kvals[kv_index<DM>(row, k, lane)] = acc[k];
+    if (tp >= 0 && tp != (int32_t)p) {
+        const int64_t trow = tp >> 6;
+        const int tlane = tp & 63;
+#pragma unroll
+        for (int r = 0; r < DM; ++r)
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) Kvals[kv_index<DM>(trow, cc * DM + r, tlane)] = acc[r * DM + cc];
+    }
 }
 
 // owner-computes assembly: lane p = stored block (row = p / 64, lane = p % 64).
@@ -1170,14 +1183,25 @@ int launch_assemble(Ctx* c) {
         const double lam = c->h_C[0 * s + 1], mu = c->h_C[(s - 1) * s + (s - 1)];     // isotropic C: C01, C(shear,shear)
         const int64_t npos = c->stored_rows * SLICE;
         const int grid = (int)((npos + bs - 1) / bs);
+        const int skip = c->dN_sums_to_zero ? 1 : 0;
         if (c->dm == 3)
             hipLaunchKernelGGL((k_assemble_gather_consistent<3>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
                                c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_F, c->d_sigma, neo, lam, mu,
-                               c->mat_params[0], c->mat_params[1], c->d_Kvals);
+                               c->mat_params[0], c->mat_params[1], c->d_tpos, skip, c->d_Kvals);
         else
             hipLaunchKernelGGL((k_assemble_gather_consistent<2>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP,
                                c->d_ctr_ptr, c->d_ctr, c->d_dsdx, c->d_vol, c->d_F, c->d_sigma, neo, lam, mu,
-                               c->mat_params[0], c->mat_params[1], c->d_Kvals);
+                               c->mat_params[0], c->mat_params[1], c->d_tpos, skip, c->d_Kvals);
+        if (skip) {
+            const int64_t nposd = (int64_t)c->nslices * SLICE;
+            const int gd = (int)((nposd + bs - 1) / bs);
+            if (c->dm == 3)
+                hipLaunchKernelGGL((k_diag_from_rowsum<3>), dim3(gd), dim3(bs), 0, c->stream, c->nslices, c->d_node_of,
+                                   c->d_rowlen, c->d_slice_off, c->d_Kvals);
+            else
+                hipLaunchKernelGGL((k_diag_from_rowsum<2>), dim3(gd), dim3(bs), 0, c->stream, c->nslices, c->d_node_of,
+                                   c->d_rowlen, c->d_slice_off, c->d_Kvals);
+        }
         timing_end(c, th);
         FEMCY_HIP(hipGetLastError());
         return FEMCY_OK;
