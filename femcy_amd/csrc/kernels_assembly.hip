@@ -187,6 +187,23 @@ __device__ __forceinline__ void cauchy_large<2>(int kind, const double* __restri
     }
 }
 
+// records of W doubles held one per lane -> the workgroup's 256 consecutive records in global memory, written
+// through an LDS transpose so that a wavefront stores 512 consecutive bytes per instruction instead of 64 8-byte
+// pieces 8 W bytes apart (the element pass writes ~100..350 B per element; strided, the stores were its bottleneck)
+template <int W>
+__device__ __forceinline__ void block_store(double* __restrict__ dst, const double (&v)[W], int nvalid, double* lds) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < W; ++i) lds[i * 257 + t] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int q = k * 256 + t;
+        if (q < nvalid * W) dst[q] = lds[(q % W) * 257 + q / W];
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------ geometry
 // one thread per element, Gauss points looped inside (dN[g] is then wave-uniform -> scalar loads)
 template <int NPE, int DM, bool STRESS>
@@ -197,8 +214,16 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                                               double* __restrict__ dsdx, double* __restrict__ vol,
                                               double* __restrict__ Fout, double* __restrict__ Sout,
                                               double* __restrict__ fe) {
-    const int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ne) return;
+    // staged stores (block_store) when an element's record is contiguous and small enough for the LDS transpose:
+    // one Gauss point (C3D4, CPS3) for dsdx / F / sigma, always for the per-element nodal forces
+    constexpr int WG = NPE * DM, WT = DM * DM;
+    constexpr bool STAGE = WG <= 16;
+    __shared__ double stage_lds[STAGE ? 257 * WG : 1];
+    const int32_t e0 = blockIdx.x * blockDim.x;
+    const int nvalid = min(256, ne - e0);
+    const bool valid = (int)threadIdx.x < nvalid;
+    const int32_t e = valid ? e0 + (int32_t)threadIdx.x : ne - 1;      // idle lanes recompute the last element, store nothing
+    const bool staged = STAGE && nGP == 1;
     double X[NPE][DM], U[NPE][DM];
     // per-element nodal forces fe[a][:] = sum_g gradN_a . sigma * vol (internal force only): the node gather then
     // reads dm doubles per incident element instead of a gradient row, a stress tensor and a weight
@@ -232,7 +257,7 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
             }
         const double det = det_inv<DM>(J, inv);
         if (dsdx) {   // post-processing recomputes F / sigma without touching the stored geometry
-            double* out = dsdx + ((int64_t)e * nGP + g) * NPE * DM;
+            double G[WG];
 #pragma unroll
             for (int a = 0; a < NPE; ++a)
 #pragma unroll
@@ -240,9 +265,16 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                     double acc = 0.0;
 #pragma unroll
                     for (int k = 0; k < DM; ++k) acc += dNg[a * DM + k] * inv[k][j];
-                    out[a * DM + j] = acc;
+                    G[a * DM + j] = acc;
                 }
-            vol[(int64_t)e * nGP + g] = det * w[g];
+            if (staged) {
+                if constexpr (STAGE) block_store<WG>(dsdx + (int64_t)e0 * WG, G, nvalid, stage_lds);
+            } else if (valid) {
+                double* out = dsdx + ((int64_t)e * nGP + g) * WG;
+#pragma unroll
+                for (int i = 0; i < WG; ++i) out[i] = G[i];
+            }
+            if (valid) vol[(int64_t)e * nGP + g] = det * w[g];
         }
 
         if (STRESS) {
@@ -278,18 +310,36 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
             }
 #pragma unroll
             for (int i = 0; i < DM; ++i) F[i][i] += 1.0;
-            double* fo = Fout + ((int64_t)e * nGP + g) * DM * DM;
-#pragma unroll
-            for (int i = 0; i < DM; ++i)
-#pragma unroll
-                for (int j = 0; j < DM; ++j) fo[i * DM + j] = F[i][j];
-            if (Sout) {   // get_deformation_gradient alone (post-processing) leaves the stored stress untouched
-                cauchy_large<DM>(mat_kind, C, p0, p1, F, sig);
-                double* so = Sout + ((int64_t)e * nGP + g) * DM * DM;
+            {
+                double Fl[WT];
 #pragma unroll
                 for (int i = 0; i < DM; ++i)
 #pragma unroll
-                    for (int j = 0; j < DM; ++j) so[i * DM + j] = sig[i][j];
+                    for (int j = 0; j < DM; ++j) Fl[i * DM + j] = F[i][j];
+                if (staged) {
+                    if constexpr (STAGE) block_store<WT>(Fout + (int64_t)e0 * WT, Fl, nvalid, stage_lds);
+                } else if (valid) {
+                    double* fo = Fout + ((int64_t)e * nGP + g) * WT;
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) fo[i] = Fl[i];
+                }
+            }
+            if (Sout) {   // get_deformation_gradient alone (post-processing) leaves the stored stress untouched
+                cauchy_large<DM>(mat_kind, C, p0, p1, F, sig);
+                {
+                    double Sl[WT];
+#pragma unroll
+                    for (int i = 0; i < DM; ++i)
+#pragma unroll
+                        for (int j = 0; j < DM; ++j) Sl[i * DM + j] = sig[i][j];
+                    if (staged) {
+                        if constexpr (STAGE) block_store<WT>(Sout + (int64_t)e0 * WT, Sl, nvalid, stage_lds);
+                    } else if (valid) {
+                        double* so = Sout + ((int64_t)e * nGP + g) * WT;
+#pragma unroll
+                        for (int i = 0; i < WT; ++i) so[i] = Sl[i];
+                    }
+                }
                 if (fe) {
                     const double vg = det * w[g];
 #pragma unroll
@@ -315,11 +365,18 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
         }
     }
     if (STRESS && fe) {
-        double* out = fe + (int64_t)e * NPE * DM;
+        double Fe[WG];
 #pragma unroll
         for (int a = 0; a < NPE; ++a)
 #pragma unroll
-            for (int i = 0; i < DM; ++i) out[a * DM + i] = facc[STRESS ? a : 0][i];
+            for (int i = 0; i < DM; ++i) Fe[a * DM + i] = facc[STRESS ? a : 0][i];
+        if constexpr (STAGE) {
+            block_store<WG>(fe + (int64_t)e0 * WG, Fe, nvalid, stage_lds);
+        } else if (valid) {
+            double* out = fe + (int64_t)e * WG;
+#pragma unroll
+            for (int i = 0; i < WG; ++i) out[i] = Fe[i];
+        }
     }
 }
 
