@@ -148,3 +148,30 @@ def test_neighbour_lists_pair_up(nranks, axis):
         assert union == set(p.iface_local_dofs.tolist())
         if axis == 2:
             assert len(p.nb_ranks) <= 2                      # slabs: at most the ranks below and above
+
+
+def test_local_deck_splits_boundary_conditions():
+    """partition.LocalDeck: every loaded facet lands on exactly one rank (the one holding its element), node sets
+    keep exactly the nodes a rank holds, shared nodes appear on every rank that holds them."""
+    from helpers import deck
+    from femcy_amd import partition
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck("cook_3d_linearEl_largeDef.inp"))
+    el = inp.eSets["C3D4"]
+    parts = partition.build_all_parts(inp.nodes, el, 3, axis=0)
+    decks = [partition.LocalDeck(inp, p, Body(p.nodes, p.elements, inp.ELE)) for p in parts]
+    for k, nb in enumerate(inp.neumann_bc_info):
+        seen = []
+        for p, d in zip(parts, decks):
+            assert d.neumann_bc_info[k]["traction"] == nb["traction"]
+            seen += [tuple(sorted(p.l2g[list(f)].tolist())) for f in d.neumann_bc_info[k]["face_set"]]
+        assert sorted(seen) == sorted(tuple(sorted(f)) for f in nb["face_set"])          # once each, none lost
+    for k, bc in enumerate(inp.dirichlet_bc_info):
+        glob = set(np.asarray(bc["node_set"]).tolist())
+        back = set()
+        for p, d in zip(parts, decks):
+            loc = np.asarray(d.dirichlet_bc_info[k]["node_set"])
+            assert set(p.l2g[loc].tolist()) == glob & set(p.l2g.tolist())
+            back |= set(p.l2g[loc].tolist())
+        assert back == glob and d.dirichlet_bc_info[k]["dof"] == bc["dof"]
