@@ -7,7 +7,7 @@ so that (a) the -m gpu suite can compare the HIP path without re-running 40 s Ne
 CPU and (b) any later change to the oracle that moves a result is caught by the CPU suite.
 
     python tests/golden/make_golden.py            # solves the decks that are not in oracle_solutions.npz yet
-    python tests/golden/make_golden.py --all      # re-solves everything (about 10 minutes)
+    python tests/golden/make_golden.py --all      # re-solves everything (about 85 minutes, 71 of them the C3D10 twist)
 """
 import os
 import sys
@@ -49,6 +49,7 @@ SOLVE_DECKS = [
     "cookMembrane_CPE6_smallDef.inp", "cookMembrane_CPE6_smallDef_3d5MPa.inp",
     "cookMembrane_CPE6_largeDef_3d5MPa.inp",
     "ellip_dense_CPS3_0d04.inp",      # densest CPS3 deck (NAFEMS LE1 convergence series of the README)
+    "twist_plate_C3D10.inp",          # the full C3D10 twist: 225 increments, 2923 solves -- 71 minutes of numpy oracle
     # generated decks (femcy_amd.meshgen.beam_quad8, written by write_generated_decks() below):
     # BASELINE configs[1] asks for a CPE8 large-deformation beam, which the reference does not ship
     "gen_beam_CPE8_tip4.inp",       # plane strain StVK, 20 x 2 quad8, converges in 4 increments

@@ -23,6 +23,7 @@ CASES = [  # (deck, tolerance)
     ("beamDeflec_quadPSE_largeD_load800", 1e-6),          # CPS6 large deformation, traction load
     ("twist_plate_C3D4", 1e-6),                           # 180 degree twist, user Dirichlet BC, 186 solves
     ("cookMembrane_2d_linearEl_largeDef", 1e-6),          # CPE3 plane strain large deformation, 670 solves
+    ("twist_plate_C3D10", 1e-6),                          # the full C3D10 twist deck: 225 increments, 2923 solves
     ("twist_C3D10_coarse", 1e-6),                         # C3D10 twist (BASELINE configs[4] element), 1184 solves
     ("cookMembrane_CPE6_largeDef", 1e-6),                 # CPE6 plane strain large deformation, 190 solves
     ("cookMembrane_CPE6_largeDef_5MPa", 1e-6),            # same at a higher load: 213 solves
