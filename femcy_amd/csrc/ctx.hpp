@@ -55,8 +55,8 @@ struct PcgState {
                      // solve-independent and a burst of iterations can be replayed from a hipGraph)
     int32_t iters;   // completed iterations (written by k_update_d, read by k_update_xr of the next iteration)
     int32_t it_k3;   // iteration index handed from k_update_xr to k_update_d
-    int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown
-    int32_t pad_;
+    int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown: written by k_update_d, tested by k_spmv / k_update_xr
+    int32_t skip;    // `done` as k_update_xr saw it, handed to the k_update_d of the same iteration
 };
 
 // contiguous slice range of each XCD for the SpMV (balanced by stored blocks), passed by value

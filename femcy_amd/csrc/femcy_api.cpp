@@ -160,7 +160,8 @@ int femcy_ctx_create(int device, femcy_ctx** out) {
         return FEMCY_EHIP;
     }
     int rc = FEMCY_OK;
-    if ((rc = dev_alloc(&c->d_part1, (size_t)MAX_PARTIALS)) || (rc = dev_alloc(&c->d_part2, (size_t)2 * MAX_PARTIALS)) ||
+    // + a zero slot behind each partial array (read by out-of-range lanes of the PCG kernels, never written)
+    if ((rc = dev_alloc(&c->d_part1, (size_t)MAX_PARTIALS + 8)) || (rc = dev_alloc(&c->d_part2, (size_t)2 * MAX_PARTIALS + 8)) ||
         (rc = dev_alloc(&c->d_state, 1))) {
         delete ctx;
         return rc;

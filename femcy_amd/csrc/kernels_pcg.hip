@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(BS) k_pcg_init_final(int np, const double* __r
         st->it_k3 = 0;
         st->eps = eps;
         st->done = (m == 0.0) ? 1 : ((m != m || isinf(m)) ? 2 : 0);
+        st->skip = st->done ? 1 : 0;
     }
 }
 
@@ -278,51 +279,96 @@ __device__ __forceinline__ void st2(double2* p, double2 v) {
     }
 }
 
+// Element-wise PCG kernels.  A thread owns up to VU double2 elements per batch, base + u * stride, and issues the
+// loads of the whole batch before anything else, so that one memory round trip (instead of one per element) hides
+// under the scalar prologue that re-reduces the producer's partials.  At 548 535 DOF and the default 512-workgroup
+// cap a thread holds 2.09 elements: one batch.
+constexpr int VU = 4;
+constexpr int PU = 4;    // d.Ad partials prefetched per thread (covers 1024 SpMV workgroups; more are looped)
+constexpr int PU2 = 2;   // (r.M.r, max|r|) pairs prefetched per thread (covers the default 512-workgroup cap)
+
 // r -= alpha Ad with alpha = r.M.r / d.Ad, partials of (r.M.r, max|r|) of the new r; alpha is published for k_update_d,
 // which applies x += alpha d in the pass where it reads d anyway (x would otherwise be the only reason for this
-// kernel to load d: 8 n bytes per iteration)
-template <bool NT>
+// kernel to load d: 8 n bytes per iteration).
+// Stop flag: `done` is written by k_update_d only and tested by k_spmv / k_update_xr only; k_update_xr hands it to
+// k_update_d as `skip`.  No kernel tests a word that a workgroup of the same launch writes (a late workgroup of
+// k_update_d could otherwise see the flag its block 0 had just set and drop the x / d update of the converging
+// iteration).
+template <bool NT, bool MULTI>
 __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const double* __restrict__ part1,
                                                   const double* __restrict__ dAd_reduced, PcgState* st,
                                                   const double2* __restrict__ Ad, const double2* __restrict__ M,
                                                   double2* __restrict__ r, const uint8_t* __restrict__ owner,
                                                   double* __restrict__ part2) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
-    if (st->done) return;
-    // issue the first tile's loads before the scalar prologue so the partial reduction hides under them
-    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (st->done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->skip = 1;
+        return;
+    }
     const int64_t stride = (int64_t)gridDim.x * BS;
     const double2 z2 = make_double2(0.0, 0.0);
-    double2 av = z2, mv = z2, rv = z2;
-    if (i < n2) {
-        av = ld2<NT>(Ad + i);
-        mv = ld2<NT>(M + i);
-        rv = ld2<NT>(r + i);
+    int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
+    // the producer's partials first (VMEM returns in order: loaded after the batch they would only arrive behind it)
+    double pv[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int k = threadIdx.x + u * BS;            // branch-free (out-of-range lanes read the always-zero slot
+        pv[u] = MULTI ? 0.0 : part1[k < np1 ? k : MAX_PARTIALS];   // behind the array): the compiler can then count the
+    }                                                  // loads -- vmcnt(N) instead of a full drain before the first use
+    double2 av[VU], mv[VU], rv[VU];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+        const int64_t i = min(base + u * stride, n2 - 1);
+        av[u] = ld2<NT>(Ad + i);
+        mv[u] = ld2<NT>(M + i);
+        rv[u] = ld2<NT>(r + i);
     }
     const int it = st->iters;                       // stable: written by the previous iteration's k_update_d
-    const double dAd = dAd_reduced ? *dAd_reduced : reduce_partials_sum(part1, np1, sm1);
+    double dAd;
+    if (MULTI) {                                    // multi-rank: d.Ad was reduced over the ranks by the exchange
+        dAd = *dAd_reduced;
+    } else {
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < PU; ++u) v += pv[u];
+        for (int k = threadIdx.x + PU * BS; k < np1; k += BS) v += part1[k];
+        dAd = block_sum(v, sm1);
+    }
     const double alpha = st->rMr[it & 1] / dAd;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->it_k3 = it;
         st->alpha = alpha;
+        st->skip = 0;
     }
     double rMr = 0.0, rm = 0.0;
-    while (i < n2) {
-        rv.x = rv.x - alpha * av.x;
-        rv.y = rv.y - alpha * av.y;
-        st2<NT>(r + i, rv);
-        double w0 = 1.0, w1 = 1.0;
-        if (owner) {
-            w0 = owner[2 * i];
-            w1 = owner[2 * i + 1];
+    while (base < n2) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int64_t i = base + u * stride;
+            if (i < n2) {
+                rv[u].x = rv[u].x - alpha * av[u].x;
+                rv[u].y = rv[u].y - alpha * av[u].y;
+                st2<NT>(r + i, rv[u]);
+                double w0 = 1.0, w1 = 1.0;
+                if (owner) {
+                    w0 = owner[2 * i];
+                    w1 = owner[2 * i + 1];
+                }
+                rMr += w0 * (rv[u].x * mv[u].x * rv[u].x) + w1 * (rv[u].y * mv[u].y * rv[u].y);
+                rm = fmax(rm, fmax(nan_to_inf_abs(rv[u].x), nan_to_inf_abs(rv[u].y)));
+            }
         }
-        rMr += w0 * (rv.x * mv.x * rv.x) + w1 * (rv.y * mv.y * rv.y);
-        rm = fmax(rm, fmax(nan_to_inf_abs(rv.x), nan_to_inf_abs(rv.y)));
-        i += stride;
-        if (i < n2) {
-            av = ld2<NT>(Ad + i);
-            mv = ld2<NT>(M + i);
-            rv = ld2<NT>(r + i);
+        base += VU * stride;
+        if (base < n2) {
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int64_t i = base + u * stride;
+                if (i < n2) {
+                    av[u] = ld2<NT>(Ad + i);
+                    mv[u] = ld2<NT>(M + i);
+                    rv[u] = ld2<NT>(r + i);
+                }
+            }
         }
     }
     const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
@@ -339,28 +385,38 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
                                                  const double2* __restrict__ M, double2* __restrict__ d,
                                                  double2* __restrict__ x) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
-    if (st->done) return;
-    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (st->skip) return;                           // written by this iteration's k_update_xr, never by this kernel
     const int64_t stride = (int64_t)gridDim.x * BS;
     const double2 z2 = make_double2(0.0, 0.0);
-    double2 rv = z2, mv = z2, dv = z2, xv = z2;
-    if (i < n2) {           // first tile in flight while the scalars are reduced
-        rv = ld2<NT>(r + i);
-        mv = ld2<NT>(M + i);
-        dv = ld2<NT>(d + i);
-        xv = ld2<NT>(x + i);
+    int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
+    // (r.M.r, max|r|) pairs of k_update_xr first, then the batch (in-order VMEM returns, see k_update_xr)
+    const double* __restrict__ pairs = gathered ? gathered : part2;
+    const int npairs = gathered ? nranks : np2;
+    const int zslot = gathered ? nranks : MAX_PARTIALS;   // a (0, 0) pair behind either array that nothing ever writes
+    double2 pp[PU2];
+#pragma unroll
+    for (int u = 0; u < PU2; ++u) {
+        const int k = threadIdx.x + u * BS;            // branch-free through the zero slot (see k_update_xr)
+        pp[u] = *reinterpret_cast<const double2*>(pairs + 2 * (k < npairs ? k : zslot));
+    }
+    double2 rv[VU], mv[VU], dv[VU], xv[VU];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {                  // first batch in flight while the scalars are reduced
+        const int64_t i = min(base + u * stride, n2 - 1);
+        rv[u] = ld2<NT>(r + i);
+        mv[u] = ld2<NT>(M + i);
+        dv[u] = ld2<NT>(d + i);
+        xv[u] = ld2<NT>(x + i);
     }
     double s = 0.0, m = 0.0;
-    if (gathered) {
-        for (int k = threadIdx.x; k < nranks; k += BS) {
-            s += gathered[2 * k];
-            m = fmax(m, gathered[2 * k + 1]);
-        }
-    } else {
-        for (int k = threadIdx.x; k < np2; k += BS) {
-            s += part2[2 * k];
-            m = fmax(m, part2[2 * k + 1]);
-        }
+#pragma unroll
+    for (int u = 0; u < PU2; ++u) {
+        s += pp[u].x;
+        m = fmax(m, pp[u].y);
+    }
+    for (int k = threadIdx.x + PU2 * BS; k < npairs; k += BS) {
+        s += pairs[2 * k];
+        m = fmax(m, pairs[2 * k + 1]);
     }
     const double rMr_new = block_sum(s, sm1);
     const double rmax = block_max(m, sm2);
@@ -370,19 +426,31 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     const double rMr_old = st->rMr[it & 1];
     const double r0 = st->r0;
     const double beta = rMr_new / rMr_old;
-    while (i < n2) {
-        xv.x = xv.x + alpha * dv.x;
-        xv.y = xv.y + alpha * dv.y;
-        dv.x = mv.x * rv.x + beta * dv.x;
-        dv.y = mv.y * rv.y + beta * dv.y;
-        st2<NT>(x + i, xv);
-        st2<NT>(d + i, dv);
-        i += stride;
-        if (i < n2) {
-            rv = ld2<NT>(r + i);
-            mv = ld2<NT>(M + i);
-            dv = ld2<NT>(d + i);
-            xv = ld2<NT>(x + i);
+    while (base < n2) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int64_t i = base + u * stride;
+            if (i < n2) {
+                xv[u].x = xv[u].x + alpha * dv[u].x;
+                xv[u].y = xv[u].y + alpha * dv[u].y;
+                dv[u].x = mv[u].x * rv[u].x + beta * dv[u].x;
+                dv[u].y = mv[u].y * rv[u].y + beta * dv[u].y;
+                st2<NT>(x + i, xv[u]);
+                st2<NT>(d + i, dv[u]);
+            }
+        }
+        base += VU * stride;
+        if (base < n2) {
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int64_t i = base + u * stride;
+                if (i < n2) {
+                    rv[u] = ld2<NT>(r + i);
+                    mv[u] = ld2<NT>(M + i);
+                    dv[u] = ld2<NT>(d + i);
+                    xv[u] = ld2<NT>(x + i);
+                }
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -722,11 +790,12 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
                                    c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
             dAd_red = slot;
         }
-#define FEMCY_XR(NT_)                                                                                              \
-    hipLaunchKernelGGL(k_update_xr<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red, c->d_state, \
-                       (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                            \
+#define FEMCY_XR(NT_, MU_)                                                                                         \
+    hipLaunchKernelGGL((k_update_xr<NT_, MU_>), dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red,       \
+                       c->d_state, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                \
                        (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
-        if (c->vec_nt) FEMCY_XR(true); else FEMCY_XR(false);
+        if (multi) { if (c->vec_nt) FEMCY_XR(true, true); else FEMCY_XR(false, true); }
+        else       { if (c->vec_nt) FEMCY_XR(true, false); else FEMCY_XR(false, false); }
 #undef FEMCY_XR
         if (multi) {
             double* pair = c->d_commbuf + c->niface_global + 2;

@@ -82,6 +82,26 @@ def spatial_renumber(nodes: np.ndarray, el: np.ndarray):
     return np.ascontiguousarray(nodes[order]), new_id[el].astype(np.int32)
 
 
+def plate_slab(nx: int, ny: int, nz: int, z0: int, z1: int, box: Tuple[float, float, float] = BOX):
+    """cell layers [z0, z1) of the (nx, ny, nz) plate, built without the global mesh: local nodes (the node planes
+    z0 .. z1, in global order), local tets (the same Kuhn split and node order as `plate_grid`, so a slab is
+    element for element the corresponding range of the global mesh) and l2g (global id of every local node)."""
+    assert 0 <= z0 < z1 <= nz
+    xs = np.linspace(0.0, box[0], nx + 1)
+    ys = np.linspace(0.0, box[1], ny + 1)
+    zs = np.linspace(0.0, box[2], nz + 1)[z0:z1 + 1]
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    nodes = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    plane = (nx + 1) * (ny + 1)
+    sx, sy, sz = 1, nx + 1, plane
+    iz, iy, ix = np.meshgrid(np.arange(z1 - z0), np.arange(ny), np.arange(nx), indexing="ij")
+    base = (ix * sx + iy * sy + iz * sz).ravel().astype(np.int32)
+    corner_off = np.array([(c & 1) * sx + ((c >> 1) & 1) * sy + ((c >> 2) & 1) * sz for c in range(8)], dtype=np.int32)
+    tets = base[:, None, None] + corner_off[_kuhn_local()][None, :, :]
+    l2g = np.arange(z0 * plane, (z1 + 1) * plane, dtype=np.int64)
+    return nodes, tets.reshape(-1, 4).astype(np.int32, copy=False), l2g
+
+
 def twist_plate(nx: int, ny: int, nz: int, quadratic: bool = False, renumber: bool = False) -> Dict:
     """the twist-plate model on an (nx,ny,nz)-cell grid, in the reader's vocabulary."""
     nodes, el = plate_grid(nx, ny, nz)
@@ -100,6 +120,17 @@ def twist_plate(nx: int, ny: int, nz: int, quadratic: bool = False, renumber: bo
             "elastic": (2.0e11, 0.3), "geometric_nonlinear": True,
             "time_incs": {"ini_inc": 0.05, "max_time": 1.0, "min_inc": 1e-5, "max_inc": 0.05},
             "cells": (nx, ny, nz)}
+
+
+def twist_plate_bcs(nodes: np.ndarray):
+    """the twist model's *Boundary blocks on a (sub-)mesh of the plate: (dirichlet_bc_info, node_sets) with node ids
+    local to `nodes` -- a z-slab that touches neither end face gets empty sets."""
+    tol = 1e-9 * BOX[2]
+    clamp = np.nonzero(np.abs(nodes[:, 2] - BOX[2]) < tol)[0]
+    twist = np.nonzero(np.abs(nodes[:, 2]) < tol)[0]
+    dirichlet = ([{"node_set": clamp, "dof": d, "val": 0.0, "user": False} for d in range(3)] +
+                 [{"node_set": twist, "dof": d, "val": 0.0, "user": True} for d in range(3)])
+    return dirichlet, {"Set-10": clamp, "fit_right_z": twist}
 
 
 def twist_plate_k(k: int, quadratic: bool = False, renumber: bool = False) -> Dict:

@@ -115,6 +115,51 @@ def build_part(nodes: np.ndarray, elements: np.ndarray, nranks: int, rank: int, 
                 nb_dofs=(np.concatenate(nb_dofs) if nb_dofs else np.zeros(0)).astype(np.int32))
 
 
+def plate_slab_part(nx: int, ny: int, nz: int, nranks: int, rank: int) -> Part:
+    """the z-slab `Part` of rank `rank` of the structured C3D4 twist plate (`meshgen.plate_grid`), built from the
+    rank's own cell layers only -- O(local) host memory and time instead of the O(global) of `build_part`, with
+    identical contents (tests/test_distributed_cpu.py compares them field by field).  Needs nz % nranks == 0, which
+    is what makes `element_ranks` cut on cell layers."""
+    from . import meshgen
+    assert nz % nranks == 0, "z-slab partition of the plate needs nz divisible by the number of ranks"
+    per = nz // nranks
+    z0, z1 = rank * per, (rank + 1) * per
+    nodes, el, l2g = meshgen.plate_slab(nx, ny, nz, z0, z1)
+    plane = (nx + 1) * (ny + 1)
+    dm, comp = 3, np.arange(3)
+    ne_per = 6 * nx * ny * per
+    elem_ids = np.arange(rank * ne_per, (rank + 1) * ne_per, dtype=np.int64)
+    # cut planes: global node plane q * per for q = 1 .. nranks-1, slot = (q-1) * plane + in-plane index
+    lo_cut, hi_cut = rank > 0, rank < nranks - 1
+    nloc = nodes.shape[0]
+    inplane = np.arange(plane, dtype=np.int64)
+    loc_iface, slots = [], []
+    if lo_cut:
+        loc_iface.append(inplane)
+        slots.append((rank - 1) * plane + inplane)
+    if hi_cut:
+        loc_iface.append(nloc - plane + inplane)
+        slots.append(rank * plane + inplane)
+    loc_iface = np.concatenate(loc_iface) if loc_iface else np.zeros(0, dtype=np.int64)
+    slots = np.concatenate(slots) if slots else np.zeros(0, dtype=np.int64)
+    iface_local_dofs = (loc_iface[:, None] * dm + comp[None, :]).ravel().astype(np.int32)
+    iface_global_slot = (slots[:, None] * dm + comp[None, :]).ravel().astype(np.int32)
+    owner = np.ones(nloc * dm, dtype=np.uint8)
+    if lo_cut:
+        owner[:plane * dm] = 0                                      # the lower neighbour (lower rank) owns the cut
+    nb_ranks, nb_ptr, nb_dofs = [], [0], []
+    for q, ids in ((rank - 1, inplane if lo_cut else None), (rank + 1, (nloc - plane + inplane) if hi_cut else None)):
+        if ids is not None:
+            nb_ranks.append(q)
+            nb_dofs.append((ids[:, None] * dm + comp[None, :]).ravel())
+            nb_ptr.append(nb_ptr[-1] + ids.size * dm)
+    return Part(rank=rank, nranks=nranks, elem_ids=elem_ids, l2g=l2g, nodes=nodes, elements=el,
+                iface_local_dofs=iface_local_dofs, iface_global_slot=iface_global_slot,
+                niface_global=int((nranks - 1) * plane * dm), owner=owner, dm=dm,
+                nb_ranks=np.asarray(nb_ranks, dtype=np.int32), nb_ptr=np.asarray(nb_ptr, dtype=np.int32),
+                nb_dofs=(np.concatenate(nb_dofs) if nb_dofs else np.zeros(0)).astype(np.int32))
+
+
 def build_all_parts(nodes, elements, nranks, axis=2) -> List[Part]:
     rank_of = element_ranks(nodes, elements, nranks, axis)
     return [build_part(nodes, elements, nranks, r, axis, rank_of) for r in range(nranks)]

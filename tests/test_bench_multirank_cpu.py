@@ -86,6 +86,8 @@ class MockContext:
     def internal_force(self, u_vec, f_vec):
         from oracle import femcy_oracle as orc
         self.vec[f_vec] = orc.internal_force(self.topo, self.vec[u_vec], self.mat)[0]
+        if self.part is not None:                     # femcy_internal_force sums over the interface itself
+            self.iface_sum(f_vec)
 
     def assemble_K(self, u_vec):
         from oracle import femcy_oracle as orc
@@ -143,7 +145,7 @@ def _worker(rank, world, port, out_dir):
     out = os.open(os.path.join(out_dir, f"stdout{rank}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     os.dup2(out, 1)
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "1", "--iters", "4", "--cells", "4,2,6",
-                "--no-cpu-baseline"]
+                "--no-cpu-baseline", "--prewarm", "0"]
     import bench
     bench.main()
     np.save(os.path.join(out_dir, f"uid{rank}.npy"), np.array([MockContext.uid_calls]))

@@ -175,3 +175,22 @@ def test_local_deck_splits_boundary_conditions():
             assert set(p.l2g[loc].tolist()) == glob & set(p.l2g.tolist())
             back |= set(p.l2g[loc].tolist())
         assert back == glob and d.dirichlet_bc_info[k]["dof"] == bc["dof"]
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4])
+def test_slab_local_part_equals_global_partition(nranks):
+    """bench.py builds each rank's slab (+ interface tables) without the global mesh; it must be the `Part` the
+    global partition gives, field by field, and carry the same boundary-condition node sets."""
+    nx, ny, nz = 4, 2, 12
+    m = meshgen.twist_plate(nx, ny, nz)
+    for r in range(nranks):
+        a = partition.build_part(m["nodes"], m["elements"], nranks, r)
+        b = partition.plate_slab_part(nx, ny, nz, nranks, r)
+        for f in ("elem_ids", "l2g", "nodes", "elements", "iface_local_dofs", "iface_global_slot", "owner", "nb_ranks",
+                  "nb_ptr", "nb_dofs"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (nranks, r, f)
+        assert a.niface_global == b.niface_global and a.dm == b.dm
+        bcs, sets = meshgen.twist_plate_bcs(b.nodes)
+        for bc_l, bc_g in zip(bcs, m["dirichlet_bc_info"]):
+            assert np.array_equal(bc_l["node_set"], a.localize_nodes(bc_g["node_set"]))
+            assert (bc_l["dof"], bc_l["user"]) == (bc_g["dof"], bc_g["user"])

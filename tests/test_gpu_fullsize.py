@@ -130,3 +130,282 @@ def test_fullsize_properties(full):
     assert np.abs(Kx(xs) - bb).max() < 1.0001e-3 * r0
     it2, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
     assert it2 == it and np.array_equal(ctx.download(be.VEC_X), xs)       # run-to-run bit reproducible
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: the ~8 M-element C3D4 plate (k = 24: 7 962 624 elements, 4 183 275 DOF).  (a) on one GPU
+# against the C oracle -- the matrix (1.55 GB) streams from HBM here, so this is the non-temporal / in-kernel-loop
+# branch of the SpMV at the size it was written for; (b) the same mesh cut into 8 z-slabs, one context per slab
+# joined by the in-process transport (the kernels and call sequence of the 8-GPU RCCL run), both interface
+# exchanges, against the single-context result.
+@pytest.fixture(scope="module")
+def full8():
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+    m = meshgen.twist_plate_k(24)
+    assert m["elements"].shape == (7962624, 4) and m["nodes"].shape == (1394425, 3)
+    ctx = be.Context(0)
+    ctx.set_mesh(m["nodes"], m["elements"])
+    ctx.set_element(Element_linear_tetrahedral())
+    ctx.set_material(LinearIsotropic(*m["elastic"]))
+    info = ctx.build_pattern()
+    assert (info.n, info.nnzb, info.max_row_blocks) == (4183275, 20375785, 15)
+    u = np.zeros(ctx.n)
+    cons = []
+    for bc in m["dirichlet_bc_info"]:
+        cons.append(np.asarray(bc["node_set"]) * 3 + bc["dof"])
+        if bc["user"]:
+            user_dirichletBC_values(u, bc["node_set"], 3, bc["dof"], m["nodes"], 0.05)
+    cons = np.unique(np.concatenate(cons))
+    yield dict(be=be, ctx=ctx, m=m, u=u, cons=cons, info=info)
+    ctx.close()
+
+
+def test_8M_single_gpu_against_c_oracle(full8):
+    from helpers import node_adjacency
+    from oracle.c_oracle import COracle
+    from oracle.elements import elem_def
+    from oracle.femcy_oracle import Material
+    be, ctx, u, cons, m = full8["be"], full8["ctx"], full8["u"], full8["cons"], full8["m"]
+    ed = elem_def("C3D4")
+    ptr, idx = node_adjacency(m["elements"], m["nodes"].shape[0])
+    assert idx.size == full8["info"].nnzb                          # the device pattern = the reference's adjacency
+    co = COracle(m["nodes"], m["elements"], ed.dN_table(), ed.gauss_weights, Material("lin3d", m["elastic"]).C, ptr, idx)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.assemble_K(be.VEC_DOF)
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
+    assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy(), co.dsdx) < 1e-12
+    x = np.random.default_rng(0).standard_normal(ctx.n)
+    ctx.upload(be.VEC_TMP0, x)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    y = ctx.download(be.VEC_TMP1)
+    assert rel(y, co.compute_Ad(x)) < 1e-12
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f = co.internal_force(u, 0, *m["elastic"])
+    assert rel(ctx.download(be.VEC_FORCE), f) < 1e-11
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), co.sigma) < 1e-11
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    co.zero_rows_cols_unit_diag(cons)
+    f[cons] = 0.0
+    assert rel(ctx.download(be.VEC_RESIDUAL), f) < 1e-11
+    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+    xo, ito, r0o, rmaxo = co.cg(f, eps=0.0, maxit=30)
+    assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
+    assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+    # size-independent properties at this size
+    rng = np.random.default_rng(2)
+
+    def Kx(v):
+        ctx.upload(be.VEC_TMP0, v)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        return ctx.download(be.VEC_TMP1)
+
+    ctx.assemble_K(be.VEC_DOF)
+    z = rng.standard_normal(ctx.n)
+    Kx1, Kz1 = Kx(x), Kx(z)
+    scale = np.abs(Kx1).max()
+    assert abs(z @ Kx1 - x @ Kz1) < 1e-10 * abs(z @ Kx1)                                   # symmetry
+    assert np.abs(Kx(2.5 * x - 0.5 * z) - (2.5 * Kx1 - 0.5 * Kz1)).max() < 1e-12 * scale   # linearity
+    t = np.zeros(ctx.n)
+    t[1::3] = 1.0
+    assert np.abs(Kx(t)).max() < 1e-9 * scale                                              # rigid translation
+    ctx.assemble_K(be.VEC_DOF)
+    assert np.array_equal(Kx(x), Kx1)                                                      # bit-reproducible assembly
+    ctx.upload(be.VEC_RESIDUAL, f)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    it1, r01, rm1 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-2, maxit=400)
+    xs = ctx.download(be.VEC_X)
+    it2, _, rm2 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-2, maxit=400)
+    assert (it2, rm2) == (it1, rm1) and np.array_equal(ctx.download(be.VEC_X), xs)         # and solve
+    full8["f_dirichlet"] = f
+
+
+def test_8M_eight_slab_partition_equals_single_context(full8):
+    from femcy_amd import meshgen, partition
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from test_gpu_multirank import run_ranks
+    be, ctx, u_g, cons_g, m = full8["be"], full8["ctx"], full8["u"], full8["cons"], full8["m"]
+    nx, ny, nz = m["cells"]
+    nranks = 8
+    rng = np.random.default_rng(7)
+    x_g = rng.standard_normal(ctx.n)
+    # single-context reference on the whole mesh
+    ctx.upload(be.VEC_DOF, u_g)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f_ref = ctx.download(be.VEC_FORCE)
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.upload(be.VEC_TMP0, x_g)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    y_ref = ctx.download(be.VEC_TMP1)
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+    ctx.dirichlet_newton(cons_g, be.VEC_RESIDUAL)
+    hist_ref = []
+    for maxit in (1, 25):
+        res = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=maxit)
+        hist_ref.append((res, ctx.download(be.VEC_X)))
+    uid = be.Context.comm_local_id()
+    plane_dofs = (nx + 1) * (ny + 1) * 3
+
+    def rank_main(r):
+        p = partition.plate_slab_part(nx, ny, nz, nranks, r)      # the rank's own slab only, as bench.py builds it
+        assert p.elements.shape[0] == 995328 and p.niface_global == 7 * plane_dofs
+        c = be.Context(0)
+        try:
+            c.set_mesh(p.nodes, p.elements)
+            c.set_element(Element_linear_tetrahedral())
+            c.set_material(LinearIsotropic(*m["elastic"]))
+            c.build_pattern()
+            c.comm_init(r, nranks, uid, p.iface_local_dofs, p.iface_global_slot, p.niface_global, p.owner)
+            c.comm_set_neighbours(p)
+            bcs, _ = meshgen.twist_plate_bcs(p.nodes)
+            cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in bcs])).astype(np.int32)
+            out = {}
+            for exch in (0, 1):
+                c.set_option(be.OPT_EXCHANGE, exch)
+                c.upload(be.VEC_DOF, p.scatter_global(u_g))
+                c.internal_force(be.VEC_DOF, be.VEC_FORCE)
+                f = c.download(be.VEC_FORCE)
+                c.assemble_K(be.VEC_DOF)
+                c.upload(be.VEC_TMP0, p.scatter_global(x_g))
+                c.spmv(be.VEC_TMP0, be.VEC_TMP1)
+                y = c.download(be.VEC_TMP1)
+                c.vector(be.VEC_RHS).fill(0.0)
+                c.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+                c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+                hist = []
+                for maxit in (1, 25):
+                    res = c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=maxit)
+                    hist.append((res, c.download(be.VEC_X)))
+                out[exch] = (f, y, hist)
+            return p, out
+        finally:
+            c.close()
+
+    outs = run_ranks(nranks, rank_main)
+    sf, sy = np.abs(f_ref).max(), np.abs(y_ref).max()
+    for p, out in outs:
+        for exch in (0, 1):
+            f, y, hist = out[exch]
+            assert np.abs(f - p.scatter_global(f_ref)).max() < 1e-11 * sf
+            assert np.abs(y - p.scatter_global(y_ref)).max() < 1e-12 * sy
+            for ((k, r0k, rmaxk), xk), ((kr, r0r, rmaxr), xr) in zip(hist, hist_ref):
+                assert k == kr and abs(r0k - r0r) <= 1e-12 * r0r and abs(rmaxk - rmaxr) <= 1e-8 * rmaxr
+                assert np.linalg.norm(xk - p.scatter_global(xr)) <= 1e-9 * np.linalg.norm(xr)
+    # every rank saw the same scalars, and the two exchange forms agree with each other
+    for exch in (0, 1):
+        assert len({tuple(h[0] for h in out[exch][2]) for _, out in outs}) == 1
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at bench size: C3D10 twist plate 48 x 6 x 72 cells (124 416 elements, the same 182 845 nodes /
+# 548 535 DOF as the 1 M C3D4 plate), rows of 27..65 blocks: row-centric assembly + 4-wavefront SpMV vs the C oracle.
+@pytest.fixture(scope="module")
+def quad():
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_quadratic_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+    from oracle.c_oracle import COracle
+    from oracle.elements import elem_def
+    from oracle.femcy_oracle import Material
+    from helpers import node_adjacency
+    m = meshgen.twist_plate(48, 6, 72, quadratic=True)
+    assert m["elements"].shape == (124416, 10) and m["nodes"].shape == (182845, 3)
+    ctx = be.Context(0)
+    ctx.set_mesh(m["nodes"], m["elements"])
+    ctx.set_element(Element_quadratic_tetrahedral())
+    ctx.set_material(LinearIsotropic(*m["elastic"]))
+    info = ctx.build_pattern()
+    u = np.zeros(ctx.n)
+    cons = []
+    for bc in m["dirichlet_bc_info"]:
+        cons.append(np.asarray(bc["node_set"]) * 3 + bc["dof"])
+        if bc["user"]:
+            user_dirichletBC_values(u, bc["node_set"], 3, bc["dof"], m["nodes"], 0.05)
+    cons = np.unique(np.concatenate(cons))
+    ed = elem_def("C3D10")
+    ptr, idx = node_adjacency(m["elements"], m["nodes"].shape[0])
+    assert idx.size == info.nnzb and info.max_row_blocks == int(np.diff(ptr).max())
+    co = COracle(m["nodes"], m["elements"], ed.dN_table(), ed.gauss_weights, Material("lin3d", m["elastic"]).C, ptr, idx)
+    yield dict(be=be, ctx=ctx, m=m, u=u, cons=cons, co=co, info=info)
+    ctx.close()
+
+
+def test_c3d10_bench_size_against_c_oracle(quad):
+    be, ctx, u, cons, co, m = quad["be"], quad["ctx"], quad["u"], quad["cons"], quad["co"], quad["m"]
+    ctx.upload(be.VEC_DOF, u)
+    ctx.assemble_K(be.VEC_DOF)                                   # AUTO: the row-centric kernel for npe > 4
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
+    assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy(), co.dsdx) < 1e-12
+    x = np.random.default_rng(0).standard_normal(ctx.n)
+    yo = co.compute_Ad(x)
+    ctx.upload(be.VEC_TMP0, x)
+    ys = {}
+    for wps in (0, 1, 2, 4):                                     # every SpMV variant on the long rows (0 = auto = 4)
+        ctx.set_option(be.OPT_SPMV_VARIANT, wps)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        ys[wps] = ctx.download(be.VEC_TMP1)
+        assert rel(ys[wps], yo) < 1e-12
+    ctx.set_option(be.OPT_SPMV_VARIANT, 0)
+    scale = np.abs(yo).max()
+    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_AUTO):
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        assert np.abs(ctx.download(be.VEC_TMP1) - yo).max() < 1e-12 * scale, mode
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+    assert np.array_equal(ctx.download(be.VEC_TMP1), ys[0])      # the default assembly is bit-reproducible
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f = co.internal_force(u, 0, *m["elastic"])
+    assert rel(ctx.download(be.VEC_FORCE), f) < 1e-11
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), co.sigma) < 1e-11
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+    ctx.assemble_K(be.VEC_DOF)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    co.get_dsdx_and_vol(u)
+    co.assemble()
+    co.zero_rows_cols_unit_diag(cons)
+    f[cons] = 0.0
+    assert rel(ctx.download(be.VEC_RESIDUAL), f) < 1e-11
+    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+    xo, ito, r0o, rmaxo = co.cg(f, eps=0.0, maxit=30)
+    assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
+    assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+    # properties
+    rng = np.random.default_rng(3)
+
+    def Kx(v):
+        ctx.upload(be.VEC_TMP0, v)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        return ctx.download(be.VEC_TMP1)
+
+    ctx.assemble_K(be.VEC_DOF)
+    z = rng.standard_normal(ctx.n)
+    Kx1, Kz1 = Kx(x), Kx(z)
+    assert abs(z @ Kx1 - x @ Kz1) < 1e-10 * abs(z @ Kx1)
+    for i in range(3):
+        t = np.zeros(ctx.n)
+        t[i::3] = 1.0
+        assert np.abs(Kx(t)).max() < 1e-9 * np.abs(Kx1).max()
+    ctx.upload(be.VEC_RESIDUAL, f)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    it1, _, rm1 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+    xs = ctx.download(be.VEC_X)
+    assert 0 < it1 < ctx.n and rm1 < 1e-3 * r0
+    it2, _, rm2 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+    assert (it2, rm2) == (it1, rm1) and np.array_equal(ctx.download(be.VEC_X), xs)

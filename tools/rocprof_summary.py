@@ -26,8 +26,26 @@ def pmc(db, counter):
         print(f"{name[:72]:<72} {n:>6} {a:>12.1f} {mn:>12.1f} {mx:>12.1f} {d/1e3:>9.2f}")
 
 
+def pmc_all(db, pattern=None):
+    """every counter of a PMC pass, per kernel: average per dispatch (summed over the counter's instances / XCDs as
+    rocprofv3 stores them)"""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+    last = None
+    for name, ctr, n, a, d in rows:
+        if pattern and pattern not in name:
+            continue
+        if name != last:
+            print(f"\n{name[:110]}   ({n} dispatches, avg {d/1e3:.2f} us)")
+            last = name
+        print(f"    {ctr:<36} {a:>18.1f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmc_all":
+        pmc_all(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         pmc(sys.argv[2], sys.argv[3])
