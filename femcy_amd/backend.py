@@ -28,14 +28,14 @@ GP_DSDX, GP_VOL, GP_F, GP_SIGMA, GP_STRAIN, GP_MISES, GP_ENERGY = range(7)
 OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT, OPT_EW_GRID, OPT_PCG_GRAPH, OPT_SELL_SIGMA = range(7)
 OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent tangent (extension)
 OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neighbour send/recv
-ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM = 0, 1, 2, 3, 4, 5
+ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2 = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "femcy_ctx_create", "femcy_ctx_destroy", "femcy_last_error", "femcy_version", "femcy_set_option", "femcy_sync",
     "femcy_set_mesh", "femcy_set_element", "femcy_set_material", "femcy_build_pattern", "femcy_get_pattern_info",
     "femcy_vec_upload", "femcy_vec_download", "femcy_vec_fill", "femcy_vec_copy", "femcy_vec_scatter",
     "femcy_vec_sub", "femcy_vec_axpy", "femcy_vec_scale", "femcy_vec_norm", "femcy_vec_absmax",
-    "femcy_assemble_K", "femcy_internal_force", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
+    "femcy_assemble_K", "femcy_internal_force", "femcy_residual_and_K", "femcy_apply_dirichlet_linear", "femcy_apply_dirichlet_newton",
     "femcy_dofset_create", "femcy_dofset_dirichlet_newton", "femcy_dofset_dirichlet_linear", "femcy_dofset_fill",
     "femcy_dofset_scatter", "femcy_loadset_create", "femcy_loadset_neumann", "femcy_spmv", "femcy_pcg", "femcy_compute_strain_stress", "femcy_elastic_energy", "femcy_extrapolate",
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
@@ -99,7 +99,7 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_vec_scatter": [p, cint, p, p, i32], "femcy_vec_sub": [p, cint, cint, cint],
         "femcy_vec_axpy": [p, cint, cint, f64, cint], "femcy_vec_scale": [p, cint, f64],
         "femcy_vec_norm": [p, cint, C.POINTER(f64)], "femcy_vec_absmax": [p, cint, C.POINTER(f64)],
-        "femcy_assemble_K": [p, cint], "femcy_internal_force": [p, cint, cint],
+        "femcy_assemble_K": [p, cint], "femcy_internal_force": [p, cint, cint], "femcy_residual_and_K": [p, cint, cint],
         "femcy_apply_dirichlet_linear": [p, p, p, i32, cint], "femcy_apply_dirichlet_newton": [p, p, i32, cint],
         "femcy_dofset_create": [p, p, i32, C.POINTER(i32)], "femcy_dofset_dirichlet_newton": [p, i32, cint],
         "femcy_dofset_dirichlet_linear": [p, i32, f64, cint], "femcy_dofset_fill": [p, i32, cint, f64],
@@ -289,6 +289,10 @@ class Context:
 
     def internal_force(self, u_vec: int = VEC_DOF, f_vec: int = VEC_FORCE):
         self._call("femcy_internal_force", int(u_vec), int(f_vec))
+
+    def residual_and_K(self, u_vec: int = VEC_DOF, f_vec: int = VEC_FORCE):
+        """internal force + matrix of one Newton residual evaluation from ONE element pass."""
+        self._call("femcy_residual_and_K", int(u_vec), int(f_vec))
 
     def dirichlet_linear(self, dofs, vals, rhs_vec: int = VEC_RHS):
         dofs, vals = _i32(dofs).ravel(), _f64(vals).ravel()

@@ -84,6 +84,8 @@ struct Ctx {
     int32_t mat_kind = -1;
     double mat_params[4] = {0, 0, 0, 0};
     double h_C[36] = {0};             // host copy of C (the consistent tangent reads lambda, mu from it)
+    bool C_is_cubic = false;          // dm = 3: C has the cubic pattern (c11, c12, c44; kblock_cubic3)
+    double cubic[3] = {0, 0, 0};
     bool have_mesh = false, have_element = false, have_material = false, have_pattern = false;
     bool dN_sums_to_zero = false;     // element tables satisfy sum_a dN_a = 0 (partition of unity)
 
@@ -127,6 +129,12 @@ struct Ctx {
     double* d_mises = nullptr;
     double* d_energy = nullptr;
     double* d_fe = nullptr;           // [ne][npe][dm] per-element nodal forces of the last femcy_internal_force
+    // The force evaluation of a Newton residual does not store F and sigma (at 1 M C3D4 they are 143 of the 334 MB the
+    // element pass would write, and nothing on the solve path reads them).  The reference's post-processing reads
+    // "the stress of the last force evaluation", so that state is kept as a copy of the displacement it was made
+    // with (8 n bytes) and F / sigma are recomputed from it when somebody asks (ensure_gp_stress).
+    bool gp_lazy = false;
+    double* d_u_lazy = nullptr;
 
     // ---- vectors
     double* d_vec[FEMCY_VEC_COUNT] = {nullptr};
@@ -208,8 +216,11 @@ void timing_collect(Ctx* c);
 int build_pattern(Ctx* c);
 void spmv_split(Ctx* c);
 // kernels_*.hip (host launchers)
-int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom = true, bool write_sigma = true,
-                bool write_fe = false);
+// what the element pass leaves in memory: current-configuration gradients + det J w (always computed), the
+// deformation gradient, the Cauchy stress, the per-element nodal forces
+enum : unsigned { GEOM_DSDX = 1, GEOM_F = 2, GEOM_SIGMA = 4, GEOM_FE = 8 };
+int launch_geom(Ctx* c, const double* d_u, unsigned what);
+int ensure_gp_stress(Ctx* c);   // F / sigma of the last force evaluation, recomputed on demand (see Ctx::gp_lazy)
 int launch_post(Ctx* c, int large);
 int launch_energy(Ctx* c);
 int launch_extrapolate(Ctx* c, const double* d_E, const double* d_field, int width, int comp, double* d_out);

@@ -106,6 +106,25 @@ static int check_vec(Ctx* c, int v) {
     return FEMCY_OK;
 }
 
+// element pass of a force evaluation: gradients + per-element nodal forces; F / sigma stay un-stored (gp_lazy)
+int force_pass(Ctx* c, const double* d_u) {
+    if (c->opt_tangent == 1) {                       // the consistent tangent reads F and sigma right away
+        c->gp_lazy = false;
+        return launch_geom(c, d_u, GEOM_DSDX | GEOM_F | GEOM_SIGMA | GEOM_FE);
+    }
+    int rc = launch_geom(c, d_u, GEOM_DSDX | GEOM_FE);
+    if (rc) return rc;
+    FEMCY_HIP(hipMemcpyAsync(c->d_u_lazy, d_u, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+    c->gp_lazy = true;
+    return FEMCY_OK;
+}
+
+int ensure_gp_stress(Ctx* c) {
+    if (!c->gp_lazy) return FEMCY_OK;
+    c->gp_lazy = false;
+    return launch_geom(c, c->d_u_lazy, GEOM_F | GEOM_SIGMA);
+}
+
 }  // namespace femcy
 
 using namespace femcy;
@@ -191,7 +210,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
     for (auto& v : c->d_vec) dev_free(&v);
-    dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad);
+    dev_free(&c->d_r); dev_free(&c->d_d); dev_free(&c->d_M); dev_free(&c->d_Ad); dev_free(&c->d_u_lazy);
     dev_free(&c->d_part1); dev_free(&c->d_part2); dev_free(&c->d_state);
     dev_free(&c->d_idx_scratch); dev_free(&c->d_val_scratch);
     dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_slot2dof); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
@@ -222,7 +241,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
     CTX_OR_FAIL(ctx);
     switch (option) {
         case FEMCY_OPT_ASSEMBLY:
-            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_GATHER_SYM_ROWSUM, "bad assembly mode %lld", (long long)value);
+            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS2, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
         case FEMCY_OPT_PCG_POLL:
@@ -341,8 +360,9 @@ int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, 
     for (auto& v : c->d_vec)
         if ((rc = dev_alloc(&v, nalloc))) return rc;
     if ((rc = dev_alloc(&c->d_r, nalloc)) || (rc = dev_alloc(&c->d_d, nalloc)) || (rc = dev_alloc(&c->d_M, nalloc)) ||
-        (rc = dev_alloc(&c->d_Ad, nalloc)))
+        (rc = dev_alloc(&c->d_Ad, nalloc)) || (rc = dev_alloc(&c->d_u_lazy, nalloc)))
         return rc;
+    c->gp_lazy = false;
     pcg_graph_reset(c);
     c->have_mesh = true;
     c->have_element = c->have_pattern = false;
@@ -385,6 +405,7 @@ int femcy_set_element(femcy_ctx* ctx, int32_t nGP, const double* dN, const doubl
         (rc = dev_alloc(&c->d_energy, ngp)))
         return rc;
     c->have_element = true;
+    c->gp_lazy = false;
     return FEMCY_OK;
 }
 
@@ -404,6 +425,19 @@ int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C, const doub
     FEMCY_HIP(hipMemcpy(c->d_C, C, sizeof(double) * s * s, hipMemcpyHostToDevice));
     for (int i = 0; i < s * s; ++i) c->h_C[i] = C[i];
     c->mat_kind = kind;
+    // cubic pattern of a 6 x 6 C (exact comparisons: anything else takes the dense-pattern evaluation)
+    c->C_is_cubic = false;
+    if (s == 6) {
+        const double c11 = C[0], c12 = C[1], c44 = C[3 * 6 + 3];
+        bool ok = true;
+        for (int i = 0; i < 6 && ok; ++i)
+            for (int j = 0; j < 6 && ok; ++j) {
+                const double want = (i == j) ? (i < 3 ? c11 : c44) : ((i < 3 && j < 3) ? c12 : 0.0);
+                ok = C[i * 6 + j] == want;
+            }
+        c->C_is_cubic = ok;
+        c->cubic[0] = c11; c->cubic[1] = c12; c->cubic[2] = c44;
+    }
     for (int i = 0; i < 4; ++i) c->mat_params[i] = (i < nparams) ? params[i] : 0.0;
     c->have_material = true;
     return FEMCY_OK;
@@ -525,7 +559,8 @@ int femcy_assemble_K(femcy_ctx* ctx, int u_vec) {
         du = c->d_vec[u_vec];
     }
     // the consistent tangent needs F and sigma of this state: the element pass then also evaluates the material
-    int rc = launch_geom(c, du, c->opt_tangent == 1);
+    if (c->opt_tangent == 1) c->gp_lazy = false;
+    int rc = launch_geom(c, du, c->opt_tangent == 1 ? (GEOM_DSDX | GEOM_F | GEOM_SIGMA) : GEOM_DSDX);
     if (rc) return rc;
     return launch_assemble(c);
 }
@@ -535,10 +570,24 @@ int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec) {
     READY_OR_FAIL();
     VEC_OR_FAIL(u_vec);
     VEC_OR_FAIL(f_vec);
-    int rc = launch_geom(c, c->d_vec[u_vec], true, true, true, true);
+    int rc = force_pass(c, c->d_vec[u_vec]);
     if (rc) return rc;
     if ((rc = launch_nodal_force(c, c->d_vec[f_vec]))) return rc;
     return iface_sum(c, c->d_vec[f_vec]);      // multi-rank: forces of the elements other ranks hold (no-op otherwise)
+}
+
+int femcy_residual_and_K(femcy_ctx* ctx, int u_vec, int f_vec) {
+    CTX_OR_FAIL(ctx);
+    READY_OR_FAIL();
+    VEC_OR_FAIL(u_vec);
+    VEC_OR_FAIL(f_vec);
+    // ONE element pass for both halves of a Newton residual evaluation: the internal force and the matrix are
+    // evaluated on the same displacement, so the gradients the force pass leaves are the ones the assembly reads
+    int rc = force_pass(c, c->d_vec[u_vec]);
+    if (rc) return rc;
+    if ((rc = launch_nodal_force(c, c->d_vec[f_vec]))) return rc;
+    if ((rc = iface_sum(c, c->d_vec[f_vec]))) return rc;
+    return launch_assemble(c);
 }
 
 static int stage_dofs(Ctx* c, const int32_t* dofs, const double* vals, int32_t k) {
@@ -781,8 +830,9 @@ int femcy_compute_strain_stress(femcy_ctx* ctx, int u_vec, int large) {
     VEC_OR_FAIL(u_vec);
     // get_deformation_gradient: F only -- dsdx, vol and (for nlgeom) the Cauchy stress of the last
     // constitutiveOfLargeDeform stay as they are, exactly as in the reference
-    int rc = launch_geom(c, c->d_vec[u_vec], true, false, false);
+    int rc = ensure_gp_stress(c);
     if (rc) return rc;
+    if ((rc = launch_geom(c, c->d_vec[u_vec], GEOM_F))) return rc;
     return launch_post(c, large ? 1 : 0);
 }
 
@@ -790,8 +840,9 @@ int femcy_elastic_energy(femcy_ctx* ctx, int u_vec, double* total) {
     CTX_OR_FAIL(ctx);
     FEMCY_REQUIRE(c->have_mesh && c->have_element && c->have_material && total, "context not fully defined");
     VEC_OR_FAIL(u_vec);
-    int rc = launch_geom(c, c->d_vec[u_vec], true, false, false);
+    int rc = ensure_gp_stress(c);
     if (rc) return rc;
+    if ((rc = launch_geom(c, c->d_vec[u_vec], GEOM_F))) return rc;
     if ((rc = launch_energy(c))) return rc;
     return launch_energy_sum(c, total);
 }
@@ -811,6 +862,10 @@ int femcy_extrapolate(femcy_ctx* ctx, int gp_field, int comp, const double* E, d
         default: set_error("field %d cannot be extrapolated", gp_field); return FEMCY_EINVAL;
     }
     FEMCY_REQUIRE(comp >= 0 && comp < width, "component %d out of range for field %d", comp, gp_field);
+    if (gp_field == FEMCY_GP_F || gp_field == FEMCY_GP_SIGMA) {
+        int rcl = ensure_gp_stress(c);
+        if (rcl) return rcl;
+    }
     struct Tmp {   // freed on every return path
         double* p = nullptr;
         ~Tmp() {
@@ -905,6 +960,10 @@ int femcy_get_gp_field(femcy_ctx* ctx, int which, double* out) {
         case FEMCY_GP_MISES: src = c->d_mises; count = ngp; break;
         case FEMCY_GP_ENERGY: src = c->d_energy; count = ngp; break;
         default: set_error("unknown Gauss-point field %d", which); return FEMCY_EINVAL;
+    }
+    if (which == FEMCY_GP_F || which == FEMCY_GP_SIGMA) {
+        int rcl = ensure_gp_stress(c);
+        if (rcl) return rcl;
     }
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     FEMCY_HIP(hipMemcpy(out, src, count * sizeof(double), hipMemcpyDeviceToHost));

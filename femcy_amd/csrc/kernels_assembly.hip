@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
             }
 #pragma unroll
             for (int i = 0; i < DM; ++i) F[i][i] += 1.0;
-            {
+            if (Fout) {   // the Newton residual needs neither F nor sigma in memory (femcy_residual_and_K)
                 double Fl[WT];
 #pragma unroll
                 for (int i = 0; i < DM; ++i)
@@ -324,9 +324,9 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                     for (int i = 0; i < WT; ++i) fo[i] = Fl[i];
                 }
             }
-            if (Sout) {   // get_deformation_gradient alone (post-processing) leaves the stored stress untouched
+            if (Sout || fe) {   // get_deformation_gradient alone (post-processing) leaves the stored stress untouched
                 cauchy_large<DM>(mat_kind, C, p0, p1, F, sig);
-                {
+                if (Sout) {
                     double Sl[WT];
 #pragma unroll
                     for (int i = 0; i < DM; ++i)
@@ -698,6 +698,243 @@ __global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, 
         }
         __syncthreads();
     }
+}
+
+// B_a^T C B_b * v for a C with the cubic sparsity pattern (c11 on the normal diagonal, c12 between normal
+// components, c44 on the shear diagonal, zero elsewhere): every material of the reference -- isotropic Hooke
+// (c11 = lambda + 2 mu, c12 = lambda, c44 = mu) and the neo-Hookean constant tangent 4 C1 I + 2 D1 1x1 -- has it.
+//   K[i][k] = c12 a_i b_k + c44 a_k b_i                     (i != k)
+//   K[i][i] = c11 a_i b_i + c44 sum_{j != i} a_j b_j
+// 30 multiply-adds instead of the 90 of the dense-pattern evaluation; femcy_set_material detects the pattern with
+// exact comparisons and everything else takes kblock_add.
+__device__ __forceinline__ void kblock_cubic3(const double* __restrict__ ga, const double* __restrict__ gb, double c11,
+                                              double c12, double c44, double v, double (&acc)[9]) {
+    const double a0 = ga[0] * v, a1 = ga[1] * v, a2 = ga[2] * v, b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    const double p00 = a0 * b0, p11 = a1 * b1, p22 = a2 * b2;
+    acc[0] += c11 * p00 + c44 * (p11 + p22);
+    acc[4] += c11 * p11 + c44 * (p00 + p22);
+    acc[8] += c11 * p22 + c44 * (p00 + p11);
+    acc[1] += c12 * (a0 * b1) + c44 * (a1 * b0);
+    acc[2] += c12 * (a0 * b2) + c44 * (a2 * b0);
+    acc[3] += c12 * (a1 * b0) + c44 * (a0 * b1);
+    acc[5] += c12 * (a1 * b2) + c44 * (a2 * b1);
+    acc[6] += c12 * (a2 * b0) + c44 * (a0 * b2);
+    acc[7] += c12 * (a2 * b1) + c44 * (a1 * b2);
+}
+
+// LDS hand-off between the lanes of ONE wavefront: the LDS serves a wave's instructions in issue order, so all that
+// is needed is that the compiler keeps the order (no s_barrier: the waves of a workgroup run independently here)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// row-centric assembly, second form (3-D elements whose shape-function gradients sum to zero; default for C3D10).
+// One workgroup per 64-row slice of the SELL matrix, one wavefront per row at a time (16 rows per wavefront).
+// Differences to k_assemble_rows, each answering a counter of profiles/r02_pmc_c3d10_baseline.txt:
+//   * the dsdx / vol records of the row's incident elements are staged in wave-private LDS by full-width 16-byte
+//     loads (one 1-KiB instruction per C3D10 element) instead of 28 scattered 8-byte gathers per lane and Gauss
+//     point -- the old kernel kept the texture-address path 60 % busy (TA_TA_BUSY) with 22 cache lines per load
+//     instruction and spent 65 % of its wave cycles in s_waitcnt;
+//   * a pass = up to EPC incident elements of one row; the records of pass p+1 and the element list of pass p+2
+//     are fetched into registers while pass p computes (a row's chain row -> element list -> records is three
+//     dependent memory round trips; un-pipelined they, not the arithmetic, set the kernel time);
+//   * lanes are the (element, column node != row node) pairs, 7 elements x 9 columns = 63 lanes per pass for
+//     C3D10; the diagonal block, which every incident element hits (7-way ds_add_f64 conflicts), is not
+//     accumulated at all but taken from the row sum K_aa = -sum_{b != a} K_ab at the end, in LDS;
+//   * cubic-pattern C (all reference materials): 30 instead of 90 multiply-adds per block and Gauss point;
+//   * all rows of a slice are written by one workgroup, i.e. through ONE XCD's L2, where the 8/16-byte pieces of
+//     the lane-interleaved block rows merge into full lines before they go to HBM (the old kernel wrote 1.5 x the
+//     matrix: WRITE_SIZE 540 MB for 357 MB of K).
+// Deterministic: fixed pass order, ds_add_f64 of one instruction applied in lane order, fixed-order diagonal sum.
+template <int NPE, int NGP, bool CUBIC>
+__global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t Lmax,
+                                                        const int32_t* __restrict__ ne_ptr,
+                                                        const int32_t* __restrict__ ne_idx,
+                                                        const uint16_t* __restrict__ slotj,
+                                                        const int32_t* __restrict__ rowlen,
+                                                        const int32_t* __restrict__ node_of,
+                                                        const int64_t* __restrict__ slice_off,
+                                                        const double* __restrict__ dsdx, const double* __restrict__ vol,
+                                                        const double* __restrict__ C, double c11, double c12, double c44,
+                                                        double* __restrict__ Kvals) {
+    constexpr int DM = 3, DD = 9, T = NPE - 1, EPC = 64 / T, RD = NGP * NPE * DM, P16 = RD / 2;
+    constexpr int NIT = (EPC * P16 + 63) / 64;                   // 16-byte pieces per lane and pass (C3D10: 7)
+    constexpr int VOLW = (EPC * NGP + 1) & ~1, CODEW = (EPC + 1) / 2 * 2 / 2 + 1;
+    static_assert(RD % 2 == 0, "records are staged in 16-byte pieces");
+    static_assert(EPC * NGP <= 64, "one vol value per lane and pass");
+    extern __shared__ __attribute__((aligned(16))) double lds_rows2[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int accw = (Lmax * DD + 1) & ~1;
+    double* rec = lds_rows2 + (size_t)wave * (EPC * RD + VOLW + accw + 2 * CODEW);
+    double* vl = rec + EPC * RD;
+    double* acc = vl + VOLW;
+    int32_t* codes = reinterpret_cast<int32_t*>(acc + accw);
+    const int32_t s = blockIdx.x;
+    if (s >= nslices) return;
+    const int64_t off = slice_off[s];
+
+    // ---- the wave's rows (slice lanes wave, wave + 4, ...): lane i holds the metadata of its i-th row
+    constexpr int RPW = SLICE / 4;
+    int32_t m_L = 0, m_k0 = 0, m_cnt = 0;
+    bool m_valid = false;
+    if (lane < RPW) {
+        const int32_t a = node_of[(int64_t)s * SLICE + wave + 4 * lane];
+        if (a >= 0) {                                            // padding lanes only at the tail of the last slice
+            m_valid = true;
+            m_L = rowlen[a];
+            m_k0 = ne_ptr[a];
+            m_cnt = ne_ptr[a + 1] - m_k0;
+        }
+    }
+    const int nrows = __popcll(__ballot(m_valid));               // valid rows are a prefix
+    if (nrows == 0) return;
+#define ROW_CNT(i) __builtin_amdgcn_readlane(m_cnt, (i))
+#define ROW_K0(i) __builtin_amdgcn_readlane(m_k0, (i))
+#define ROW_L(i) __builtin_amdgcn_readlane(m_L, (i))
+    // pass iterator: (row i, first incident element c0); a row without elements still takes one (empty) pass
+    auto advance = [&](int& i, int& c0) {
+        c0 += EPC;
+        if (i < nrows && c0 >= ROW_CNT(i)) {
+            ++i;
+            c0 = 0;
+        }
+    };
+    auto load_codes = [&](int i, int c0) -> int32_t {           // lane q: (element, local row node) code of element q
+        if (i >= nrows) return 0;
+        const int32_t nE = min(EPC, ROW_CNT(i) - c0);
+        return lane < nE ? ne_idx[ROW_K0(i) + c0 + lane] : 0;
+    };
+    double2 R[NIT];
+    double V = 0.0;
+    int32_t JS = 0;          // slot of the lane's block in the row (needed last, fetched with the records: VMEM returns
+                             // in order, so a load issued in the compute phase would wait for the prefetches before it)
+    // 16-byte pieces of a pass's records + det J w into registers (a macro, not a lambda: R must stay in VGPRs)
+#define LOAD_RECORDS(code_, i_, c0_)                                                                  \
+    if ((i_) < nrows) {                                                                               \
+        const int32_t nE_ = min(EPC, ROW_CNT(i_) - (c0_));                                            \
+        _Pragma("unroll") for (int u = 0; u < NIT; ++u) {                                             \
+            const int32_t p_ = lane + 64 * u;                                                         \
+            const int32_t q_ = p_ / P16, w_ = p_ - q_ * P16;                                          \
+            const int64_t e_ = __shfl((code_), q_, 64) / NPE;                                         \
+            if (p_ < nE_ * P16) R[u] = reinterpret_cast<const double2*>(dsdx + e_ * RD)[w_];          \
+        }                                                                                             \
+        const int32_t qv_ = lane / NGP, gv_ = lane - qv_ * NGP;                                       \
+        const int64_t ev_ = __shfl((code_), qv_, 64) / NPE;                                           \
+        if (lane < nE_ * NGP) V = vol[ev_ * NGP + gv_];                                               \
+        const int32_t qt_ = lane / T, jb_ = lane - qt_ * T;                                           \
+        const int32_t ct_ = __shfl((code_), qt_, 64);                                                 \
+        const int32_t lat_ = ct_ % NPE;                                                               \
+        if (lane < nE_ * T) JS = slotj[(int64_t)ct_ * NPE + jb_ + (jb_ >= lat_ ? 1 : 0)];             \
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) R[u] = make_double2(0.0, 0.0);
+
+    int i0 = 0, c00 = 0, i1 = 0, c01 = 0, i2 = 0, c02 = 0;
+    advance(i1, c01);
+    i2 = i1;
+    c02 = c01;
+    advance(i2, c02);
+    int32_t code_c = load_codes(i0, c00);
+    int32_t code_n = load_codes(i1, c01);
+    LOAD_RECORDS(code_c, i0, c00)
+    for (int idx = lane; idx < ROW_L(0) * DD; idx += 64) acc[idx] = 0.0;
+
+    while (i0 < nrows) {
+        const int32_t cnt = ROW_CNT(i0);
+        const int32_t nE = max(0, min(EPC, cnt - c00));
+        wave_lds_sync();                                        // the previous pass is done with rec / vl / codes
+        if (lane < nE) codes[lane] = code_c;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int32_t p = lane + 64 * u;
+            const int32_t q = p / P16, w = p - q * P16;
+            if (p < nE * P16) reinterpret_cast<double2*>(rec + q * RD)[w] = R[u];
+        }
+        if (lane < nE * NGP) vl[lane] = V;
+        int32_t j = JS;
+        asm volatile("" : "+v"(j));     // consume JS HERE: a copy the compiler sinks below the prefetch would have to wait
+                                        // for the prefetch loads as well (vmcnt counts in order)
+        // prefetch: records of the next pass (its element list arrived during the previous pass), list of the one after
+        LOAD_RECORDS(code_n, i1, c01)
+        const int32_t code_nn = load_codes(i2, c02);
+        wave_lds_sync();
+        if (lane < nE * T) {
+            const int32_t q = lane / T, jb = lane - q * T;
+            const int32_t code = codes[q];
+            const int32_t la = code % NPE;
+            const int32_t lb = jb + (jb >= la ? 1 : 0);         // every column node of the element but the row node
+            double blk[DD];
+#pragma unroll
+            for (int k = 0; k < DD; ++k) blk[k] = 0.0;
+#pragma unroll
+            for (int g = 0; g < NGP; ++g) {
+                const double* ga = rec + q * RD + (g * NPE + la) * DM;
+                const double* gb = rec + q * RD + (g * NPE + lb) * DM;
+                if (CUBIC) kblock_cubic3(ga, gb, c11, c12, c44, vl[q * NGP + g], blk);
+                else kblock_add<3>(ga, gb, C, vl[q * NGP + g], blk);
+            }
+#if defined(FEMCY_EXP_NOATOMIC)
+#pragma unroll
+            for (int k = 0; k < DD; ++k) acc[j * DD + k] = blk[k];
+#elif defined(FEMCY_EXP_NOCOMPUTE)
+            if (blk[0] == 123.456) acc[j * DD] = blk[1];
+#else
+#pragma unroll
+            for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
+#endif
+        }
+#ifdef FEMCY_EXP_NOWRITE
+        if (c00 + EPC >= cnt && Lmax == 12345) {
+#else
+        if (c00 + EPC >= cnt) {                                 // last pass of the row: diagonal, write-out
+#endif
+            const int32_t L = ROW_L(i0);
+            const int r = wave + 4 * i0;
+            wave_lds_sync();
+            // diagonal block from the row sum: 7 x 9 partial sums over the slots 1.., combined in a fixed order
+            // (rec is free: the pass above only read it before the sync)
+            if (lane < 63) {
+                const int jj = lane / DD, k = lane - jj * DD;
+                double t = 0.0;
+                for (int32_t j = 1 + jj; j < L; j += 7) t += acc[j * DD + k];
+                rec[lane] = t;
+            }
+            wave_lds_sync();
+            if (lane < DD) {
+                double t = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < 7; ++jj) t += rec[jj * DD + lane];
+                acc[lane] = -t;
+            }
+            wave_lds_sync();
+            // the row: per block four 16-byte pairs + the trailing 8-byte entry (kv_index layout), lane r of the slice
+            double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
+            for (int idx = lane; idx < L * 5; idx += 64) {
+                const int j = idx / 5, pc = idx - j * 5;
+                double* dst = Krow + (int64_t)j * (DD * SLICE);
+                if (pc < 4) {
+                    reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] =
+                        make_double2(acc[j * DD + 2 * pc], acc[j * DD + 2 * pc + 1]);
+                } else {
+                    dst[4 * (2 * SLICE) + r] = acc[j * DD + 8];
+                }
+            }
+            wave_lds_sync();
+            if (i0 + 1 < nrows)
+                for (int idx = lane; idx < ROW_L(i0 + 1) * DD; idx += 64) acc[idx] = 0.0;
+        }
+        i0 = i1; c00 = c01;
+        i1 = i2; c01 = c02;
+        advance(i2, c02);
+        code_c = code_n;
+        code_n = code_nn;
+    }
+#undef LOAD_RECORDS
+#undef ROW_CNT
+#undef ROW_K0
+#undef ROW_L
 }
 
 // scatter assembly with hardware f64 atomics: one lane per element-local (a,b) block
@@ -1197,16 +1434,18 @@ int launch_energy_sum(Ctx* c, double* total) {
         launched = true;                                                 \
     }
 
-int launch_geom(Ctx* c, const double* d_u, bool with_stress, bool write_geom, bool write_sigma, bool write_fe) {
+int launch_geom(Ctx* c, const double* d_u, unsigned what) {
     const int bs = 256, grid = (c->ne + bs - 1) / bs;
     bool launched = false;
+    const bool with_stress = (what & (GEOM_F | GEOM_SIGMA | GEOM_FE)) != 0;
     size_t th = timing_begin(c, T_GEOM);
 #define GEOM_CALL                                                                                                   \
     if (with_stress)                                                                                                \
         hipLaunchKernelGGL((k_geom<NPE, DM, true>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes,  \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \
-                           c->mat_params[1], write_geom ? c->d_dsdx : nullptr, c->d_vol, c->d_F,                  \
-                           write_sigma ? c->d_sigma : nullptr, (write_fe && write_sigma) ? c->d_fe : nullptr);      \
+                           c->mat_params[1], (what & GEOM_DSDX) ? c->d_dsdx : nullptr, c->d_vol,                    \
+                           (what & GEOM_F) ? c->d_F : nullptr, (what & GEOM_SIGMA) ? c->d_sigma : nullptr,          \
+                           (what & GEOM_FE) ? c->d_fe : nullptr);                                                   \
     else                                                                                                            \
         hipLaunchKernelGGL((k_geom<NPE, DM, false>), dim3(grid), dim3(bs), 0, c->stream, c->ne, c->nGP, c->d_nodes, \
                            d_u, c->d_elems, c->d_dN, c->d_w, c->mat_kind, c->d_C, c->mat_params[0],                 \
@@ -1232,7 +1471,8 @@ int launch_assemble(Ctx* c) {
     size_t th = timing_begin(c, T_ASM);
     int mode = c->opt_assembly;
     if (mode == FEMCY_ASM_AUTO)
-        mode = (c->npe > 4) ? FEMCY_ASM_ROWS : (c->dN_sums_to_zero ? FEMCY_ASM_GATHER_SYM_ROWSUM : FEMCY_ASM_GATHER_SYM);
+        mode = (c->npe > 4) ? ((c->dm == 3 && c->npe == 10 && c->nGP == 4 && c->dN_sums_to_zero) ? FEMCY_ASM_ROWS2 : FEMCY_ASM_ROWS)
+                            : (c->dN_sums_to_zero ? FEMCY_ASM_GATHER_SYM_ROWSUM : FEMCY_ASM_GATHER_SYM);
     if (c->opt_tangent == 1) {
         FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
         const bool neo = c->mat_kind == FEMCY_MAT_NEOHOOKE;
@@ -1263,7 +1503,20 @@ int launch_assemble(Ctx* c) {
         FEMCY_HIP(hipGetLastError());
         return FEMCY_OK;
     }
-    if (mode == FEMCY_ASM_ROWS) {
+    if (mode == FEMCY_ASM_ROWS2) {
+        FEMCY_REQUIRE(c->dm == 3 && c->dN_sums_to_zero && ((c->npe == 10 && c->nGP == 4) || (c->npe == 4 && c->nGP == 1)),
+                      "ROWS2 assembly is instantiated for C3D10 / C3D4 tables with sum_a dN_a = 0 (npe %d, nGP %d)", c->npe, c->nGP);
+        const int T = c->npe - 1, EPC = 64 / T, RD = c->nGP * c->npe * 3;
+        const int volw = (EPC * c->nGP + 1) & ~1, codew = (EPC + 1) / 2 * 2 / 2 + 1, accw = (c->max_row_blocks * 9 + 1) & ~1;
+        const size_t lds = (size_t)4 * (EPC * RD + volw + accw + 2 * codew) * sizeof(double);
+#define FEMCY_ROWS2(NPE_, NGP_, CUB_)                                                                                  \
+    hipLaunchKernelGGL((k_assemble_rows2<NPE_, NGP_, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,    \
+                       c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of, c->d_slice_off, \
+                       c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2], c->d_Kvals)
+        if (c->npe == 10) { if (c->C_is_cubic) FEMCY_ROWS2(10, 4, true); else FEMCY_ROWS2(10, 4, false); }
+        else              { if (c->C_is_cubic) FEMCY_ROWS2(4, 1, true); else FEMCY_ROWS2(4, 1, false); }
+#undef FEMCY_ROWS2
+    } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);
         if (c->dm == 3)

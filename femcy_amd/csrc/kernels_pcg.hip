@@ -306,7 +306,6 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
         return;
     }
     const int64_t stride = (int64_t)gridDim.x * BS;
-    const double2 z2 = make_double2(0.0, 0.0);
     int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
     // the producer's partials first (VMEM returns in order: loaded after the batch they would only arrive behind it)
     double pv[PU];
@@ -387,7 +386,6 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->skip) return;                           // written by this iteration's k_update_xr, never by this kernel
     const int64_t stride = (int64_t)gridDim.x * BS;
-    const double2 z2 = make_double2(0.0, 0.0);
     int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
     // (r.M.r, max|r|) pairs of k_update_xr first, then the batch (in-order VMEM returns, see k_update_xr)
     const double* __restrict__ pairs = gathered ? gathered : part2;

@@ -275,8 +275,9 @@ class System_of_equations:
     def _residual(self, dirichletBCs):
         """nodal force + K at the current dof, residual = f_int - rhs, Newton Dirichlet treatment,
         RMS norm (the block the reference repeats at :756-759, :779-783 and in inside_relaxation)."""
-        self.assemble_nodal_force_GN()
-        self.assemble_stiffnessMtrx()
+        self.ctx.residual_and_K(be.VEC_DOF, be.VEC_FORCE)     # assemble_nodal_force_GN + assemble_stiffnessMtrx,
+        self.stats["force_evals"] += 1                        # one element pass (same dof for both)
+        self.stats["assemblies"] += 1
         tg.c_equals_a_minus_b(self.residual_nodal_force, self.nodal_force, self.rhs)
         self.dirichletBC_forNewtonMethod(dirichletBCs)
         return tg.field_norm(self.residual_nodal_force)

@@ -81,10 +81,13 @@ enum femcy_assembly {
     FEMCY_ASM_GATHER = 0, /* owner-computes: one lane per stored block, deterministic            */
     FEMCY_ASM_ATOMIC = 1, /* element scatter with f64 HW atomics (comparison / race check)        */
     FEMCY_ASM_ROWS = 2,   /* one wavefront per matrix row, LDS reduction, deterministic           */
-    FEMCY_ASM_AUTO = 3,   /* default: ROWS for npe > 4 (measured 1.8x on C3D10), GATHER_SYM(_ROWSUM) otherwise */
+    FEMCY_ASM_AUTO = 3,   /* default: ROWS2 for C3D10, ROWS for the other npe > 4, GATHER_SYM(_ROWSUM) otherwise */
     FEMCY_ASM_GATHER_SYM = 4, /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
-    FEMCY_ASM_GATHER_SYM_ROWSUM = 5 /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
+    FEMCY_ASM_GATHER_SYM_ROWSUM = 5, /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
                                 unity, checked on the element tables); AUTO picks it for npe <= 4 */
+    FEMCY_ASM_ROWS2 = 6   /* ROWS with the element records staged in LDS, one workgroup per 64-row slice, row-sum
+                             diagonal, 30-flop blocks for cubic-pattern C: AUTO picks it for C3D10 (3.x faster than ROWS);
+                             instantiated for C3D10 and C3D4 tables whose gradients sum to zero */
 };
 
 enum femcy_option {
@@ -175,6 +178,12 @@ int femcy_assemble_K(femcy_ctx* ctx, int u_vec);
 /* assemble_nodal_force_GN (stiffnessMtrx.py:609-644): F (ref. config), sigma(F), dsdx/vol (current
  * config), node-parallel gather of dsdx . sigma * vol */
 int femcy_internal_force(femcy_ctx* ctx, int u_vec, int f_vec);
+/* One Newton residual evaluation: assemble_nodal_force_GN followed by get_dsdx_and_vol + assemble_stiffnessMtrx on
+ * the same displacement (the pair the reference issues back to back at stiffnessMtrx.py:756-759, 779-783 and in
+ * inside_relaxation) as ONE element pass: vec[f] = internal force, K = matrix at x = X + vec[u].  Same results as
+ * femcy_internal_force + femcy_assemble_K; the second geometry pass and the F / sigma stores are gone (F and sigma
+ * "of the last force evaluation" are recomputed when post-processing asks for them). */
+int femcy_residual_and_K(femcy_ctx* ctx, int u_vec, int f_vec);
 /* dirichletBC_linearEquations (stiffnessMtrx.py:279-307) for one *Boundary block, race-free */
 int femcy_apply_dirichlet_linear(femcy_ctx* ctx, const int32_t* dofs, const double* vals, int32_t k, int rhs_vec);
 /* dirichletBC_forNewtonMethod_kernel (stiffnessMtrx.py:317-341) */

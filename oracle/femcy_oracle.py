@@ -113,7 +113,7 @@ def _voigt3(E):
 
 
 def _unvoigt3(v):
-    S = np.empty(v.shape[:-1] + (3, 3))
+    S = np.empty(v.shape[:-1] + (3, 3), dtype=v.dtype)
     S[..., 0, 0], S[..., 1, 1], S[..., 2, 2] = v[..., 0], v[..., 1], v[..., 2]
     S[..., 0, 1] = S[..., 1, 0] = v[..., 3]
     S[..., 0, 2] = S[..., 2, 0] = v[..., 4]
@@ -150,7 +150,7 @@ def _inv(A):
 
 def _F3_plane_stress(F, nu):
     """linear_isotropic_plane_stress.py:72-75: F embedded in 3D with a synthesised F33."""
-    F3 = np.zeros(F.shape[:-2] + (3, 3))
+    F3 = np.zeros(F.shape[:-2] + (3, 3), dtype=F.dtype)
     F3[..., :2, :2] = F
     F3[..., 2, 2] = -nu / (1. - nu) * (F[..., 0, 0] + F[..., 1, 1] - 2.) + 1.
     return F3
@@ -226,7 +226,7 @@ def energy_density(mat: Material, F: np.ndarray) -> np.ndarray:
     elif mat.kind == "pstress":
         F3, C6 = _F3_plane_stress(F, mat.params[1]), mat.C_6x6
     else:  # pstrain: linear_isotropic_plane_strain.py:88-100
-        F3 = np.zeros(F.shape[:-2] + (3, 3))
+        F3 = np.zeros(F.shape[:-2] + (3, 3), dtype=F.dtype)
         F3[..., :2, :2] = F
         F3[..., 2, 2] = 1.
         C6 = mat.C_6x6
@@ -383,6 +383,38 @@ def internal_force(topo: Topology, dof: np.ndarray, mat: Material):
     gd = (topo.elements[:, :, None] * topo.dm + np.arange(topo.dm)[None, None, :])
     np.add.at(f, gd.ravel(), fe.ravel())
     return f, sig, F, dsdx, vol
+
+
+def consistent_tangent(topo: Topology, dof: np.ndarray, mat: Material, h: float = 1.0e-30) -> sp.csr_matrix:
+    """d internal_force / d dof, by complex-step differentiation of the restatement above (no reference
+    counterpart: the reference's tangent updates are commented out, neo_hookean.py:62-64, 79-81).  The nodal forces
+    of an element depend on that element's DOFs only, so one complex perturbation of local DOF k in EVERY element
+    at once gives column k of every element tangent: npe*dm evaluations for the whole mesh, exact to rounding (no
+    difference quotient, no step-size error).  It shares no formula with the device kernel it is the oracle for
+    (kblock_consistent assembles the spatial elasticity tensor + geometric stiffness analytically)."""
+    ed, dm = topo.ed, topo.dm
+    el = topo.elements
+    ne, npe = el.shape
+    m = npe * dm
+    Xf = topo.nodes[el].reshape(-1, dm)                          # every element owns private copies of its nodes
+    elf = np.arange(ne * npe).reshape(ne, npe)
+    Ue = np.asarray(dof, dtype=float).reshape(-1, dm)[el].reshape(ne, m)
+    Ke = np.empty((ne, m, m))
+    for k in range(m):
+        Up = Ue.astype(complex)
+        Up[:, k] += 1j * h
+        w = Up.reshape(-1)
+        F = deformation_gradient(Xf, elf, w, ed)
+        sig = cauchy_large(mat, F)
+        dsdx, vol = dsdx_and_vol(Xf, elf, w, ed)
+        fe = np.einsum('egaj,egji,eg->eai', dsdx, sig, vol)
+        Ke[:, :, k] = fe.reshape(ne, m).imag / h
+    gd = (el[:, :, None] * dm + np.arange(dm)[None, None, :]).reshape(ne, m)
+    rows = np.repeat(gd, m, axis=1).ravel()
+    cols = np.tile(gd, (1, m)).ravel()
+    K = sp.coo_matrix((Ke.ravel(), (rows, cols)), shape=(topo.n, topo.n)).tocsr()
+    K.sum_duplicates()
+    return K
 
 
 # ===================================================================== boundary conditions

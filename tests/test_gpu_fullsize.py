@@ -102,12 +102,13 @@ def test_fullsize_properties(full):
     ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ATOMIC)
     ctx.assemble_K(be.VEC_DOF)
     assert np.abs(Kx(x) - Kx1).max() < 1e-12 * scale
-    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ROWS)
-    ctx.assemble_K(be.VEC_DOF)
-    y_rows = Kx(x)
-    assert np.abs(y_rows - Kx1).max() < 1e-12 * scale
-    ctx.assemble_K(be.VEC_DOF)
-    assert np.array_equal(Kx(x), y_rows)                                # row-centric variant is deterministic too
+    for rows_mode in (be.ASM_ROWS, be.ASM_ROWS2):
+        ctx.set_option(be.OPT_ASSEMBLY, rows_mode)
+        ctx.assemble_K(be.VEC_DOF)
+        y_rows = Kx(x)
+        assert np.abs(y_rows - Kx1).max() < 1e-12 * scale
+        ctx.assemble_K(be.VEC_DOF)
+        assert np.array_equal(Kx(x), y_rows)                            # the row-centric variants are deterministic too
     ctx.set_option(be.OPT_ASSEMBLY, be.ASM_AUTO)
     ctx.assemble_K(be.VEC_DOF)
     # Dirichlet: constrained rows/columns become identity
@@ -345,7 +346,7 @@ def quad():
 def test_c3d10_bench_size_against_c_oracle(quad):
     be, ctx, u, cons, co, m = quad["be"], quad["ctx"], quad["u"], quad["cons"], quad["co"], quad["m"]
     ctx.upload(be.VEC_DOF, u)
-    ctx.assemble_K(be.VEC_DOF)                                   # AUTO: the row-centric kernel for npe > 4
+    ctx.assemble_K(be.VEC_DOF)                                   # AUTO: the LDS-staged row kernel (ROWS2) for C3D10
     co.get_dsdx_and_vol(u)
     co.assemble()
     assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
@@ -361,7 +362,7 @@ def test_c3d10_bench_size_against_c_oracle(quad):
         assert rel(ys[wps], yo) < 1e-12
     ctx.set_option(be.OPT_SPMV_VARIANT, 0)
     scale = np.abs(yo).max()
-    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_AUTO):
+    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_AUTO):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(be.VEC_DOF)
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)

@@ -59,10 +59,12 @@ def smooth_disp(nodes, scale):
 
 
 @pytest.mark.parametrize("name", DECKS)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
 def test_assemble_K(gpu_ctx_factory, name, mode):
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
+    if mode == be.ASM_ROWS2 and et not in ("C3D4", "C3D10"):
+        pytest.skip("the LDS-staged row assembly is instantiated for the 3-D simplex elements")
     ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
     ctx.set_option(be.OPT_ASSEMBLY, mode)
     topo = orc.Topology(inp.nodes, el, elem_def(et))
@@ -85,6 +87,64 @@ def test_assemble_K(gpu_ctx_factory, name, mode):
     assert abs(Kell - K).max() == 0.0
     info = ctx.pattern_info()
     assert info.nnzb == topo.adj_idx.size and info.max_row_blocks == np.diff(topo.adj_ptr).max()
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_C3D10_coarse.inp"])
+def test_assemble_K_general_C(gpu_ctx_factory, name):
+    """a material plugin whose C does NOT have the cubic pattern (anisotropic, fully populated, symmetric): every
+    assembly variant must take the dense-pattern evaluation of B^T C B, not the 30-flop cubic form."""
+    from types import SimpleNamespace
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((6, 6))
+    Cg = mat.C + 0.05 * np.abs(mat.C).max() * (A + A.T)
+    plugin = SimpleNamespace(kind=mat.kind, C=Cg, params=mat.params)
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(inp.nodes, el)
+    ctx.set_element(inp.ELE)
+    ctx.set_material(plugin)
+    ctx.build_pattern()
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    u = smooth_disp(inp.nodes, 0.02)
+    ctx.upload(be.VEC_DOF, u)
+    Ko = orc.assemble_K(topo, u, Cg)
+    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_AUTO):
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(be.VEC_DOF)
+        K = ctx.get_K_bsr().tocsr()
+        assert abs(K - Ko).max() / abs(Ko).max() < 1e-12, mode
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_C3D10_coarse.inp", "cook_3d_linearEl_largeDef.inp",
+                                  "ellip_CPS8.inp", "cookMembrane_2d_linearEl_largeDef.inp"])
+def test_residual_and_K_is_the_two_calls_in_one_pass(gpu_ctx_factory, name):
+    """femcy_residual_and_K (one element pass) = femcy_internal_force + femcy_assemble_K, bit for bit; F and sigma
+    "of the last force evaluation" are not stored by it but are what post-processing then sees (recomputed lazily
+    from the displacement of that evaluation, even after dof has moved on)."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    u = smooth_disp(inp.nodes, 0.02)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f_sep = ctx.download(be.VEC_FORCE)
+    ctx.assemble_K(be.VEC_DOF)
+    K_sep = ctx.get_K_bsr().tocsr()
+    ctx.vector(be.VEC_FORCE).fill(0.0)
+    ctx.upload(be.VEC_DOF, np.zeros_like(u))
+    ctx.assemble_K(be.VEC_DOF)                               # leave a different matrix behind
+    ctx.upload(be.VEC_DOF, u)
+    ctx.residual_and_K(be.VEC_DOF, be.VEC_FORCE)
+    assert np.array_equal(ctx.download(be.VEC_FORCE), f_sep)
+    assert abs(ctx.get_K_bsr().tocsr() - K_sep).max() == 0.0
+    # dof moves on (as in a line search); the stress of the last force evaluation is still the one at u
+    ctx.upload(be.VEC_DOF, 0.5 * u)
+    ctx.assemble_K(be.VEC_DOF)
+    _, sig, F, _, _ = orc.internal_force(topo, u, oracle_material(mat))
+    assert rel(ctx.gauss_field(be.GP_SIGMA).to_numpy(), sig) < 1e-11
+    assert rel(ctx.gauss_field(be.GP_F).to_numpy(), F) < 1e-13
 
 
 DSLOAD_DECKS = ["beamDeflec_quadPSE_largeD_load800.inp", "cookMembrane_2d_linearEl_largeDef.inp",

@@ -1,0 +1,34 @@
+"""time the assembly kernel alone (HIP events around the launch) on the C3D10 / C3D4 bench meshes.
+usage: python tools/asm_probe.py c3d10|c3d4 [mode=6] [reps=20]   (FEMCY_HIP_LIB selects an experimental build)"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from femcy_amd import backend as be, meshgen
+from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
+from femcy_amd.material_zoo import LinearIsotropic
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3d10"
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else be.ASM_ROWS2
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+quad = wl == "c3d10"
+m = meshgen.twist_plate(48, 6, 72, quadratic=True) if quad else meshgen.twist_plate_k(12)
+ctx = be.Context(0)
+ctx.set_mesh(m["nodes"], m["elements"])
+ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetrahedral())
+ctx.set_material(LinearIsotropic(*m["elastic"]))
+ctx.build_pattern()
+ctx.set_option(be.OPT_ASSEMBLY, mode)
+ctx.upload(be.VEC_DOF, np.zeros(ctx.n))
+for _ in range(3):
+    ctx.assemble_K(be.VEC_DOF)
+ctx.set_option(be.OPT_TIMING, 1)
+ctx.timing_reset()
+for _ in range(reps):
+    ctx.assemble_K(be.VEC_DOF)
+tm = ctx.timing()
+print(f"{wl} mode {mode} lib {os.path.basename(be.LIB_PATH)}: geom {tm['geom_ms']/tm['geom_launches']*1e3:.1f} us, "
+      f"assemble {tm['assemble_ms']/tm['assemble_launches']*1e3:.1f} us")
+ctx.close()
