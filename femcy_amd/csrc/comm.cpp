@@ -242,7 +242,7 @@ int comm_register_neighbours(Ctx* c) {
 
 // every rank sends segment k of d_nb_send to neighbour h_nb_rank[k] and receives that neighbour's segment for it
 // into segment k of d_nb_recv (the two sides list the shared DOFs in the same order)
-int comm_neighbour_exchange(Ctx* c) {
+int comm_neighbour_exchange(Ctx* c, hipStream_t stream) {
     if (!c->comm) return FEMCY_OK;
     const int nnb = (int)c->h_nb_rank.size();
     if (c->comm_local) {
@@ -250,8 +250,8 @@ int comm_neighbour_exchange(Ctx* c) {
         const int64_t total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
         std::vector<double>& mine = g->stage[c->rank];
         mine.resize((size_t)total);
-        if (total) FEMCY_HIP(hipMemcpyAsync(mine.data(), c->d_nb_send, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
-        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        if (total) FEMCY_HIP(hipMemcpyAsync(mine.data(), c->d_nb_send, sizeof(double) * total, hipMemcpyDeviceToHost, stream));
+        FEMCY_HIP(hipStreamSynchronize(stream));
         int rc = local_barrier(g);
         if (rc) return rc;
         std::vector<double> in((size_t)total);
@@ -269,8 +269,8 @@ int comm_neighbour_exchange(Ctx* c) {
             std::memcpy(in.data() + c->h_nb_ptr[k], g->stage[q].data() + g->nb_ptr[q][kq], sizeof(double) * cnt);
         }
         if ((rc = local_barrier(g))) return rc;
-        if (total) FEMCY_HIP(hipMemcpyAsync(c->d_nb_recv, in.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
-        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        if (total) FEMCY_HIP(hipMemcpyAsync(c->d_nb_recv, in.data(), sizeof(double) * total, hipMemcpyHostToDevice, stream));
+        FEMCY_HIP(hipStreamSynchronize(stream));
         return FEMCY_OK;
     }
     if (!R.send || !R.recv || !R.group_start || !R.group_end) {
@@ -280,8 +280,8 @@ int comm_neighbour_exchange(Ctx* c) {
     FEMCY_NCCL(R.group_start());
     for (int k = 0; k < nnb; ++k) {
         const size_t cnt = (size_t)(c->h_nb_ptr[k + 1] - c->h_nb_ptr[k]);
-        FEMCY_NCCL(R.send(c->d_nb_send + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, c->stream));
-        FEMCY_NCCL(R.recv(c->d_nb_recv + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, c->stream));
+        FEMCY_NCCL(R.send(c->d_nb_send + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, stream));
+        FEMCY_NCCL(R.recv(c->d_nb_recv + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, stream));
     }
     FEMCY_NCCL(R.group_end());
     return FEMCY_OK;

@@ -195,6 +195,16 @@ struct Ctx {
     double* d_commbuf = nullptr;      // [niface_global + 8]
     double* d_gather = nullptr;       // [nranks*2]
 
+    // ---- overlapped iteration (neighbour exchange): interface slices first, their exchange on a second stream
+    // while the interior slices are multiplied
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_iface = nullptr, ev_xchg = nullptr;
+    int opt_overlap = 1;              // FEMCY_OPT_OVERLAP
+    bool split_ready = false;
+    std::vector<int32_t> h_iface_dof; // host copy of the local interface DOFs (femcy_comm_init)
+    int32_t* d_split_list = nullptr;  // [nslices] slices holding an interface node first, then the others
+    int32_t n_if_slices = 0;
+
     // ---- neighbour exchange (femcy_comm_set_neighbours): the alternative to the packed all-reduce
     int exchange = 0;                 // FEMCY_OPT_EXCHANGE: 0 packed all-reduce, 1 neighbour send/recv
     std::vector<int32_t> h_nb_rank, h_nb_ptr;   // neighbours (ascending) and their segments of the send / recv buffers
@@ -229,6 +239,10 @@ int launch_assemble(Ctx* c);
 int launch_nodal_force(Ctx* c, double* d_f);
 int launch_neumann(Ctx* c, const Ctx::LoadSet& ls, double traction, bool along_normal, double* d_rhs);
 int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out);
+// part 1 / 2 of the split product: the slices holding interface nodes / all others (partials go to
+// d_partials[part_off ...]); split_prepare builds the slice list once per pattern + communicator
+int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d_partials, int part_off, int* nblocks_out);
+int split_prepare(Ctx* c);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
               double* rmax);
@@ -247,7 +261,7 @@ int comm_local_id(void* id128);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
-int comm_neighbour_exchange(Ctx* c);   // d_nb_send segments -> neighbours, their segments -> d_nb_recv
+int comm_neighbour_exchange(Ctx* c, hipStream_t stream);   // d_nb_send segments -> neighbours, their segments -> d_nb_recv
 int comm_register_neighbours(Ctx* c);  // in-process transport: publish this rank's segment table
 int comm_destroy(Ctx* c);
 int iface_sum(Ctx* c, double* d_v);

@@ -216,6 +216,13 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_iface_dof); dev_free(&c->d_iface_slot); dev_free(&c->d_slot2dof); dev_free(&c->d_owner); dev_free(&c->d_commbuf);
     dev_free(&c->d_gather);
     dev_free(&c->d_nb_dofs); dev_free(&c->d_nb_send); dev_free(&c->d_nb_recv); dev_free(&c->d_if_ptr); dev_free(&c->d_if_src);
+    dev_free(&c->d_split_list);
+    if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
+    if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
+    if (c->comm_stream) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipStreamDestroy(c->comm_stream);
+    }
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     for (auto& ds : c->dofsets) {
@@ -269,6 +276,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || value == 1, "exchange: 0 (all-reduce) or 1 (neighbour send/recv)");
             FEMCY_REQUIRE(value == 0 || c->d_if_ptr, "femcy_comm_set_neighbours must come first");
             c->exchange = (int)value;
+            break;
+        case FEMCY_OPT_OVERLAP:
+            FEMCY_REQUIRE(value == 0 || value == 1, "overlap: 0 (one stream) or 1 (exchange overlapped with the interior product)");
+            c->opt_overlap = (int)value;
             break;
         case FEMCY_OPT_TANGENT:
             FEMCY_REQUIRE(value == 0 || value == 1, "tangent: 0 (reference) or 1 (consistent)");
@@ -450,6 +461,7 @@ int femcy_build_pattern(femcy_ctx* ctx) {
     pcg_graph_reset(c);
     int rc = build_pattern(c);
     if (rc) return rc;
+    c->split_ready = false;
     c->have_pattern = true;
     return FEMCY_OK;
 }
@@ -1017,6 +1029,8 @@ int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id
     if (rc) return rc;
     c->niface_local = niface_local;
     c->niface_global = niface_global;
+    c->h_iface_dof.assign(iface_local_dofs, iface_local_dofs + niface_local);
+    c->split_ready = false;
     if ((rc = dev_alloc(&c->d_iface_dof, (size_t)std::max(niface_local, 1), false))) return rc;
     if ((rc = dev_alloc(&c->d_iface_slot, (size_t)std::max(niface_local, 1), false))) return rc;
     if ((rc = dev_alloc(&c->d_owner, (size_t)c->n + 64))) return rc;

@@ -744,9 +744,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 //     C3D10; the diagonal block, which every incident element hits (7-way ds_add_f64 conflicts), is not
 //     accumulated at all but taken from the row sum K_aa = -sum_{b != a} K_ab at the end, in LDS;
 //   * cubic-pattern C (all reference materials): 30 instead of 90 multiply-adds per block and Gauss point;
-//   * all rows of a slice are written by one workgroup, i.e. through ONE XCD's L2, where the 8/16-byte pieces of
-//     the lane-interleaved block rows merge into full lines before they go to HBM (the old kernel wrote 1.5 x the
-//     matrix: WRITE_SIZE 540 MB for 357 MB of K).
+//   * all rows of a slice are written by one workgroup (one XCD's L2).  (Writing the four rows the waves of a
+//     workgroup finish together as 64-byte requests, behind two barriers per row, was measured too: TA busy 140 M ->
+//     82 M cycles, WRITE_SIZE 517 -> 439 MB, kernel 389 -> 401 us -- the barriers cost what the requests saved.
+//     A fourth wave per SIMD -- __launch_bounds__(256, 4), LDS accumulator sized per slice-length class -- measured
+//     605 us: the 128-VGPR cap spills the prefetch registers.)
 // Deterministic: fixed pass order, ds_add_f64 of one instruction applied in lane order, fixed-order diagonal sum.
 template <int NPE, int NGP, bool CUBIC>
 __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t Lmax,
@@ -875,21 +877,10 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
                 if (CUBIC) kblock_cubic3(ga, gb, c11, c12, c44, vl[q * NGP + g], blk);
                 else kblock_add<3>(ga, gb, C, vl[q * NGP + g], blk);
             }
-#if defined(FEMCY_EXP_NOATOMIC)
-#pragma unroll
-            for (int k = 0; k < DD; ++k) acc[j * DD + k] = blk[k];
-#elif defined(FEMCY_EXP_NOCOMPUTE)
-            if (blk[0] == 123.456) acc[j * DD] = blk[1];
-#else
 #pragma unroll
             for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
-#endif
         }
-#ifdef FEMCY_EXP_NOWRITE
-        if (c00 + EPC >= cnt && Lmax == 12345) {
-#else
         if (c00 + EPC >= cnt) {                                 // last pass of the row: diagonal, write-out
-#endif
             const int32_t L = ROW_L(i0);
             const int r = wave + 4 * i0;
             wave_lds_sync();

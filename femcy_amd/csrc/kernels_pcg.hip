@@ -83,13 +83,16 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
 // WPS = wavefronts per slice: long rows (C3D10: 27-65 blocks per node) are split into WPS contiguous j-chunks
 // handled by WPS waves of the same workgroup and summed through LDS, so that the chain per wave stays short and
 // the few thousand slices still fill 1024 SIMDs evenly.
+// slice_list != nullptr: the XCD ranges count positions of that list instead of slices (multi-rank split product:
+// interface slices and interior slices are two launches over the two halves of one list)
 template <int DM, int WPS, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
                                              const int32_t* __restrict__ bcol, const int32_t* __restrict__ node_of,
                                              const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
-                                             double* __restrict__ partials, const int32_t* __restrict__ done) {
+                                             double* __restrict__ partials, const int32_t* __restrict__ done,
+                                             const int32_t* __restrict__ slice_list) {
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
@@ -108,8 +111,9 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
     const int ntask = (s_end - xr.start[k] + SPB - 1) / SPB;
     double dot = 0.0;
     for (int task = blockIdx.x / NXCD; task < ntask; task += bpx) {   // uniform trip count within a workgroup
-        const int s = xr.start[k] + task * SPB + wave / WPS;
-        const bool active = s < s_end;
+        const int spos = xr.start[k] + task * SPB + wave / WPS;
+        const bool active = spos < s_end;
+        const int s = (active && slice_list) ? slice_list[spos] : spos;
         double acc[DM];
 #pragma unroll
         for (int r = 0; r < DM; ++r) acc[r] = 0.0;
@@ -645,8 +649,8 @@ int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1
 // ---------------------------------------------------------------------------------------- SpMV
 __global__ void k_fence_noop() {}
 
-int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
-    const int grid = c->spmv_grid;
+static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out,
+                            const XcdRanges& xr, int grid, const int32_t* slice_list) {
     if (grid > MAX_PARTIALS) {
         set_error("SpMV grid %d exceeds MAX_PARTIALS %d", grid, MAX_PARTIALS);
         return FEMCY_EINVAL;
@@ -656,15 +660,16 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     // begin/end timestamps -- no marker packets between the PCG kernels, agrees with rocprofv3's kernel trace
     // FEMCY_OPT_TIMING = k > 1 samples every k-th SpMV launch: a profiled dispatch costs ~5 us of pipeline
     // drain, which would otherwise inflate every CG iteration of a timed run by ~10 %
-    const bool sample = c->opt_timing == 1 || (c->opt_timing > 1 && (c->spmv_count++ % c->opt_timing) == 0);
+    const bool sample = !slice_list &&
+                        (c->opt_timing == 1 || (c->opt_timing > 1 && (c->spmv_count++ % c->opt_timing) == 0));
     EventPair* ev = sample ? timing_acquire(c, T_SPMV) : nullptr;
     hipEvent_t ea = ev ? ev->a : nullptr, eb = ev ? ev->b : nullptr;
     // a sampled dispatch is preceded by an empty kernel: the profiled start stamp is taken when the packet is
     // picked up, i.e. possibly while the previous PCG kernel is still draining; the empty kernel absorbs that wait
     if (ev && c->opt_timing_fence) hipLaunchKernelGGL(k_fence_noop, dim3(1), dim3(64), 0, c->stream);
 #define SPMV_ARGS                                                                                              \
-    c->nn, c->xcd, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,  \
-        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done
+    c->nn, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,      \
+        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list
 #define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \
@@ -695,16 +700,59 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     return FEMCY_OK;
 }
 
+int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
+    return launch_spmv_impl(c, d_x, d_y, d_partials, nblocks_out, c->xcd, c->spmv_grid, nullptr);
+}
+
+// the slices that hold at least one interface node, then all others (ascending inside each half, so the interior
+// half keeps the spatial order the XCD ranges rely on)
+int split_prepare(Ctx* c) {
+    if (c->split_ready) return FEMCY_OK;
+    std::vector<uint8_t> is_if((size_t)c->nslices, 0);
+    for (int32_t dof : c->h_iface_dof) is_if[c->h_pos[dof / c->dm] >> 6] = 1;
+    std::vector<int32_t> list;
+    list.reserve(c->nslices);
+    for (int32_t s2 = 0; s2 < c->nslices; ++s2)
+        if (is_if[s2]) list.push_back(s2);
+    c->n_if_slices = (int32_t)list.size();
+    for (int32_t s2 = 0; s2 < c->nslices; ++s2)
+        if (!is_if[s2]) list.push_back(s2);
+    if (c->d_split_list) (void)hipFree(c->d_split_list);
+    c->d_split_list = nullptr;
+    FEMCY_HIP(hipMalloc((void**)&c->d_split_list, std::max<size_t>(list.size(), 1) * sizeof(int32_t)));
+    FEMCY_HIP(hipMemcpy(c->d_split_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!c->comm_stream) FEMCY_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    if (!c->ev_iface) FEMCY_HIP(hipEventCreateWithFlags(&c->ev_iface, hipEventDisableTiming));
+    if (!c->ev_xchg) FEMCY_HIP(hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming));
+    c->split_ready = true;
+    return FEMCY_OK;
+}
+
+int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d_partials, int part_off,
+                     int* nblocks_out) {
+    const int32_t p0 = part == 1 ? 0 : c->n_if_slices, p1 = part == 1 ? c->n_if_slices : c->nslices;
+    if (nblocks_out) *nblocks_out = 0;
+    if (p1 <= p0) return FEMCY_OK;
+    const int spb = 4 / c->spmv_wps;                       // slices per workgroup
+    XcdRanges xr;
+    for (int k = 0; k <= NXCD; ++k) xr.start[k] = p0 + (int32_t)((int64_t)(p1 - p0) * k / NXCD);
+    int per = 1;
+    for (int k = 0; k < NXCD; ++k) per = std::max(per, (xr.start[k + 1] - xr.start[k] + spb - 1) / spb);
+    const int grid = std::min(per, std::max(1, c->spmv_bpx_cap)) * NXCD;
+    return launch_spmv_impl(c, d_x, d_y, d_partials ? d_partials + part_off : nullptr, nblocks_out, xr, grid,
+                            c->d_split_list);
+}
+
 // sum a sub-assembled vector over the ranks that share each interface DOF
-static int iface_sum_p2p(Ctx* c, double* d_v) {
+static int iface_sum_p2p(Ctx* c, double* d_v, hipStream_t stream) {
     const int32_t total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
     if (total > 0)
-        hipLaunchKernelGGL(k_p2p_pack, dim3((total + BS - 1) / BS), dim3(BS), 0, c->stream, total, c->d_nb_dofs,
+        hipLaunchKernelGGL(k_p2p_pack, dim3((total + BS - 1) / BS), dim3(BS), 0, stream, total, c->d_nb_dofs,
                            (const double*)d_v, c->d_nb_send);
-    int rc = comm_neighbour_exchange(c);
+    int rc = comm_neighbour_exchange(c, stream);
     if (rc) return rc;
     if (c->niface_local > 0)
-        hipLaunchKernelGGL(k_p2p_sum, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, c->stream, c->niface_local,
+        hipLaunchKernelGGL(k_p2p_sum, dim3((c->niface_local + BS - 1) / BS), dim3(BS), 0, stream, c->niface_local,
                            c->d_iface_dof, c->d_if_ptr, c->d_if_src, (const double*)c->d_nb_recv, d_v);
     FEMCY_HIP(hipGetLastError());
     return FEMCY_OK;
@@ -712,7 +760,7 @@ static int iface_sum_p2p(Ctx* c, double* d_v) {
 
 int iface_sum(Ctx* c, double* d_v) {
     if (!c->comm) return FEMCY_OK;
-    if (c->exchange == 1) return iface_sum_p2p(c, d_v);
+    if (c->exchange == 1) return iface_sum_p2p(c, d_v, c->stream);
     hipLaunchKernelGGL(k_iface_pack_all, dim3((c->niface_global + BS - 1) / BS + 1), dim3(BS), 0, c->stream,
                        c->niface_global, c->d_slot2dof, d_v, c->d_commbuf, 0, (const double*)nullptr);
     int rc = comm_allreduce_sum(c, c->d_commbuf, c->niface_global);
@@ -763,17 +811,39 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
                        (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, eps);
     FEMCY_HIP(hipGetLastError());
 
+    if (multi && c->exchange == 1 && c->opt_overlap) {
+        int rc = split_prepare(c);
+        if (rc) return rc;
+    }
     // one CG iteration = 3 launches (+ the exchange in multi-rank mode); nothing in their arguments depends on
     // the iteration number or on eps (both live in PcgState), so a burst can be captured once and replayed
     auto enqueue_iteration = [&]() -> int {
         int np1 = 0;
-        int rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1);
-        if (rc) return rc;
+        int rc;
         const double* dAd_red = nullptr;
-        if (multi && c->exchange == 1) {
+        if (multi && c->exchange == 1 && c->opt_overlap) {
+            // overlapped schedule: interface slices first; their exchange (pack, send/recv, rank-ordered sum into the
+            // interface rows of Ad) runs on the comm stream while the main stream multiplies the interior slices; the
+            // scalar d.K_loc.d needs both halves and travels in an 8-byte all-reduce of its own
+            int gA = 0, gB = 0;
+            if ((rc = launch_spmv_part(c, 1, c->d_d, c->d_Ad, c->d_part1, 0, &gA))) return rc;
+            FEMCY_HIP(hipEventRecord(c->ev_iface, c->stream));
+            if ((rc = launch_spmv_part(c, 2, c->d_d, c->d_Ad, c->d_part1, gA, &gB))) return rc;
+            np1 = gA + gB;
+            FEMCY_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_iface, 0));
+            if ((rc = iface_sum_p2p(c, c->d_Ad, c->comm_stream))) return rc;
+            FEMCY_HIP(hipEventRecord(c->ev_xchg, c->comm_stream));
+            double* slot = c->d_commbuf + c->niface_global;
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, np1, (const double*)c->d_part1, 0, slot);
+            if ((rc = comm_allreduce_sum(c, slot, 1))) return rc;
+            FEMCY_HIP(hipStreamWaitEvent(c->stream, c->ev_xchg, 0));
+            dAd_red = slot;
+        } else if ((rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1))) {
+            return rc;
+        } else if (multi && c->exchange == 1) {
             // neighbour send/recv of the interface entries of Ad, then the scalar d.Ad by an 8-byte all-reduce
             double* slot = c->d_commbuf + c->niface_global;
-            if ((rc = iface_sum_p2p(c, c->d_Ad))) return rc;
+            if ((rc = iface_sum_p2p(c, c->d_Ad, c->stream))) return rc;
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BS), 0, c->stream, np1, (const double*)c->d_part1, 0, slot);
             if ((rc = comm_allreduce_sum(c, slot, 1))) return rc;
             dAd_red = slot;

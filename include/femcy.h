@@ -104,6 +104,9 @@ enum femcy_option {
     FEMCY_OPT_EXCHANGE = 8,     /* multi-rank interface exchange: 0 = all-reduce of the packed global interface vector
                                    (default), 1 = send/recv with the neighbouring ranks (needs
                                    femcy_comm_set_neighbours); femcy_comm_tune measures both and sets it */
+    FEMCY_OPT_OVERLAP = 9,      /* multi-rank PCG with the neighbour exchange: 1 (default) = the slices that hold interface
+                                   nodes are multiplied first and their exchange runs on a second stream while the
+                                   interior slices are multiplied; 0 = everything on one stream */
     FEMCY_OPT_TANGENT = 7       /* what femcy_assemble_K assembles.  0 (default) = the reference's matrix: B^T C B
                                    on the current configuration with the constant C (stiffnessMtrx.py:124-186).
                                    1 = the consistent tangent of femcy_internal_force: spatial elasticity tensor of

@@ -286,6 +286,12 @@ def test_neighbour_exchange_equals_allreduce(name, nranks, axis):
                 y = c.download(be.VEC_TMP1)
                 res = c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=40)
                 out[mode] = (y, res, c.download(be.VEC_X))
+            # the neighbour form runs overlapped by default (interface slices first, exchange on a second stream
+            # beside the interior product); the one-stream schedule must give the same iterates
+            c.set_option(be.OPT_OVERLAP, 0)
+            res = c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=40)
+            out[2] = (None, res, c.download(be.VEC_X))
+            c.set_option(be.OPT_OVERLAP, 1)
             tune = c.comm_tune(5)
             return out, tune
         finally:
@@ -297,6 +303,8 @@ def test_neighbour_exchange_equals_allreduce(name, nranks, axis):
         assert np.abs(y1 - y0).max() <= 1e-13 * np.abs(y0).max()
         assert r0[0] == r1[0] == 40 and abs(r0[2] - r1[2]) <= 1e-9 * r0[2]
         assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(x0)
+        assert out[2][1][0] == 40 and abs(out[2][1][2] - r1[2]) <= 1e-9 * r1[2]
+        assert np.linalg.norm(out[2][2] - x1) <= 1e-9 * np.linalg.norm(x1)
         assert tune["allreduce_us"] > 0 and tune["neighbour_us"] > 0          # cross-check passed on every rank
     assert len({o[1]["exchange"] for o in outs}) == 1                          # one decision for the whole job
     # replicas of shared DOFs are bit-identical under the neighbour exchange

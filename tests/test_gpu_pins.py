@@ -1,0 +1,152 @@
+"""-m gpu: the HIP path against pins that come from neither the oracle's nor the product's tables.
+
+  * one-element meshes against the exactly integrated K^e and the closed-form homogeneous-deformation forces of
+    tests/sympy_pins.py (derived symbolically from the node ordering alone);
+  * affine patch tests on multi-element meshes: under a homogeneous deformation gradient every Gauss point must carry
+    the closed-form Cauchy stress (written out here, in the test) and every interior node must be in equilibrium;
+  * the opt-in consistent tangent against the oracle's complex-step derivative of the oracle's internal force
+    (oracle.consistent_tangent) -- before round 2 that kernel was only ever compared with finite differences of the
+    HIP force itself.
+"""
+import numpy as np
+import pytest
+
+from helpers import deck, oracle_material
+from oracle import femcy_oracle as orc
+from oracle.elements import elem_def
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(factory, nodes, el, ELE, mat):
+    ctx = factory()
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(ELE)
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    return ctx
+
+
+def _ele(etype):
+    from femcy_amd import element_zoo as ez
+    return {"C3D4": ez.Element_linear_tetrahedral, "C3D10": ez.Element_quadratic_tetrahedral,
+            "CPE8": ez.Element_quadratic_quadrilateral}[etype]()
+
+
+@pytest.mark.parametrize("etype", ["C3D4", "C3D10"])
+def test_one_element_Ke_equals_exact_integration(gpu_ctx_factory, etype):
+    from types import SimpleNamespace
+    from femcy_amd import backend as be
+    import sympy_pins as spn
+    Ke, X, C = spn.exact_Ke(etype)
+    el = np.arange(X.shape[0], dtype=np.int32)[None, :]
+    mat = SimpleNamespace(kind=be_kind("lin3d"), C=C, params=np.array([1.0, 0.25]))
+    ctx = _ctx(gpu_ctx_factory, X, el, _ele(etype), mat)
+    modes = [be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ATOMIC, be.ASM_AUTO]
+    for mode in modes:
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(-1)                                    # undeformed configuration
+        K = ctx.get_K_bsr().toarray()
+        assert np.abs(K - Ke).max() < 1e-13 * np.abs(Ke).max(), mode
+
+
+def be_kind(name):
+    return {"lin3d": 0, "pstrain": 1, "pstress": 2, "neohooke": 3}[name]
+
+
+@pytest.mark.parametrize("etype", ["C3D4", "C3D10"])
+@pytest.mark.parametrize("material", ["stvk", "neohooke"])
+def test_one_element_homogeneous_deformation(gpu_ctx_factory, etype, material):
+    import sympy as sp
+    from femcy_amd import backend as be
+    from femcy_amd.material_zoo import LinearIsotropic, NeoHookean
+    import sympy_pins as spn
+    if material == "stvk":
+        lam, mu = 1.5, 1.25
+        spec = ("stvk", sp.Rational(3, 2), sp.Rational(5, 4))
+        mat = LinearIsotropic(mu * (3 * lam + 2 * mu) / (lam + mu), lam / (2 * (lam + mu)))
+    else:
+        spec = ("neohooke", sp.Rational(2, 5), sp.Rational(1, 4))
+        mat = NeoHookean(0.4, 0.25)
+    f, u, X, F, sig = spn.homogeneous_case(etype, spec)
+    el = np.arange(X.shape[0], dtype=np.int32)[None, :]
+    ctx = _ctx(gpu_ctx_factory, X, el, _ele(etype), mat)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.residual_and_K(be.VEC_DOF, be.VEC_FORCE)
+    assert np.abs(ctx.download(be.VEC_FORCE) - f).max() < 1e-13 * np.abs(f).max()
+    Fg = ctx.gauss_field(be.GP_F).to_numpy()
+    Sg = ctx.gauss_field(be.GP_SIGMA).to_numpy()
+    assert np.abs(Fg - F).max() < 1e-14 and np.abs(Sg - sig).max() < 1e-13 * np.abs(sig).max()
+
+
+def _closed_form_cauchy(kind, F, params):
+    """written out here, independent of oracle/ and of the kernels (material_zoo docstrings give the laws)"""
+    dm = F.shape[0]
+    J = np.linalg.det(F)
+    if kind == "neohooke":
+        C1, D1 = params
+        return 2 * C1 / J * (F @ F.T - np.eye(dm)) + 2 * D1 * (J - 1) * np.eye(dm)
+    E_, nu = params
+    lam, mu = E_ * nu / ((1 + nu) * (1 - 2 * nu)), E_ / (2 * (1 + nu))
+    E = (F.T @ F - np.eye(dm)) / 2
+    S = lam * np.trace(E) * np.eye(dm) + 2 * mu * E              # 3-D St.Venant-Kirchhoff; plane strain: E33 = 0
+    return F @ S @ F.T / J
+
+
+@pytest.mark.parametrize("name,kind", [("twist_plate_C3D4.inp", "lin3d"), ("twist_C3D10_coarse.inp", "lin3d"),
+                                       ("cook_3d_linearEl_largeDef.inp", "neohooke"), ("gen_beam_CPE8_tip4.inp", "pstrain")])
+def test_affine_patch(gpu_ctx_factory, name, kind):
+    """homogeneous F on a whole mesh: sigma = closed form at every Gauss point, interior nodes in equilibrium"""
+    from femcy_amd import backend as be
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    el = inp.eSets[et]
+    mat = list(inp.materials.values())[0]
+    assert oracle_material(mat).kind == kind
+    dm = inp.nodes.shape[1]
+    F = np.array([[1.08, 0.05, -0.03], [0.02, 0.95, 0.06], [-0.04, 0.07, 1.04]])[:dm, :dm]
+    u = (inp.nodes @ (F - np.eye(dm)).T).ravel()
+    ctx = _ctx(gpu_ctx_factory, inp.nodes, el, inp.ELE, mat)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.residual_and_K(be.VEC_DOF, be.VEC_FORCE)
+    f = ctx.download(be.VEC_FORCE).reshape(-1, dm)
+    sig = _closed_form_cauchy(kind, F, [float(v) for v in mat.params])
+    Sg = ctx.gauss_field(be.GP_SIGMA).to_numpy()
+    Fg = ctx.gauss_field(be.GP_F).to_numpy()
+    assert np.abs(Fg - F).max() < 1e-12
+    assert np.abs(Sg - sig).max() < 1e-11 * np.abs(sig).max()
+    boundary_nodes = np.unique(np.concatenate([np.asarray(k) for k in Body(inp.nodes, el, inp.ELE).get_boundary().keys()]))
+    interior = np.setdiff1d(np.arange(inp.nodes.shape[0]), boundary_nodes)
+    assert interior.size > 0
+    assert np.abs(f[interior]).max() < 1e-10 * np.abs(f).max()
+    # total force = 0 and total moment = 0 (a homogeneous stress field is self-equilibrated)
+    assert np.abs(f.sum(axis=0)).max() < 1e-10 * np.abs(f).max()
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "cook_3d_linearEl_largeDef.inp", "twist_C3D10_coarse.inp",
+                                  "cookMembrane_2d_linearEl_largeDef.inp"])
+def test_consistent_tangent_equals_oracle_complex_step(gpu_ctx_factory, name):
+    from femcy_amd import backend as be
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    el = inp.eSets[et]
+    mat = list(inp.materials.values())[0]
+    topo = orc.Topology(inp.nodes, el, elem_def(et))
+    L = np.ptp(inp.nodes, axis=0).max()
+    x = inp.nodes / L
+    u = (0.05 * L * np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]), 0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0],
+                              0.3 * np.sin(x.sum(axis=1))][:topo.dm], axis=1)).ravel()
+    Ko = orc.consistent_tangent(topo, u, oracle_material(mat))
+    ctx = _ctx(gpu_ctx_factory, inp.nodes, el, inp.ELE, mat)
+    ctx.set_option(be.OPT_TANGENT, 1)
+    ctx.upload(be.VEC_DOF, u)
+    ctx.assemble_K(be.VEC_DOF)
+    K = ctx.get_K_bsr().tocsr()
+    assert abs(K - Ko).max() < 1e-10 * abs(Ko).max()
+    # and the reference's matrix (B^T C B with the constant C) is NOT that derivative at 5 % strain
+    ctx.set_option(be.OPT_TANGENT, 0)
+    ctx.assemble_K(be.VEC_DOF)
+    assert abs(ctx.get_K_bsr().tocsr() - Ko).max() > 1e-3 * abs(Ko).max()
