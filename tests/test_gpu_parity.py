@@ -380,7 +380,9 @@ def test_dirichlet(gpu_ctx_factory, name):
 @pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "ellip_membrane_quadritic_trig_neumann.inp",
                                   "twist_C3D10_coarse.inp"])
 def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
-    """same recurrence, same stopping rule: iteration counts equal and iterates agree."""
+    """same recurrence, same stopping rule: iterates agree and the stop falls on the same iteration up to the drift
+    that a different summation order causes at a tight tolerance (at most max(2, 2 %) iterations, asserted below; the
+    fixed-iteration comparisons of tests/test_gpu_fullsize.py and test_gpu_multirank.py are exact in the count)."""
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
     ctx = make_ctx(gpu_ctx_factory, inp, el, mat)

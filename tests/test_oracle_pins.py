@@ -257,3 +257,97 @@ def test_element_golden_vectors():
         dsdx, vol = orc.dsdx_and_vol(inp.nodes, el, np.zeros(inp.nodes.size), elem_def(et))
         Ke = orc.element_stiffness(dsdx, vol, oracle_material(list(inp.materials.values())[0]).C)[0]
         assert np.abs(Ke - g[et]).max() <= 1e-12 * np.abs(g[et]).max()
+
+
+# ------------------------------------------------------------------ (iv) first-principles pins (sympy, tests/sympy_pins.py)
+# Everything above pins the oracle against itself or against 2-D published numbers.  The tetrahedral path (the
+# headline configuration) is pinned here against derivations that use neither the oracle's nor the product's
+# tables: nodal polynomial bases solved from the interpolation conditions, exactly integrated element matrices,
+# closed-form forces of a homogeneous deformation.
+TETS = ["C3D4", "C3D10"]
+
+
+@pytest.mark.parametrize("etype", TETS)
+def test_sympy_shape_functions_pin_the_tables(etype):
+    import sympy_pins as spn
+    from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
+    N, dN = spn.numeric_tables(etype)
+    ed = elem_def(etype)
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        c = rng.random(3) * 0.33
+        assert np.abs(N(c) - ed.N(c)).max() < 1e-14
+        assert np.abs(dN(c) - ed.dN(c)).max() < 1e-13
+    # the product's plugin tables (what the HIP kernels are fed) at its own Gauss points
+    ELE = Element_linear_tetrahedral() if etype == "C3D4" else Element_quadratic_tetrahedral()
+    t = ELE.tables()
+    assert t["npe"] == ed.npe and t["nGP"] == ed.nGP
+    for g, c in enumerate(ed.gauss_points):
+        assert np.abs(np.asarray(t["dN"]).reshape(ed.nGP, ed.npe, 3)[g] - dN(c)).max() < 1e-13
+    # the Gauss rule itself: exact for the complete polynomial space of degree 1 (C3D4) / 2 (C3D10) on the
+    # reference tetrahedron, i.e. for every product the stiffness integrand of an affine element contains
+    deg = 1 if etype == "C3D4" else 2
+    w = np.asarray(t["w"], dtype=float)
+    for a in range(deg + 1):
+        for b in range(deg + 1 - a):
+            for c_ in range(deg + 1 - a - b):
+                exact = float(spn.integrate_ref_tet(spn.XI ** a * spn.ETA ** b * spn.ZETA ** c_))
+                got = sum(w[g] * p[0] ** a * p[1] ** b * p[2] ** c_ for g, p in enumerate(ed.gauss_points))
+                assert abs(got - exact) < 1e-15, (a, b, c_)
+
+
+@pytest.mark.parametrize("etype", TETS)
+def test_exactly_integrated_Ke_pins_the_oracle(etype):
+    """K^e of an affine element integrated exactly in rational arithmetic (the Gauss rules above are exact for it)"""
+    import sympy_pins as spn
+    Ke, X, C = spn.exact_Ke(etype)
+    ed = elem_def(etype)
+    el = np.arange(X.shape[0])[None, :]
+    dsdx, vol = orc.dsdx_and_vol(X, el, np.zeros(X.size), ed)
+    Ko = orc.element_stiffness(dsdx, vol, C)[0]
+    assert np.abs(Ko - Ke).max() < 5e-14 * np.abs(Ke).max()
+    assert abs(vol.sum() - abs(np.linalg.det(X[1:4] - X[0])) / 6.0) < 1e-14 * vol.sum()     # the element's volume
+
+
+@pytest.mark.parametrize("etype", TETS)
+@pytest.mark.parametrize("material", ["stvk", "neohooke"])
+def test_homogeneous_deformation_pins_the_large_deformation_path(etype, material):
+    """F, Cauchy stress and nodal forces of one element under a homogeneous finite deformation, in closed form"""
+    import sympy as sp
+    import sympy_pins as spn
+    if material == "stvk":
+        lam, mu = 1.5, 1.25
+        spec = ("stvk", sp.Rational(3, 2), sp.Rational(5, 4))
+        mat = orc.Material("lin3d", (mu * (3 * lam + 2 * mu) / (lam + mu), lam / (2 * (lam + mu))))
+    else:
+        spec = ("neohooke", sp.Rational(2, 5), sp.Rational(1, 4))
+        mat = orc.Material("neohooke", (0.4, 0.25))
+    f, u, X, F, sig = spn.homogeneous_case(etype, spec)
+    ed = elem_def(etype)
+    topo = orc.Topology(X, np.arange(X.shape[0])[None, :], ed)
+    fo, so, Fo, _, _ = orc.internal_force(topo, u, mat)
+    assert np.abs(Fo - F).max() < 1e-14
+    assert np.abs(so - sig).max() < 1e-13 * np.abs(sig).max()
+    assert np.abs(fo - f).max() < 1e-13 * np.abs(f).max()
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "cook_3d_linearEl_largeDef.inp", "twist_C3D10_coarse.inp",
+                                  "cookMembrane_2d_linearEl_largeDef.inp"])
+def test_oracle_consistent_tangent_is_the_derivative_of_the_oracle_force(name):
+    """oracle.consistent_tangent (complex step) against central differences of oracle.internal_force, and symmetric
+    (these materials are hyperelastic): the checker the device tangent is compared with in tests/test_gpu_pins.py"""
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    mat = oracle_material(list(inp.materials.values())[0])
+    topo = orc.Topology(inp.nodes, inp.eSets[et], elem_def(et))
+    L = np.ptp(inp.nodes, axis=0).max()
+    x = inp.nodes / L
+    u = (0.05 * L * np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]),
+                              0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0],
+                              0.3 * np.sin(x.sum(axis=1))][:topo.dm], axis=1)).ravel()
+    K = orc.consistent_tangent(topo, u, mat)
+    assert abs(K - K.T).max() < 1e-13 * abs(K).max()
+    v = np.random.default_rng(0).standard_normal(topo.n)
+    h = 1e-6 * L
+    fd = (orc.internal_force(topo, u + h * v, mat)[0] - orc.internal_force(topo, u - h * v, mat)[0]) / (2 * h)
+    assert np.abs(K @ v - fd).max() < 1e-6 * np.abs(fd).max()
