@@ -153,6 +153,12 @@ struct Ctx {
     const double* pcg_graph_x = nullptr;
     int pcg_graph_iters = 0, pcg_graph_g = 0, pcg_graph_np1 = 0;
     int opt_graph = 1;
+    // ---- one-launch PCG for small systems (k_pcg_small)
+    int opt_small = 1;                // FEMCY_OPT_PCG_SMALL
+    int small_max_lds = 65536;        // LDS a workgroup may allocate (device attribute, femcy_ctx_create)
+    int small_max_wg = 128;           // workgroups that are certainly co-resident at one per CU
+    double* d_small = nullptr;        // Ad double buffer, d.Ad partials, barrier counter
+    int64_t small_cap = 0;
     int ew_cap = 512;                 // FEMCY_OPT_EW_GRID
 
     // ---- device-resident DOF lists of *Boundary blocks

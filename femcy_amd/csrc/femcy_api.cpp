@@ -191,6 +191,13 @@ int femcy_ctx_create(int device, femcy_ctx** out) {
         delete ctx;
         return FEMCY_ENOMEM;
     }
+    {
+        int lds = 0, cus = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+            c->small_max_lds = lds;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            c->small_max_wg = std::max(1, cus / 2);   // one workgroup per CU with half the chip to spare
+    }
     *out = ctx;
     return FEMCY_OK;
 }
@@ -217,6 +224,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_gather);
     dev_free(&c->d_nb_dofs); dev_free(&c->d_nb_send); dev_free(&c->d_nb_recv); dev_free(&c->d_if_ptr); dev_free(&c->d_if_src);
     dev_free(&c->d_split_list);
+    dev_free(&c->d_small);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
     if (c->comm_stream) {
@@ -276,6 +284,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || value == 1, "exchange: 0 (all-reduce) or 1 (neighbour send/recv)");
             FEMCY_REQUIRE(value == 0 || c->d_if_ptr, "femcy_comm_set_neighbours must come first");
             c->exchange = (int)value;
+            break;
+        case FEMCY_OPT_PCG_SMALL:
+            FEMCY_REQUIRE(value == 0 || value == 1, "small-system PCG: 0 (off) or 1 (auto)");
+            c->opt_small = (int)value;
             break;
         case FEMCY_OPT_OVERLAP:
             FEMCY_REQUIRE(value == 0 || value == 1, "overlap: 0 (one stream) or 1 (exchange overlapped with the interior product)");

@@ -772,6 +772,262 @@ int iface_sum(Ctx* c, double* d_v) {
     return FEMCY_OK;
 }
 
+// ------------------------------------------------------------------- small systems: one launch per solve
+// Below ~1e4 DOF (every deck the reference ships) an iteration of the three-kernel loop costs 17 us -- launch latency,
+// from a hipGraph as well -- for 1-2 us of work.  Here the whole solve is ONE persistent launch with ONE grid barrier
+// per iteration: workgroup g multiplies slice g by d, publishes its rows of Ad (write-through stores) and its part of
+// d.Ad, meets the others at the barrier, and then updates the WHOLE r and d -- redundantly, every workgroup the same
+// arithmetic in the same order on its private copy (r and M in registers, d in LDS) -- so the reductions r.M.r and
+// max|r| need no second exchange and the gathers of the next product read d from LDS.  x is kept in registers for the
+// workgroup's own rows only and written once at the end.  Recurrence, preconditioner (Jacobi) and stopping rule are those of pcg_solve / the reference
+// (conjugateGradientSolver.py:103-127).
+// Inter-workgroup protocol (cdna_hip_programming.md, Guideline 16, form R1): payload = sc1 stores, every storing wave
+// drains vmcnt, one lane arrives on a monotonic agent-scope counter; consumers poll that counter relaxed and read the
+// payload with sc1 loads.  Ad and the d.Ad partials are double-buffered by iteration parity: a workgroup can run at
+// most one barrier ahead of the slowest one.  Every spin is bounded; a timeout ends the launch with state.done = 3.
+struct SmallPcg {
+    const int32_t* slice_len;
+    const int64_t* slice_off;
+    const int32_t* bcol;
+    const int32_t* node_of;
+    const double* vals;
+    const double* b;
+    const double* M;
+    double* x;
+    double* Adbuf;        // [2][npad]
+    double* part;         // [2][G]
+    unsigned int* counter;
+    PcgState* st;
+    int32_t n, npad, maxit;
+    double eps;
+};
+
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K = ceil(n / 256): thread t owns the entries t, t + 256, ... of r and M and keeps them in REGISTERS for the whole
+// solve (one workgroup per CU: a wave may use the full register file); only d, which the product gathers, lives in LDS
+template <int DM, int K>
+__global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_small[];
+    double* d_l = lds_small;
+    double* red = d_l + a.npad;                 // [4][DM][64] partial rows of the four waves
+    double* sm1 = red + 4 * DM * 64;
+    double* sm2 = sm1 + BS / 64;
+    __shared__ int s_fail;
+    const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    constexpr int DD = DM * DM, NP = DD / 2;
+    if (tid == 0) s_fail = 0;
+
+    // ---- x0 = 0, r = b, d = M r; r.M.r and max|r0| (every workgroup computes the same numbers)
+    double rr[K], mm[K];
+    double accs = 0.0, accm = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = tid + k * BS;
+        const bool in = i < n;
+        const int ic = in ? i : n - 1;
+        const double bi = in ? a.b[ic] : 0.0, mi = a.M[ic];
+        rr[k] = bi;
+        mm[k] = mi;
+        if (in) d_l[i] = mi * bi;
+        accs += bi * mi * bi;
+        accm = fmax(accm, nan_to_inf_abs(bi));
+    }
+    double rMr = block_sum(accs, sm1);
+    const double r0 = block_max(accm, sm2);
+    double rmax = r0;
+    const int32_t node = a.node_of[(int64_t)g * SLICE + lane];   // row permutation (SELL-C-sigma); -1 = padding lane
+    double xo[DM];                                               // the workgroup's own rows of x (wave 0)
+#pragma unroll
+    for (int r = 0; r < DM; ++r) xo[r] = 0.0;
+    int done = (r0 == 0.0) ? 1 : ((r0 != r0 || isinf(r0)) ? 2 : 0);
+    int it = 0;
+    const int32_t L = a.slice_len[g];
+    const int64_t off = a.slice_off[g];
+    const int32_t chunk = (L + 3) / 4;
+    const int32_t j0 = wave * chunk, j1 = min(L, j0 + chunk);
+    const int32_t* __restrict__ bc = a.bcol + off * SLICE + lane;
+    const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + off * (int64_t)(DD * SLICE)) + lane;
+    const double* __restrict__ vs = a.vals + off * (int64_t)(DD * SLICE) + NP * (2 * SLICE) + lane;
+    while (!done && it < a.maxit) {
+        __syncthreads();                                 // d_l of the previous iteration is complete
+        // ---- rows of slice g of K d, four waves share the row (block columns j0 .. j1 each), d gathered from LDS
+        double acc[DM];
+#pragma unroll
+        for (int r = 0; r < DM; ++r) acc[r] = 0.0;
+#pragma unroll 2
+        for (int32_t j = j0; j < j1; ++j) {
+            const int32_t col = bc[(int64_t)j * SLICE];
+            double xv[DM], e[DD];
+#pragma unroll
+            for (int kp = 0; kp < NP; ++kp) {
+                const double2 t = vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE];
+                e[2 * kp] = t.x;
+                e[2 * kp + 1] = t.y;
+            }
+            if (DD & 1) e[DD - 1] = vs[(int64_t)j * (DD * SLICE)];
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) xv[cc] = d_l[col * DM + cc];
+#pragma unroll
+            for (int r = 0; r < DM; ++r)
+#pragma unroll
+                for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
+        }
+#pragma unroll
+        for (int r = 0; r < DM; ++r) red[(wave * DM + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        double dot = 0.0;
+        double dold[DM];
+        double* Adw = a.Adbuf + (size_t)(it & 1) * a.npad;
+        if (wave == 0 && node >= 0) {
+#pragma unroll
+            for (int r = 0; r < DM; ++r) {
+                double v = acc[r];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v += red[(w * DM + r) * 64 + lane];
+                st_sc1(Adw + (int64_t)node * DM + r, v);
+                dold[r] = d_l[node * DM + r];
+                dot += dold[r] * v;
+            }
+        }
+        if (wave == 0) {                                 // only wave 0 holds rows: its own shuffle tree is the block sum
+            const double pd = wave_sum(dot);
+            if (lane == 0) st_sc1(a.part + (size_t)(it & 1) * G + g, pd);
+        }
+        // ---- grid barrier: arrive after the stores have drained, wait for everybody
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int target = (unsigned int)G * (unsigned int)(it + 1);
+            unsigned int spins = 0;
+            while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 26)) {              // seconds: a workgroup is missing (not resident / died)
+                    s_fail = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            done = 3;
+            break;
+        }
+        // ---- alpha; x (own rows), r, reductions, d -- the whole vectors in every workgroup; all loads first
+        const double ps = tid < G ? ld_sc1(a.part + (size_t)(it & 1) * G + tid) : 0.0;    // G <= 128 < BS
+        double av[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) av[k] = ld_sc1(Adw + min(tid + k * BS, n - 1));
+        const double dAd = block_sum(ps, sm1);
+        const double alpha = rMr / dAd;
+        if (wave == 0 && node >= 0) {
+#pragma unroll
+            for (int r = 0; r < DM; ++r) xo[r] += alpha * dold[r];
+        }
+        accs = 0.0;
+        accm = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool in = tid + k * BS < n;
+            const double ri = in ? rr[k] - alpha * av[k] : 0.0;
+            rr[k] = ri;
+            accs += ri * mm[k] * ri;
+            accm = fmax(accm, nan_to_inf_abs(ri));
+        }
+        // r.M.r and max|r| through one pair of barriers
+        accs = wave_sum(accs);
+        accm = wave_max(accm);
+        if (lane == 0) {
+            sm1[wave] = accs;
+            sm2[wave] = accm;
+        }
+        __syncthreads();
+        const double rMr_new = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+        rmax = fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3]));
+        ++it;
+        if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
+            done = 2;
+        } else if (rmax < a.eps * r0) {
+            done = 1;
+        } else {
+            const double beta = rMr_new / rMr;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int i = tid + k * BS;
+                if (i < n) d_l[i] = mm[k] * rr[k] + beta * d_l[i];
+            }
+        }
+        rMr = rMr_new;
+    }
+    if (wave == 0 && node >= 0) {
+#pragma unroll
+        for (int r = 0; r < DM; ++r) a.x[(int64_t)node * DM + r] = xo[r];
+    }
+    if (g == 0 && tid == 0) {
+        a.st->iters = it;
+        a.st->r0 = r0;
+        a.st->rmax = rmax;
+        a.st->done = done;
+        a.st->rMr[0] = rMr;
+    }
+}
+
+// eligibility + launch; returns FEMCY_OK with *handled = false when the system does not qualify
+static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
+    *handled = false;
+    constexpr int KMAX = 48;                               // 48 * 256 = 12 288 DOF (K = 80 spills the register file)
+    if (!c->opt_small || c->comm || c->opt_timing || c->nslices > c->small_max_wg || c->n > (int64_t)KMAX * BS)
+        return FEMCY_OK;
+    const int64_t npad = (c->n + 1) & ~(int64_t)1;
+    const size_t lds = (size_t)(npad + 4 * c->dm * 64 + 2 * (BS / 64)) * sizeof(double);
+    if (lds + 256 > (size_t)c->small_max_lds) return FEMCY_OK;    // + the kernel's static LDS
+    const int G = c->nslices;
+    if (!c->d_small || c->small_cap < 2 * npad + 2 * G + 8) {
+        if (c->d_small) (void)hipFree(c->d_small);
+        c->d_small = nullptr;
+        c->small_cap = 2 * npad + 2 * G + 8;
+        FEMCY_HIP(hipMalloc((void**)&c->d_small, sizeof(double) * c->small_cap));
+    }
+    SmallPcg a;
+    a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = c->d_bcol; a.node_of = c->d_node_of;
+    a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
+    a.Adbuf = c->d_small;
+    a.part = c->d_small + 2 * npad;
+    a.counter = reinterpret_cast<unsigned int*>(c->d_small + 2 * npad + 2 * G);
+    a.st = c->d_state;
+    a.n = (int32_t)c->n; a.npad = (int32_t)npad; a.maxit = maxit; a.eps = eps;
+    FEMCY_HIP(hipMemsetAsync(a.counter, 0, 8, c->stream));
+    const int kneed = (int)((c->n + BS - 1) / BS);
+    // register buckets: thread t keeps entries t + 256 k, k < K, of r and M
+#define FEMCY_SMALL(DM_, K_)                                                                                       \
+    do {                                                                                                           \
+        const void* fn = reinterpret_cast<const void*>(&k_pcg_small<DM_, K_>);                                     \
+        if (lds > 48 * 1024)                                                                                       \
+            FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((k_pcg_small<DM_, K_>), dim3(G), dim3(BS), lds, c->stream, a);                          \
+    } while (0)
+#define FEMCY_SMALL_K(DM_)                        \
+    do {                                          \
+        if (kneed <= 8) FEMCY_SMALL(DM_, 8);      \
+        else if (kneed <= 24) FEMCY_SMALL(DM_, 24); \
+        else FEMCY_SMALL(DM_, 48);                \
+    } while (0)
+    if (c->dm == 3) FEMCY_SMALL_K(3); else FEMCY_SMALL_K(2);
+#undef FEMCY_SMALL_K
+#undef FEMCY_SMALL
+    FEMCY_HIP(hipGetLastError());
+    *handled = true;
+    return FEMCY_OK;
+}
+
 void pcg_graph_reset(Ctx* c) {
     if (c->pcg_graph) (void)hipGraphExecDestroy(c->pcg_graph);
     c->pcg_graph = nullptr;
@@ -798,6 +1054,29 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         int rc = iface_sum(c, c->d_M);
         if (rc) return rc;
         hipLaunchKernelGGL(k_recip, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
+    }
+    if (!multi) {
+        bool handled = false;
+        int rc = pcg_small_solve(c, d_b, d_x, eps, maxit, &handled);
+        if (rc) return rc;
+        if (handled) {
+            FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            timing_end(c, th);
+            if (iters) *iters = c->h_state->iters;
+            if (r0) *r0 = c->h_state->r0;
+            if (rmax) *rmax = c->h_state->rmax;
+            c->timing.pcg_iters += c->h_state->iters;
+            if (c->h_state->done == 3) {
+                set_error("small-system PCG: grid barrier timed out after %d iterations (a workgroup was not resident)", c->h_state->iters);
+                return FEMCY_EHIP;
+            }
+            if (c->h_state->done == 2) {
+                set_error("PCG breakdown: NaN/Inf residual after %d iterations (r0 = %g)", c->h_state->iters, c->h_state->r0);
+                return FEMCY_ENUMERIC;
+            }
+            return FEMCY_OK;
+        }
     }
     hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)d_b, (const double2*)c->d_M,
                        (double2*)d_x, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),

@@ -142,6 +142,7 @@ class System_of_equations:
         it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps,
                                     maxit=self.PCG.maxit if maxit is None else maxit)
         self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
+        self.PCG.converged = r0 == 0.0 or rmax < self.PCG.eps * r0
         self.stats["linear_solves"] += 1
         self.stats["cg_iterations"] += it
         self.du.copy_from(self.PCG.x)
@@ -155,7 +156,15 @@ class System_of_equations:
         """name kept for compatibility: the "direct" branch is a tight device PCG (module docstring)."""
         # standing in for a direct solve: CG in floating point can need more than n iterations on an ill-conditioned
         # K (nu -> 0.5), so the cap is 10 n here instead of the reference CG's n
-        return self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
+        du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
+        if not self.PCG.converged:
+            # a direct solver would have returned the solution (or failed loudly); an unconverged iterate must not be
+            # used as if it were one: report it like a numerical breakdown, so that a Newton step is cut back
+            # (advance_inc) and a linear deck fails instead of printing a wrong answer
+            raise be.FemcyError("direct-solve stand-in: PCG stopped at max|r| = {:.3e} > {:.1e} * {:.3e} after {} "
+                                "iterations".format(self.PCG.rmax, self.direct_eps, self.PCG.r0, self.PCG.iterations),
+                                status=be.FEMCY_ENUMERIC)
+        return du
 
     def solve_dof(self):
         if self.n_system < 1e5:                        # DOFs of the whole system (all ranks take the same branch)
@@ -169,13 +178,15 @@ class System_of_equations:
 
     def _dofset(self, nodeSet, dm_specified: int) -> int:
         """device-resident DOF list of a (node set, component) pair; the reference likewise turns every node
-        set into a ti.field once per solve (:656-659).  Cached per node-set object."""
-        key = (id(nodeSet), dm_specified)
-        hit = self._dofsets.get(key)
-        if hit is None or hit[0] is not nodeSet:
-            hit = (nodeSet, self.ctx.dofset(self._node_ids(nodeSet) * self.dm + dm_specified))
-            self._dofsets[key] = hit
-        return hit[1]
+        set into a ti.field once per solve (:656-659).  Cached by content."""
+        ids = self._node_ids(nodeSet)
+        key = (dm_specified, ids.size, int(ids[0]) if ids.size else -1, int(ids[-1]) if ids.size else -1, int(ids.sum()))
+        for cached_ids, ds in self._dofsets.get(key, ()):        # keyed by content: solve() re-wraps the node sets on
+            if np.array_equal(cached_ids, ids):                  # every call, the device lists must not pile up
+                return ds
+        ds = self.ctx.dofset(ids * self.dm + dm_specified)
+        self._dofsets.setdefault(key, []).append((ids.copy(), ds))
+        return ds
 
     def dirichletBC_linearEquations(self, nodeSet, dm_specified: int, sval: float):
         self.ctx.dofset_dirichlet_linear(self._dofset(nodeSet, dm_specified), sval, be.VEC_RHS)
@@ -201,7 +212,7 @@ class System_of_equations:
         """device load set of one *Dsload surface, built once per face set: owning element of each facet
         (body.boundary, reference :386) and the facet's type = position of its sorted local node tuple in the
         element plugin's facet tables (reference :388-392)."""
-        key = id(load_facets)
+        key = frozenset(tuple(f) for f in load_facets)           # by content: repeated solve() calls reuse the device set
         if key not in self._loadsets:
             boundary = self.body.get_boundary()
             facets = [tuple(f) for f in load_facets]
@@ -215,7 +226,7 @@ class System_of_equations:
             keys = self.ELE.facet_tables()["keys"]
             type_of = {k: i for i, k in enumerate(keys)}
             ft = np.fromiter((type_of[tuple(r)] for r in local.tolist()), dtype=np.int32, count=len(facets))
-            self._loadsets[key] = (self.ctx.loadset(self.ELE, elem, ft), load_facets)    # keep the set alive: id() is the key
+            self._loadsets[key] = (self.ctx.loadset(self.ELE, elem, ft), load_facets)
         return self._loadsets[key][0]
 
     def neumannBC(self, load_facets, load_val: float, load_dir=np.array([])):

@@ -104,6 +104,9 @@ enum femcy_option {
     FEMCY_OPT_EXCHANGE = 8,     /* multi-rank interface exchange: 0 = all-reduce of the packed global interface vector
                                    (default), 1 = send/recv with the neighbouring ranks (needs
                                    femcy_comm_set_neighbours); femcy_comm_tune measures both and sets it */
+    FEMCY_OPT_PCG_SMALL = 10,   /* 1 (default): systems whose two work vectors fit the LDS of a workgroup (~1e4 DOF on
+                                   MI355X) are solved by ONE persistent launch with one grid barrier per iteration
+                                   instead of three launches per iteration; 0 = always the three-kernel loop */
     FEMCY_OPT_OVERLAP = 9,      /* multi-rank PCG with the neighbour exchange: 1 (default) = the slices that hold interface
                                    nodes are multiplied first and their exchange runs on a second stream while the
                                    interior slices are multiplied; 0 = everything on one stream */
