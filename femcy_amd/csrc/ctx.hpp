@@ -109,7 +109,8 @@ struct Ctx {
     int32_t* d_rowlen = nullptr;      // [nn] blocks per node (indexed by node)
     int32_t* d_pos = nullptr;         // [nn] node -> storage position (slice*64 + lane): SELL-C-sigma row order
     int32_t* d_node_of = nullptr;     // [nslices*64] storage position -> node, -1 for padding lanes
-    int32_t sell_sigma = 4096;        // sorting window (nodes); 64 = natural order
+    int32_t sell_sigma = 4096;        // sorting window (nodes); 64 = natural order.  (32768 measured -1 % ... +1 % per PCG
+                                      // iteration inside bench.py on the C3D4 and C3D10 plates: no reason to move it)
     int32_t* d_bcol = nullptr;        // [stored_rows*64]
     double* d_Kvals = nullptr;        // [stored_rows*dm*dm*64]
     uint16_t* d_slotj = nullptr;      // [ne*npe*npe] element-local (a,b) -> slot j in row of node a

@@ -540,6 +540,28 @@ __global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos
     }
 }
 
+// B_a^T C B_b * v for a C with the cubic sparsity pattern (c11 on the normal diagonal, c12 between normal
+// components, c44 on the shear diagonal, zero elsewhere): every material of the reference -- isotropic Hooke
+// (c11 = lambda + 2 mu, c12 = lambda, c44 = mu) and the neo-Hookean constant tangent 4 C1 I + 2 D1 1x1 -- has it.
+//   K[i][k] = c12 a_i b_k + c44 a_k b_i                     (i != k)
+//   K[i][i] = c11 a_i b_i + c44 sum_{j != i} a_j b_j
+// 30 multiply-adds instead of the 90 of the dense-pattern evaluation; femcy_set_material detects the pattern with
+// exact comparisons and everything else takes kblock_add.
+__device__ __forceinline__ void kblock_cubic3(const double* __restrict__ ga, const double* __restrict__ gb, double c11,
+                                              double c12, double c44, double v, double (&acc)[9]) {
+    const double a0 = ga[0] * v, a1 = ga[1] * v, a2 = ga[2] * v, b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    const double p00 = a0 * b0, p11 = a1 * b1, p22 = a2 * b2;
+    acc[0] += c11 * p00 + c44 * (p11 + p22);
+    acc[4] += c11 * p11 + c44 * (p00 + p22);
+    acc[8] += c11 * p22 + c44 * (p00 + p11);
+    acc[1] += c12 * (a0 * b1) + c44 * (a1 * b0);
+    acc[2] += c12 * (a0 * b2) + c44 * (a2 * b0);
+    acc[3] += c12 * (a1 * b0) + c44 * (a0 * b1);
+    acc[5] += c12 * (a1 * b2) + c44 * (a2 * b1);
+    acc[6] += c12 * (a2 * b0) + c44 * (a0 * b2);
+    acc[7] += c12 * (a2 * b1) + c44 * (a1 * b2);
+}
+
 // owner-computes assembly: lane p = stored block (row = p / 64, lane = p % 64).
 // (A variant with the element arity as a template parameter -- constant-divisor decode of the packed
 // contribution code -- measured 28 % slower on gfx950 for C3D4 and equal for C3D10: the kernel is bound by
@@ -549,13 +571,14 @@ __global__ void __launch_bounds__(256) k_assemble_gather_consistent(int64_t npos
 // the position of block (b, a).  tpos = -2 marks the mirrored (skipped) lanes, -1 padding.  Halves the dsdx
 // gathers that bound this kernel; the mirrored stores of a wavefront land in one block row of the neighbouring
 // slice on structured numberings, i.e. they stay coalesced.  K comes out exactly symmetric.
-template <int DM, bool SYM>
+template <int DM, bool SYM, bool CUBIC>
 __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t npe, int32_t nGP,
                                                          const int32_t* __restrict__ ctr_ptr,
                                                          const int32_t* __restrict__ ctr,
                                                          const int32_t* __restrict__ tpos,
                                                          const double* __restrict__ dsdx,
                                                          const double* __restrict__ vol, const double* __restrict__ C,
+                                                         double c11, double c12, double c44,
                                                          double* __restrict__ Kvals, int skip_diag) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npos) return;
@@ -582,8 +605,13 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
         for (int k = 0; k < DM * DM; ++k) acc1[k] = 0.0;
         for (int g = 0; g < nGP; ++g) {
             const int64_t b0 = (e0 * nGP + g) * npe, b1 = (e1 * nGP + g) * npe;
-            kblock_add<DM>(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, C, vol[e0 * nGP + g], acc);
-            kblock_add<DM>(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, C, vol[e1 * nGP + g], acc1);
+            if constexpr (CUBIC && DM == 3) {
+                kblock_cubic3(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, c11, c12, c44, vol[e0 * nGP + g], acc);
+                kblock_cubic3(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, c11, c12, c44, vol[e1 * nGP + g], acc1);
+            } else {
+                kblock_add<DM>(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, C, vol[e0 * nGP + g], acc);
+                kblock_add<DM>(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, C, vol[e1 * nGP + g], acc1);
+            }
         }
 #pragma unroll
         for (int k = 0; k < DM * DM; ++k) acc[k] += acc1[k];
@@ -596,7 +624,10 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
         const int64_t e = t / npe;
         for (int g = 0; g < nGP; ++g) {
             const int64_t base = (e * nGP + g) * npe;
-            kblock_add<DM>(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, C, vol[e * nGP + g], acc);
+            if constexpr (CUBIC && DM == 3)
+                kblock_cubic3(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, c11, c12, c44, vol[e * nGP + g], acc);
+            else
+                kblock_add<DM>(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, C, vol[e * nGP + g], acc);
         }
     }
     const int64_t row = p >> 6;
@@ -698,28 +729,6 @@ __global__ void __launch_bounds__(256) k_assemble_rows(int32_t nn, int32_t npe, 
         }
         __syncthreads();
     }
-}
-
-// B_a^T C B_b * v for a C with the cubic sparsity pattern (c11 on the normal diagonal, c12 between normal
-// components, c44 on the shear diagonal, zero elsewhere): every material of the reference -- isotropic Hooke
-// (c11 = lambda + 2 mu, c12 = lambda, c44 = mu) and the neo-Hookean constant tangent 4 C1 I + 2 D1 1x1 -- has it.
-//   K[i][k] = c12 a_i b_k + c44 a_k b_i                     (i != k)
-//   K[i][i] = c11 a_i b_i + c44 sum_{j != i} a_j b_j
-// 30 multiply-adds instead of the 90 of the dense-pattern evaluation; femcy_set_material detects the pattern with
-// exact comparisons and everything else takes kblock_add.
-__device__ __forceinline__ void kblock_cubic3(const double* __restrict__ ga, const double* __restrict__ gb, double c11,
-                                              double c12, double c44, double v, double (&acc)[9]) {
-    const double a0 = ga[0] * v, a1 = ga[1] * v, a2 = ga[2] * v, b0 = gb[0], b1 = gb[1], b2 = gb[2];
-    const double p00 = a0 * b0, p11 = a1 * b1, p22 = a2 * b2;
-    acc[0] += c11 * p00 + c44 * (p11 + p22);
-    acc[4] += c11 * p11 + c44 * (p00 + p22);
-    acc[8] += c11 * p22 + c44 * (p00 + p11);
-    acc[1] += c12 * (a0 * b1) + c44 * (a1 * b0);
-    acc[2] += c12 * (a0 * b2) + c44 * (a2 * b0);
-    acc[3] += c12 * (a1 * b0) + c44 * (a0 * b1);
-    acc[5] += c12 * (a1 * b2) + c44 * (a2 * b1);
-    acc[6] += c12 * (a2 * b0) + c44 * (a0 * b2);
-    acc[7] += c12 * (a2 * b1) + c44 * (a1 * b2);
 }
 
 // LDS hand-off between the lanes of ONE wavefront: the LDS serves a wave's instructions in issue order, so all that
@@ -1534,12 +1543,14 @@ int launch_assemble(Ctx* c) {
         const int grid = (int)((npos + bs - 1) / bs);
         const bool rowsum = mode == FEMCY_ASM_GATHER_SYM_ROWSUM;
         FEMCY_REQUIRE(!rowsum || c->dN_sums_to_zero, "row-sum diagonal needs element tables with sum_a dN_a = 0");
-#define FEMCY_GATHER(DM_, SYM_)                                                                                   \
-    hipLaunchKernelGGL((k_assemble_gather<DM_, SYM_>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP, \
-                       c->d_ctr_ptr, c->d_ctr, c->d_tpos, c->d_dsdx, c->d_vol, c->d_C, c->d_Kvals, rowsum ? 1 : 0)
+#define FEMCY_GATHER(DM_, SYM_, CUB_)                                                                                  \
+    hipLaunchKernelGGL((k_assemble_gather<DM_, SYM_, CUB_>), dim3(grid), dim3(bs), 0, c->stream, npos, c->npe, c->nGP, \
+                       c->d_ctr_ptr, c->d_ctr, c->d_tpos, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1],        \
+                       c->cubic[2], c->d_Kvals, rowsum ? 1 : 0)
         const bool sym = mode == FEMCY_ASM_GATHER_SYM || rowsum;
-        if (c->dm == 3) { if (sym) FEMCY_GATHER(3, true); else FEMCY_GATHER(3, false); }
-        else            { if (sym) FEMCY_GATHER(2, true); else FEMCY_GATHER(2, false); }
+        if (c->dm == 3 && c->C_is_cubic) { if (sym) FEMCY_GATHER(3, true, true); else FEMCY_GATHER(3, false, true); }
+        else if (c->dm == 3)             { if (sym) FEMCY_GATHER(3, true, false); else FEMCY_GATHER(3, false, false); }
+        else                             { if (sym) FEMCY_GATHER(2, true, false); else FEMCY_GATHER(2, false, false); }
 #undef FEMCY_GATHER
         if (rowsum) {
             const int64_t nposd = (int64_t)c->nslices * SLICE;

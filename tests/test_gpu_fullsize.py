@@ -321,7 +321,7 @@ def quad():
     from oracle.elements import elem_def
     from oracle.femcy_oracle import Material
     from helpers import node_adjacency
-    m = meshgen.twist_plate(48, 6, 72, quadratic=True)
+    m = meshgen.twist_plate(48, 6, 72, quadratic=True)                     # the mesh bench.py --workload c3d10 runs
     assert m["elements"].shape == (124416, 10) and m["nodes"].shape == (182845, 3)
     ctx = be.Context(0)
     ctx.set_mesh(m["nodes"], m["elements"])

@@ -437,6 +437,7 @@ def test_pcg_single_rank_communicator(gpu_ctx_factory):
     b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
     ctx.upload(be.VEC_RESIDUAL, b)
     ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    ctx.set_option(be.OPT_PCG_SMALL, 0)                     # the three-kernel loop: the one the exchange path extends
     it0, r00, rm0 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
     x0 = ctx.download(be.VEC_X)
     iface = np.arange(0, ctx.n, 7, dtype=np.int32)          # pretend these DOFs are shared
@@ -446,6 +447,49 @@ def test_pcg_single_rank_communicator(gpu_ctx_factory):
     x1 = ctx.download(be.VEC_X)
     assert it0 == it1 and r00 == r01
     assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_plate_C3D10.inp", "ellip_dense_CPS3_0d04.inp",
+                                  "ellip_CPS8.inp"])
+def test_one_launch_small_pcg_equals_three_kernel_loop(gpu_ctx_factory, name):
+    """the persistent single-launch PCG for small systems (replicated vectors, one grid barrier per iteration) runs
+    the same recurrence as the three-kernel loop: equal iterates at fixed iteration counts, the same converged
+    solution, the stop within the rounding-order drift, r0 = 0 and the NaN report handled alike."""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    dm = ctx.dm
+    ctx.assemble_K(-1)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in inp.dirichlet_bc_info]))
+    b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    res = {}
+    for small in (0, 1):
+        ctx.set_option(be.OPT_PCG_SMALL, small)
+        out = []
+        for eps, maxit in ((0.0, 1), (0.0, 7), (0.0, 40), (1e-12, 10 * ctx.n)):
+            r = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=eps, maxit=maxit)
+            out.append((r, ctx.download(be.VEC_X)))
+        res[small] = out
+    for ((it0, r00, rm0), x0), ((it1, r01, rm1), x1) in zip(res[0][:3], res[1][:3]):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= 1e-9 * rm0
+        assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+    (it0, r00, rm0), x0 = res[0][3]
+    (it1, r01, rm1), x1 = res[1][3]
+    assert abs(it0 - it1) <= max(2, it0 // 50) and rm1 < 1e-12 * r01
+    assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(x0)
+    xs = x1.copy()
+    ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-12, maxit=10 * ctx.n)
+    assert np.array_equal(ctx.download(be.VEC_X), xs)                   # run-to-run bit reproducible
+    ctx.vector(be.VEC_RESIDUAL).fill(0.0)                               # b = 0: zero iterations, x = 0
+    assert ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)[0] == 0 and not ctx.download(be.VEC_X).any()
+    bad = b.copy()
+    bad[5] = np.nan
+    ctx.upload(be.VEC_RESIDUAL, bad)
+    with pytest.raises(be.FemcyError) as ei:
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+    assert ei.value.status == be.FEMCY_ENUMERIC
 
 
 def test_errors_are_reported_not_fatal(gpu_ctx_factory):

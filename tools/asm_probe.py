@@ -14,8 +14,11 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c3d10"
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else be.ASM_ROWS2
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 quad = wl == "c3d10"
-m = meshgen.twist_plate(48, 6, 72, quadratic=True) if quad else meshgen.twist_plate_k(12)
+m = (meshgen.twist_plate(48, 6, 72, quadratic=True, renumber=os.environ.get("FEMCY_BENCH_RENUM", "0") == "1") if quad
+     else meshgen.twist_plate_k(12))
 ctx = be.Context(0)
+if os.environ.get("FEMCY_BENCH_SIGMA"):
+    ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
 ctx.set_mesh(m["nodes"], m["elements"])
 ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetrahedral())
 ctx.set_material(LinearIsotropic(*m["elastic"]))
