@@ -299,7 +299,7 @@ constexpr int PU2 = 2;   // (r.M.r, max|r|) pairs prefetched per thread (covers 
 // k_update_d could otherwise see the flag its block 0 had just set and drop the x / d update of the converging
 // iteration).
 template <bool NT, bool MULTI>
-__global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const double* __restrict__ part1,
+__global__ void __launch_bounds__(BS) k_update_xr(XcdRanges er, int np1, const double* __restrict__ part1,
                                                   const double* __restrict__ dAd_reduced, PcgState* st,
                                                   const double2* __restrict__ Ad, const double2* __restrict__ M,
                                                   double2* __restrict__ r, const uint8_t* __restrict__ owner,
@@ -309,8 +309,13 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
         if (blockIdx.x == 0 && threadIdx.x == 0) st->skip = 1;
         return;
     }
-    const int64_t stride = (int64_t)gridDim.x * BS;
-    int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
+    // XCD-aligned element ranges (er, in double2 units): workgroup b runs on XCD b % 8 (observed; speed only) and
+    // works on the entries whose matrix rows that XCD multiplies in k_spmv -- Ad (written there), r and d (gathered
+    // there by the next product) then stay in that XCD's L2 from kernel to kernel instead of crossing the fabric
+    const int xk = blockIdx.x % NXCD;
+    const int64_t stride = (int64_t)(gridDim.x / NXCD) * BS;
+    const int64_t n2 = er.start[xk + 1];
+    int64_t base = (int64_t)er.start[xk] + (int64_t)(blockIdx.x / NXCD) * BS + threadIdx.x;
     // the producer's partials first (VMEM returns in order: loaded after the batch they would only arrive behind it)
     double pv[PU];
 #pragma unroll
@@ -321,7 +326,7 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
     double2 av[VU], mv[VU], rv[VU];
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
-        const int64_t i = min(base + u * stride, n2 - 1);
+        const int64_t i = max((int64_t)er.start[xk], min(base + u * stride, n2 - 1));
         av[u] = ld2<NT>(Ad + i);
         mv[u] = ld2<NT>(M + i);
         rv[u] = ld2<NT>(r + i);
@@ -383,14 +388,16 @@ __global__ void __launch_bounds__(BS) k_update_xr(int64_t n2, int np1, const dou
 
 // x += alpha d (this iteration's alpha, old d), then d = M r + beta d; publish scalars and the stopping decision
 template <bool NT>
-__global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const double* __restrict__ part2,
+__global__ void __launch_bounds__(BS) k_update_d(XcdRanges er, int np2, const double* __restrict__ part2,
                                                  const double* __restrict__ gathered, int nranks, PcgState* st, const double2* __restrict__ r,
                                                  const double2* __restrict__ M, double2* __restrict__ d,
                                                  double2* __restrict__ x) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
     if (st->skip) return;                           // written by this iteration's k_update_xr, never by this kernel
-    const int64_t stride = (int64_t)gridDim.x * BS;
-    int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;
+    const int xk = blockIdx.x % NXCD;               // XCD-aligned element ranges: see k_update_xr
+    const int64_t stride = (int64_t)(gridDim.x / NXCD) * BS;
+    const int64_t n2 = er.start[xk + 1];
+    int64_t base = (int64_t)er.start[xk] + (int64_t)(blockIdx.x / NXCD) * BS + threadIdx.x;
     // (r.M.r, max|r|) pairs of k_update_xr first, then the batch (in-order VMEM returns, see k_update_xr)
     const double* __restrict__ pairs = gathered ? gathered : part2;
     const int npairs = gathered ? nranks : np2;
@@ -404,7 +411,7 @@ __global__ void __launch_bounds__(BS) k_update_d(int64_t n2, int np2, const doub
     double2 rv[VU], mv[VU], dv[VU], xv[VU];
 #pragma unroll
     for (int u = 0; u < VU; ++u) {                  // first batch in flight while the scalars are reduced
-        const int64_t i = min(base + u * stride, n2 - 1);
+        const int64_t i = max((int64_t)er.start[xk], min(base + u * stride, n2 - 1));
         rv[u] = ld2<NT>(r + i);
         mv[u] = ld2<NT>(M + i);
         dv[u] = ld2<NT>(d + i);
@@ -1038,7 +1045,17 @@ void pcg_graph_reset(Ctx* c) {
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
               double* rmax) {
     const int64_t n2 = (c->n + 1) / 2;
-    const int g = ew_grid(c, n2);
+    // element ranges of the vector kernels = the node ranges whose matrix rows each XCD multiplies (c->xcd, in slices
+    // of 64 nodes; the rows of a slice are its sigma-window's nodes, so the match is exact up to one window per
+    // boundary), in double2 units; grid = 8 x workgroups per XCD
+    XcdRanges er;
+    for (int k = 0; k <= NXCD; ++k)
+        er.start[k] = (int32_t)std::min<int64_t>(n2, ((int64_t)c->xcd.start[k] * SLICE * c->dm + 1) / 2);
+    er.start[0] = 0;
+    er.start[NXCD] = (int32_t)n2;
+    int64_t emax = 1;
+    for (int k = 0; k < NXCD; ++k) emax = std::max<int64_t>(emax, er.start[k + 1] - er.start[k]);
+    const int g = NXCD * (int)std::max<int64_t>(1, std::min<int64_t>((emax + BS - 1) / BS, std::max(1, c->ew_cap / NXCD)));
     const bool multi = c->comm != nullptr;   // a 1-rank communicator still runs the exchange path (testable on one GPU)
     size_t th = timing_begin(c, T_PCG);
 
@@ -1138,7 +1155,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
             dAd_red = slot;
         }
 #define FEMCY_XR(NT_, MU_)                                                                                         \
-    hipLaunchKernelGGL((k_update_xr<NT_, MU_>), dim3(g), dim3(BS), 0, c->stream, n2, np1, c->d_part1, dAd_red,       \
+    hipLaunchKernelGGL((k_update_xr<NT_, MU_>), dim3(g), dim3(BS), 0, c->stream, er, np1, c->d_part1, dAd_red,       \
                        c->d_state, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                \
                        (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
         if (multi) { if (c->vec_nt) FEMCY_XR(true, true); else FEMCY_XR(false, true); }
@@ -1150,7 +1167,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
             if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
         }
 #define FEMCY_UD(NT_)                                                                              \
-    hipLaunchKernelGGL(k_update_d<NT_>, dim3(g), dim3(BS), 0, c->stream, n2, g, c->d_part2,         \
+    hipLaunchKernelGGL(k_update_d<NT_>, dim3(g), dim3(BS), 0, c->stream, er, g, c->d_part2,         \
                        (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state, \
                        (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d, (double2*)d_x)
         if (c->vec_nt) FEMCY_UD(true); else FEMCY_UD(false);
