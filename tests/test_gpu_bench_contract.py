@@ -30,3 +30,22 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "CG iters/s" and c["sample"]
     assert d["value"] > 0 and d["cg_iters_per_s"] > 0 and d["assemblies_per_s"] > 0
+
+
+def test_bench_c3d10_workload_and_forced_comm():
+    """the configs[4] workload line and the N = 1 run of the RCCL exchange path (both exchange forms, the neighbour
+    one with the overlapped schedule) keep the same contract"""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--iters", "20", "--prewarm", "0",
+            "--no-cpu-baseline"]
+    for extra, workload in ((["--workload", "c3d10", "--cells", "8,2,12"], "C3D10"),
+                            (["--cells", "16,4,24", "--force-comm", "--exchange", "allreduce"], "C3D4"),
+                            (["--cells", "16,4,24", "--force-comm", "--exchange", "neighbour"], "C3D4")):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, out.stdout
+        d = json.loads(lines[0])
+        assert workload in d["config"]["workload"] and d["value"] > 0 and d["n_gpus"] == 1 and "cpu_baseline" not in d
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None       # non-standard --cells
+        if "--force-comm" in extra:
+            assert d["config"]["interface_exchange"]["exchange"] == extra[-1]

@@ -28,6 +28,19 @@ for wl in c3d4 c3d10; do
   python $R/tools/rocprof_summary.py pmc $(find $OUT/fetch_$wl -name "*.db" | head -1) FETCH_SIZE > $OUT/pmc_fetch_$wl.txt 2>&1
   python $R/tools/rocprof_summary.py pmc $(find $OUT/write_$wl -name "*.db" | head -1) WRITE_SIZE > $OUT/pmc_write_$wl.txt 2>&1
 done
+declare -A PASS
+PASS[A]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+PASS[B]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM"
+PASS[C]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum"
+PASS[D]="FETCH_SIZE"
+PASS[E]="WRITE_SIZE"
+PASS[G]="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_LDS_ATOMIC SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+for p in A B C D E G; do
+  timeout 300 rocprofv3 --kernel-trace --pmc ${PASS[$p]} -d $OUT/pmcr_$p -o pmc -- python $R/tools/asm_probe.py c3d10 6 5 > $OUT/pmcr_$p.log 2>&1
+  db=$(find $OUT/pmcr_$p -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $R/tools/rocprof_summary.py pmc_all $db k_assemble_rows2 > $OUT/pmc_rows2_$p.txt 2>&1; fi
+  rm -rf $OUT/pmcr_$p
+done
 cd $R
 python tools/make_traffic_json.py $HEAD_SHA c3d4:$(find $OUT/fetch_c3d4 -name "*.db" | head -1):$(find $OUT/write_c3d4 -name "*.db" | head -1) c3d10:$(find $OUT/fetch_c3d10 -name "*.db" | head -1):$(find $OUT/write_c3d10 -name "*.db" | head -1) > $OUT/traffic.log 2>&1
 cp profiles/spmv_traffic.json $OUT/spmv_traffic.json
