@@ -757,7 +757,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 //     workgroup finish together as 64-byte requests, behind two barriers per row, was measured too: TA busy 140 M ->
 //     82 M cycles, WRITE_SIZE 517 -> 439 MB, kernel 389 -> 401 us -- the barriers cost what the requests saved.
 //     A fourth wave per SIMD -- __launch_bounds__(256, 4), LDS accumulator sized per slice-length class -- measured
-//     605 us: the 128-VGPR cap spills the prefetch registers.)
+//     605 us: the 128-VGPR cap spills the prefetch registers.  XCD-contiguous slice ranges as in k_spmv (for record
+//     reuse inside one L2: FETCH_SIZE is 563 MB reported = 1.1 GB for 123 MB of records) measured 500 us: FETCH only
+//     fell to 485 MB and the corner-node slices, three passes per row, all land on the first XCDs.)
 // Deterministic: fixed pass order, ds_add_f64 of one instruction applied in lane order, fixed-order diagonal sum.
 template <int NPE, int NGP, bool CUBIC>
 __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t Lmax,
