@@ -759,7 +759,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 //     A fourth wave per SIMD -- __launch_bounds__(256, 4), LDS accumulator sized per slice-length class -- measured
 //     605 us: the 128-VGPR cap spills the prefetch registers.  XCD-contiguous slice ranges as in k_spmv (for record
 //     reuse inside one L2: FETCH_SIZE is 563 MB reported = 1.1 GB for 123 MB of records) measured 500 us: FETCH only
-//     fell to 485 MB and the corner-node slices, three passes per row, all land on the first XCDs.)
+//     fell to 485 MB and the corner-node slices, three passes per row, all land on the first XCDs.  Rows in
+//     element-major order (nodes sorted by first incident element, XCD-contiguous ranges of that order): 590 us, FETCH
+//     still 486 MB, WRITE 832 MB -- so the fetch is not record re-reads but the read-for-fill of the K lines that
+//     are written 16 bytes at a time; what bounds the kernel besides LDS and VALU is ~0.9 GB of fabric traffic for
+//     a 357 MB matrix, and only writing whole 128-byte lines (eight adjacent rows at once) would remove it.)
 // Deterministic: fixed pass order, ds_add_f64 of one instruction applied in lane order, fixed-order diagonal sum.
 template <int NPE, int NGP, bool CUBIC>
 __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t Lmax,
