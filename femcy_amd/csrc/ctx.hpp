@@ -154,6 +154,13 @@ struct Ctx {
     const double* pcg_graph_x = nullptr;
     int pcg_graph_iters = 0, pcg_graph_g = 0, pcg_graph_np1 = 0;
     int opt_graph = 1;
+    // ---- persistent one-launch PCG for systems of one wavefront-task per SIMD (k_pcg_persist)
+    int opt_persist = 1;              // FEMCY_OPT_PCG_PERSIST
+    int opt_persist_lds = -1;         // block rows per wave kept in LDS (-1: as many as fit; test knob 104)
+    int persist_cus = 0;              // compute units of the device
+    bool persist_failed = false;      // a grid barrier timed out once: do not try again on this context
+    double* d_persist = nullptr;      // d double buffer, partials, barrier counters
+    int64_t persist_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
     int opt_small = 1;                // FEMCY_OPT_PCG_SMALL
     int small_max_lds = 65536;        // LDS a workgroup may allocate (device attribute, femcy_ctx_create)
@@ -250,6 +257,7 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 // d_partials[part_off ...]); split_prepare builds the slice list once per pattern + communicator
 int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d_partials, int part_off, int* nblocks_out);
 int split_prepare(Ctx* c);
+int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
               double* rmax);

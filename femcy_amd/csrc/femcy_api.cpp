@@ -197,6 +197,7 @@ int femcy_ctx_create(int device, femcy_ctx** out) {
             c->small_max_lds = lds;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
             c->small_max_wg = std::max(1, cus / 2);   // one workgroup per CU with half the chip to spare
+        c->persist_cus = cus;
     }
     *out = ctx;
     return FEMCY_OK;
@@ -225,6 +226,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_nb_dofs); dev_free(&c->d_nb_send); dev_free(&c->d_nb_recv); dev_free(&c->d_if_ptr); dev_free(&c->d_if_src);
     dev_free(&c->d_split_list);
     dev_free(&c->d_small);
+    dev_free(&c->d_persist);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
     if (c->comm_stream) {
@@ -284,6 +286,15 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || value == 1, "exchange: 0 (all-reduce) or 1 (neighbour send/recv)");
             FEMCY_REQUIRE(value == 0 || c->d_if_ptr, "femcy_comm_set_neighbours must come first");
             c->exchange = (int)value;
+            break;
+        case FEMCY_OPT_PCG_PERSIST:
+            FEMCY_REQUIRE(value == 0 || value == 1, "persistent PCG: 0 (off) or 1 (auto)");
+            c->opt_persist = (int)value;
+            c->persist_failed = false;
+            break;
+        case 104:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
+            FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
+            c->opt_persist_lds = (int)value;
             break;
         case FEMCY_OPT_PCG_SMALL:
             FEMCY_REQUIRE(value == 0 || value == 1, "small-system PCG: 0 (off) or 1 (auto)");

@@ -1076,6 +1076,17 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         bool handled = false;
         int rc = pcg_small_solve(c, d_b, d_x, eps, maxit, &handled);
         if (rc) return rc;
+        if (!handled) {
+            if ((rc = pcg_persist_solve(c, d_b, d_x, eps, maxit, &handled))) return rc;
+            if (handled) {       // a barrier time-out (a workgroup was not resident) falls back to the three-kernel loop
+                FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+                FEMCY_HIP(hipStreamSynchronize(c->stream));
+                if (c->h_state->done == 3) {
+                    c->persist_failed = true;
+                    handled = false;
+                }
+            }
+        }
         if (handled) {
             FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
             FEMCY_HIP(hipStreamSynchronize(c->stream));

@@ -1,0 +1,32 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "/root/repo")
+from femcy_amd import backend as be, meshgen
+from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
+from femcy_amd.material_zoo import LinearIsotropic
+wl = sys.argv[1]
+quad = wl == "c3d10"
+m = meshgen.twist_plate(48, 6, 72, quadratic=True) if quad else meshgen.twist_plate_k(12)
+ctx = be.Context(0)
+ctx.set_mesh(m["nodes"], m["elements"])
+ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetrahedral())
+ctx.set_material(LinearIsotropic(*m["elastic"]))
+info = ctx.build_pattern()
+cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in m["dirichlet_bc_info"]]))
+ctx.assemble_K(-1)
+ctx.upload(be.VEC_RESIDUAL, np.sin(np.arange(ctx.n) * 0.11) * 1e3)
+ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+print(wl, "maxrow", info.max_row_blocks, "nslices", info.nslices, flush=True)
+for lds in ([0, 8, -1, 8, -1] if not quad else [0, 8, -1]):
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(104, lds)
+    for rep in range(3):
+        t = time.perf_counter()
+        try:
+            it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=int(os.environ.get("ITERS", "200")))
+            msg = f"it {it} rmax {rmax:.9e}"
+        except Exception as e:
+            msg = "EXC " + str(e)[:150]
+        dt = time.perf_counter() - t
+        nit = int(os.environ.get("ITERS", "200"))
+        print(f"  lds {lds} rep {rep}: {dt*1e3:8.2f} ms  {dt/nit*1e6:7.2f} us/it  {msg}", flush=True)
