@@ -69,7 +69,9 @@ class Timing(C.Structure):
                 ("assemble_ms", C.c_double), ("assemble_launches", C.c_int64),
                 ("force_ms", C.c_double), ("force_launches", C.c_int64),
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64),
-                ("pcg_ms", C.c_double), ("pcg_iters", C.c_int64)]
+                ("pcg_ms", C.c_double), ("pcg_iters", C.c_int64),
+                ("persist_ms", C.c_double), ("persist_launches", C.c_int64), ("persist_iters", C.c_int64),
+                ("solves_three", C.c_int64), ("solves_small", C.c_int64), ("solves_persist", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -156,9 +156,14 @@ struct Ctx {
     int opt_graph = 1;
     // ---- persistent one-launch PCG for systems of one wavefront-task per SIMD (k_pcg_persist)
     int opt_persist = 1;              // FEMCY_OPT_PCG_PERSIST
+    int opt_persist_rj = 5;           // block rows per slice kept in registers (test knob 105)
+    int opt_persist_dbg = 0;          // timing experiments only (test knob 106): skip parts of the iteration
     int opt_persist_lds = -1;         // block rows per wave kept in LDS (-1: as many as fit; test knob 104)
     int persist_cus = 0;              // compute units of the device
     bool persist_failed = false;      // a grid barrier timed out once: do not try again on this context
+    int32_t* d_persist_assign = nullptr;   // [waves][SPW] slices of each wave (LPT-balanced per XCD range), -1 = none
+    std::vector<int64_t> persist_assign_key;
+    int64_t pattern_serial = 0;       // bumped by femcy_build_pattern
     double* d_persist = nullptr;      // d double buffer, partials, barrier counters
     int64_t persist_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
@@ -230,7 +235,7 @@ struct Ctx {
 };
 
 // timing classes
-enum { T_GEOM = 0, T_ASM = 1, T_FORCE = 2, T_SPMV = 3, T_PCG = 4 };
+enum { T_GEOM = 0, T_ASM = 1, T_FORCE = 2, T_SPMV = 3, T_PCG = 4, T_PERSIST = 5 };
 size_t timing_begin(Ctx* c, int cls);
 EventPair* timing_acquire(Ctx* c, int cls);   // registers a pair without recording (hipExtLaunchKernel fills it)
 void timing_end(Ctx* c, size_t h);

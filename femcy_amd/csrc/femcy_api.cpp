@@ -88,6 +88,7 @@ void timing_collect(Ctx* c) {
             case T_FORCE: c->timing.force_ms += ms; c->timing.force_launches++; break;
             case T_SPMV: c->timing.spmv_ms += ms; c->timing.spmv_launches++; break;
             case T_PCG: c->timing.pcg_ms += ms; break;
+            case T_PERSIST: c->timing.persist_ms += ms; c->timing.persist_launches++; break;
         }
     }
     c->ev_pending.clear();
@@ -227,6 +228,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_split_list);
     dev_free(&c->d_small);
     dev_free(&c->d_persist);
+    dev_free(&c->d_persist_assign);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
     if (c->comm_stream) {
@@ -295,6 +297,13 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case 104:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
             c->opt_persist_lds = (int)value;
+            break;
+        case 106:   /* timing experiments: bit 0 no streamed rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait */
+            c->opt_persist_dbg = (int)value;
+            break;
+        case 105:   /* test knob: block rows per slice of the persistent PCG kept in registers (0, 4 or 5) */
+            FEMCY_REQUIRE(value == 0 || value == 4 || value == 5, "register-resident block rows: 0, 4 or 5");
+            c->opt_persist_rj = (int)value;
             break;
         case FEMCY_OPT_PCG_SMALL:
             FEMCY_REQUIRE(value == 0 || value == 1, "small-system PCG: 0 (off) or 1 (auto)");
@@ -485,6 +494,7 @@ int femcy_build_pattern(femcy_ctx* ctx) {
     int rc = build_pattern(c);
     if (rc) return rc;
     c->split_ready = false;
+    c->pattern_serial++;
     c->have_pattern = true;
     return FEMCY_OK;
 }

@@ -1073,28 +1073,37 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         hipLaunchKernelGGL(k_recip, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
     }
     if (!multi) {
-        bool handled = false;
+        bool handled = false, persist = false;
         int rc = pcg_small_solve(c, d_b, d_x, eps, maxit, &handled);
         if (rc) return rc;
         if (!handled) {
             if ((rc = pcg_persist_solve(c, d_b, d_x, eps, maxit, &handled))) return rc;
+            persist = handled;
             if (handled) {       // a barrier time-out (a workgroup was not resident) falls back to the three-kernel loop
                 FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
                 FEMCY_HIP(hipStreamSynchronize(c->stream));
                 if (c->h_state->done == 3) {
                     c->persist_failed = true;
-                    handled = false;
+                    handled = persist = false;
                 }
             }
         }
         if (handled) {
-            FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
-            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            if (!persist) {
+                FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+                FEMCY_HIP(hipStreamSynchronize(c->stream));
+            }
             timing_end(c, th);
             if (iters) *iters = c->h_state->iters;
             if (r0) *r0 = c->h_state->r0;
             if (rmax) *rmax = c->h_state->rmax;
             c->timing.pcg_iters += c->h_state->iters;
+            if (persist) {
+                c->timing.solves_persist++;
+                if (c->opt_timing) c->timing.persist_iters += c->h_state->iters;
+            } else {
+                c->timing.solves_small++;
+            }
             if (c->h_state->done == 3) {
                 set_error("small-system PCG: grid barrier timed out after %d iterations (a workgroup was not resident)", c->h_state->iters);
                 return FEMCY_EHIP;
@@ -1236,6 +1245,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     if (r0) *r0 = c->h_state->r0;
     if (rmax) *rmax = c->h_state->rmax;
     c->timing.pcg_iters += c->h_state->iters;
+    c->timing.solves_three++;
     if (c->h_state->done == 2) {
         set_error("PCG breakdown: NaN/Inf residual after %d iterations (r0 = %g)", c->h_state->iters, c->h_state->r0);
         return FEMCY_ENUMERIC;

@@ -18,7 +18,11 @@
 // d is double-buffered by iteration parity (a wave may gather d_k while a faster one already publishes d_k+1), as are
 // the partial arrays.  Every spin is bounded: a timeout ends the launch with state.done = 3 and the host falls back to
 // the three-kernel loop.
+#include <algorithm>
 #include <cmath>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include "ctx.hpp"
 
 namespace femcy {
@@ -27,12 +31,14 @@ namespace {
 
 constexpr int PBS = 256;        // 4 waves per workgroup, one workgroup per CU
 constexpr int PNX = 8;
+constexpr int CH = 4;         // block rows per batch of the LDS-resident and the streamed part
 
 struct PersistPcg {
     const int32_t* slice_len;
     const int64_t* slice_off;
     const int32_t* bcol;
     const int32_t* node_of;
+    const int32_t* assign;  // [8 * waves per XCD][SPW] slices of each wave, -1 = none
     const double* vals;
     const double* b;
     const double* M;
@@ -44,7 +50,7 @@ struct PersistPcg {
     unsigned int* top;
     PcgState* st;
     XcdRanges xr;         // slice range of each XCD
-    int32_t npad, maxit, lds_rows;
+    int32_t npad, maxit, lds_rows, dbg;
     double eps;
 };
 
@@ -54,15 +60,34 @@ __device__ __forceinline__ void pst(double* p, double v) {
 __device__ __forceinline__ double pld(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double pwave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+// wave reductions on the DPP network (quad swaps, row mirrors, row broadcasts; ~6 x 8 clocks) instead of 12 dependent
+// ds_bpermute round trips through the LDS crossbar; the result (lane 63's) is returned in every lane, fixed order
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double pdpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double pwave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+__device__ __forceinline__ double plane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double pwave_sum(double v) {
+    v += pdpp<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += pdpp<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += pdpp<0x141, 0xf>(v);     // row_half_mirror
+    v += pdpp<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row's sum
+    v += pdpp<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 (other rows add the 0 of `old`)
+    v += pdpp<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+    return plane63(v);
+}
+__device__ __forceinline__ double pwave_max(double v) {   // v >= 0 (absolute values; +inf stands for NaN)
+    v = fmax(v, pdpp<0xB1, 0xf>(v));
+    v = fmax(v, pdpp<0x4E, 0xf>(v));
+    v = fmax(v, pdpp<0x141, 0xf>(v));
+    v = fmax(v, pdpp<0x140, 0xf>(v));
+    v = fmax(v, pdpp<0x142, 0xa>(v));
+    v = fmax(v, pdpp<0x143, 0xc>(v));
+    return plane63(v);
 }
 __device__ __forceinline__ double pabs(double r) {   // fmax() drops NaN; keep it visible
     const double a = fabs(r);
@@ -79,7 +104,7 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
         if (prev + 1 == members * (round + 1))                   // last arrival of this XCD group in this round
             __hip_atomic_fetch_add(a.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(a.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PNX * (round + 1)) {
+        while (!(a.dbg & 8) && __hip_atomic_load(a.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PNX * (round + 1)) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 25)) {
                 *s_fail = 1;
@@ -91,13 +116,14 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
     return *s_fail == 0;
 }
 
-template <int DM, int SPW>
+template <int DM, int SPW, int RJ>
 __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
     extern __shared__ __attribute__((aligned(16))) char lds_persist[];
     __shared__ double sm1[PBS / 64], sm2[PBS / 64];
     __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be so: scalar registers
     const int G = gridDim.x;
     if (tid == 0) s_fail = 0;
     // wave's resident block rows: [q][k][lane] doubles, then [q][lane] columns
@@ -112,25 +138,53 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     int64_t offs[SPW];
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
-        const int32_t s = a.xr.start[xk] + wx + t * nwx;
-        const bool act = s < a.xr.start[xk + 1];
+        const int32_t s = __builtin_amdgcn_readfirstlane(a.assign[((size_t)xk * nwx + wx) * SPW + t]);
+        const bool act = s >= 0;
         sl[t] = act ? s : -1;
-        Ls[t] = act ? a.slice_len[s] : 0;
-        offs[t] = act ? a.slice_off[s] : 0;
+        Ls[t] = act ? __builtin_amdgcn_readfirstlane(a.slice_len[s]) : 0;
+        const int64_t o = act ? a.slice_off[s] : 0;
+        offs[t] = ((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o);
         node[t] = act ? a.node_of[(int64_t)s * 64 + lane] : -1;
     }
-    // ---- resident part of the matrix -> LDS (once per solve)
+    // ---- resident part of the matrix (once per solve): block rows 0 .. RJ-1 of every slice -> registers (a row the
+    // slice does not have is a zero block on the lane's own node), the next lds_rows block rows of the wave -> LDS
+    double rv[SPW][RJ > 0 ? RJ : 1][DD];
+    int32_t rcl[SPW][RJ > 0 ? RJ : 1];
+#pragma unroll
+    for (int t = 0; t < SPW; ++t)
+#pragma unroll
+        for (int jj = 0; jj < RJ; ++jj) {
+            const bool has = jj < Ls[t];
+            const double* src = a.vals + (offs[t] + (has ? jj : 0)) * (int64_t)(DD * 64);
+#pragma unroll
+            for (int k = 0; k < DD; ++k) rv[t][jj][k] = has ? src[kv_index<DM>(0, k, lane)] : 0.0;
+            rcl[t][jj] = has ? a.bcol[(offs[t] + jj) * 64 + lane] : (node[t] >= 0 ? node[t] : 0);
+        }
     {
         int q = 0;
 #pragma unroll
         for (int t = 0; t < SPW; ++t)
-            for (int32_t j = 0; j < Ls[t] && q < a.lds_rows; ++j, ++q) {
+            for (int32_t j = RJ; j < Ls[t] && q < a.lds_rows; ++j, ++q) {
                 const double* src = a.vals + (offs[t] + j) * (int64_t)(DD * 64);
 #pragma unroll
                 for (int k = 0; k < DD; ++k) lvals[(q * DD + k) * 64 + lane] = src[kv_index<DM>(0, k, lane)];
                 lcols[q * 64 + lane] = a.bcol[(offs[t] + j) * 64 + lane];
             }
     }
+    // d is gathered with sc1 BUFFER loads: the same cache policy as an agent-scope atomic load (the other XCDs wrote d
+    // with sc1 stores), but an ordinary load to the compiler, which may then issue the gathers of several block rows
+    // before the first wait (with atomic loads it serialised them: 15 + 8 dependent L2 round trips per product)
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dbuf, 0, (int)((size_t)2 * a.npad * sizeof(double)), 0x00020000);
+    auto gather_d = [&](int32_t col, int32_t parity_off, double (&xv)[DM]) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int cc = 0; cc < DM; ++cc) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(drsrc, (col * DM + cc) * 8, parity_off, 16 /* sc1 */);
+            xv[cc] = __hiloint2double((int)w.y, (int)w.x);
+        }
+    };
     // ---- x0 = 0, r = b, d = M r
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
@@ -190,7 +244,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     int it = 0;
     while (!done && it < a.maxit) {
         __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
-        const double* dcur = a.dbuf + (size_t)(it & 1) * a.npad;
+        const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
         // ---- Ad = K d for the wave's rows, d gathered with sc1 loads (the other XCDs wrote it with sc1 stores)
         double dot = 0.0;
         int q = 0;
@@ -200,37 +254,80 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
             for (int r = 0; r < DM; ++r) acc[r] = 0.0;
             const int32_t L = Ls[t];
-            int32_t j = 0;
-            for (; j < L && q < a.lds_rows; ++j, ++q) {                       // resident block rows
-                const int32_t col = lcols[q * 64 + lane];
-                double xv[DM];
+            // block rows held in registers: all their gathers are issued before the first multiply
+            if (RJ > 0 && !(a.dbg & 4)) {
+                constexpr int RB = RJ > 4 ? 3 : (RJ > 0 ? RJ : 1);               // rows per batch (register budget)
 #pragma unroll
-                for (int cc = 0; cc < DM; ++cc) xv[cc] = pld(dcur + (int64_t)col * DM + cc);
+                for (int j0 = 0; j0 < RJ; j0 += RB) {
+                    double xg[RB][DM];
 #pragma unroll
-                for (int r = 0; r < DM; ++r)
+                    for (int u = 0; u < RB; ++u)
+                        if (j0 + u < RJ) gather_d(rcl[t][j0 + u], poff, xg[u]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int cc = 0; cc < DM; ++cc) acc[r] += lvals[(q * DD + r * DM + cc) * 64 + lane] * xv[cc];
+                    for (int u = 0; u < RB; ++u)
+                        if (j0 + u < RJ) {
+#pragma unroll
+                            for (int r = 0; r < DM; ++r)
+#pragma unroll
+                                for (int cc = 0; cc < DM; ++cc) acc[r] += rv[t][j0 + u][r * DM + cc] * xg[u][cc];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            int32_t j = RJ;
+            // block rows held in LDS, four at a time (a short batch repeats its last row's gather and skips the multiply)
+            while (j < L && q < a.lds_rows && !(a.dbg & 2)) {
+                const int nb = min(CH, min(L - j, a.lds_rows - q));
+                double xg[CH][DM];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) gather_d(lcols[(q + min(u, nb - 1)) * 64 + lane], poff, xg[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (u < nb) {
+#pragma unroll
+                        for (int r = 0; r < DM; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < DM; ++cc)
+                                acc[r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
+                    }
+                j += nb;
+                q += nb;
+            }
+            // streamed block rows, four at a time: columns, then the values, then the gathers, then the multiplies
             const int32_t* __restrict__ bc = a.bcol + offs[t] * 64 + lane;
             const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
             const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
-#pragma unroll 4
-            for (; j < L; ++j) {                                             // streamed block rows
-                const int32_t col = bc[(int64_t)j * 64];
-                double xv[DM], e[DD];
+            while (j < L && !(a.dbg & 1)) {
+                const int nb = min(CH, L - j);
+                int32_t col[CH];
+                double e[CH][DD], xg[CH][DM];
 #pragma unroll
-                for (int kp = 0; kp < NP; ++kp) {
-                    const double2 v2 = vp[(int64_t)j * (DD * 32) + kp * 64];
-                    e[2 * kp] = v2.x;
-                    e[2 * kp + 1] = v2.y;
-                }
-                if (DD & 1) e[DD - 1] = vs[(int64_t)j * (DD * 64)];
+                for (int u = 0; u < CH; ++u) col[u] = bc[(int64_t)(j + min(u, nb - 1)) * 64];
 #pragma unroll
-                for (int cc = 0; cc < DM; ++cc) xv[cc] = pld(dcur + (int64_t)col * DM + cc);
+                for (int u = 0; u < CH; ++u)
+                    if (u < nb) {
 #pragma unroll
-                for (int r = 0; r < DM; ++r)
+                        for (int kp = 0; kp < NP; ++kp) {
+                            const double2 v2 = vp[(int64_t)(j + u) * (DD * 32) + kp * 64];
+                            e[u][2 * kp] = v2.x;
+                            e[u][2 * kp + 1] = v2.y;
+                        }
+                        if (DD & 1) e[u][DD - 1] = vs[(int64_t)(j + u) * (DD * 64)];
+                    }
 #pragma unroll
-                    for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
+                for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (u < nb) {
+#pragma unroll
+                        for (int r = 0; r < DM; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < DM; ++cc) acc[r] += e[u][r * DM + cc] * xg[u][cc];
+                    }
+                j += nb;
             }
 #pragma unroll
             for (int r = 0; r < DM; ++r) {
@@ -272,6 +369,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         double rMr_new = 0.0;
         gather_pairs(a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax);
         ++it;
+        if (a.dbg) rmax = 1.0, rMr_new = 1.0;
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
             done = 2;
         } else if (rmax < a.eps * r0) {
@@ -312,17 +410,20 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 // eligibility + launch; *handled = false when the system does not qualify (too small, too large, multi-rank)
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
     *handled = false;
-    constexpr int SPW = 3;
     if (!c->opt_persist || c->comm || c->persist_failed) return FEMCY_OK;
     const int G = (c->persist_cus / PNX) * PNX;                  // one workgroup per CU
     if (G < PNX) return FEMCY_OK;
     const int nwx = (G / PNX) * 4;
     int32_t maxrange = 0;
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    if (maxrange > SPW * nwx || c->nslices < G) return FEMCY_OK;  // does not fit / too small to be worth a whole chip
+    if (getenv("FEMCY_DEBUG"))
+        fprintf(stderr, "[femcy] persistent PCG: %d slices, widest XCD range %d, %d waves per XCD x %d slices\n",
+                (int)c->nslices, (int)maxrange, nwx, maxrange > 3 * nwx ? 4 : 3);
+    if (maxrange > 4 * nwx || c->nslices < G) return FEMCY_OK;  // does not fit / too small to be worth a whole chip
     const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
+    const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
     lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
     const size_t lds = (size_t)4 * lds_rows * 64 * (DD * 8 + 4) + 16;
     const int64_t need = 2 * npad + 2 * G + 4 * G + 160;          // + 8 x 32 + 32 barrier counters (4 bytes each)
@@ -332,7 +433,41 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
         c->persist_cap = need;
         FEMCY_HIP(hipMalloc((void**)&c->d_persist, sizeof(double) * need));
     }
+    // slices of each wave: XCD k's waves share the slice range xcd[k] .. xcd[k+1] (the ranges are balanced by stored
+    // block rows); inside it the slices go longest first to the wave with the least rows so far (LPT) -- the sigma-
+    // sorted windows would otherwise hand all long slices to the same waves
+    {
+        std::vector<int64_t> key = {G, SPW, c->pattern_serial};
+        for (int k = 0; k <= PNX; ++k) key.push_back(c->xcd.start[k]);
+        if (key != c->persist_assign_key || !c->d_persist_assign) {
+            std::vector<int32_t> assign((size_t)PNX * nwx * SPW, -1);
+            std::vector<int32_t> order, load(nwx), cnt(nwx);
+            for (int k = 0; k < PNX; ++k) {
+                order.clear();
+                for (int32_t s = c->xcd.start[k]; s < c->xcd.start[k + 1]; ++s) order.push_back(s);
+                std::stable_sort(order.begin(), order.end(),
+                                 [&](int32_t x, int32_t y) { return c->h_slice_len[x] > c->h_slice_len[y]; });
+                std::fill(load.begin(), load.end(), 0);
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int32_t s : order) {
+                    int best = -1;
+                    for (int w = 0; w < nwx; ++w)
+                        if (cnt[w] < SPW && (best < 0 || load[w] < load[best])) best = w;
+                    assign[((size_t)k * nwx + best) * SPW + cnt[best]++] = s;
+                    load[best] += c->h_slice_len[s];
+                }
+            }
+            if (c->d_persist_assign) (void)hipFree(c->d_persist_assign);
+            c->d_persist_assign = nullptr;
+            FEMCY_HIP(hipMalloc((void**)&c->d_persist_assign, assign.size() * sizeof(int32_t)));
+            FEMCY_HIP(hipMemcpyAsync(c->d_persist_assign, assign.data(), assign.size() * sizeof(int32_t),
+                                     hipMemcpyHostToDevice, c->stream));
+            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            c->persist_assign_key = key;
+        }
+    }
     PersistPcg a;
+    a.assign = c->d_persist_assign;
     a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = c->d_bcol; a.node_of = c->d_node_of;
     a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
     a.dbuf = c->d_persist;
@@ -342,17 +477,31 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     a.top = a.xc + 8 * 32;
     a.st = c->d_state;
     a.xr = c->xcd;
-    a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
+    a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps; a.dbg = c->opt_persist_dbg;
     FEMCY_HIP(hipMemsetAsync(a.xc, 0, sizeof(unsigned int) * (8 * 32 + 32), c->stream));
-#define FEMCY_PERSIST(DM_)                                                                                        \
+#define FEMCY_PERSIST(DM_, SPW_, RJ_)                                                                             \
     do {                                                                                                          \
-        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW>);                                 \
+        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_>);                           \
         if (lds > 48 * 1024)                                                                                      \
             FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW>), dim3(G), dim3(PBS), lds, c->stream, a);                     \
+        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_>), dim3(G), dim3(PBS), lds, c->stream, a);               \
     } while (0)
-    if (c->dm == 3) FEMCY_PERSIST(3); else FEMCY_PERSIST(2);
+    const size_t tp = timing_begin(c, T_PERSIST);
+    // register-resident block rows per slice: what 512 VGPRs per lane hold next to the vectors and the streaming
+    // buffers (dm 3: 5 rows x 3 slices or 3 rows x 4 slices of 19 registers each)
+    if (c->dm == 3 && SPW == 3) {
+        if (c->opt_persist_rj == 5) FEMCY_PERSIST(3, 3, 5);
+        else if (c->opt_persist_rj == 4) FEMCY_PERSIST(3, 3, 4);
+        else FEMCY_PERSIST(3, 3, 0);
+    } else if (c->dm == 3) {
+        if (c->opt_persist_rj) FEMCY_PERSIST(3, 4, 3); else FEMCY_PERSIST(3, 4, 0);
+    } else if (SPW == 3) {
+        if (c->opt_persist_rj) FEMCY_PERSIST(2, 3, 5); else FEMCY_PERSIST(2, 3, 0);
+    } else {
+        if (c->opt_persist_rj) FEMCY_PERSIST(2, 4, 5); else FEMCY_PERSIST(2, 4, 0);
+    }
 #undef FEMCY_PERSIST
+    timing_end(c, tp);
     FEMCY_HIP(hipGetLastError());
     *handled = true;
     return FEMCY_OK;

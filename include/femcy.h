@@ -142,6 +142,9 @@ typedef struct femcy_timing_t {
     double force_ms;     int64_t force_launches;     /* nodal-force gather                    */
     double spmv_ms;      int64_t spmv_launches;      /* compute_Ad                            */
     double pcg_ms;       int64_t pcg_iters;          /* whole PCG solves (all kernels)        */
+    double persist_ms;   int64_t persist_launches;   /* one-launch PCG (k_pcg_persist) alone  */
+    int64_t persist_iters;                           /* CG iterations inside those launches   */
+    int64_t solves_three, solves_small, solves_persist; /* PCG solves by path (always counted) */
 } femcy_timing_t;
 
 /* ------------------------------------------------------------------ life cycle / diagnostics */

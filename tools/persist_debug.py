@@ -17,10 +17,12 @@ ctx.assemble_K(-1)
 ctx.upload(be.VEC_RESIDUAL, np.sin(np.arange(ctx.n) * 0.11) * 1e3)
 ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
 print(wl, "maxrow", info.max_row_blocks, "nslices", info.nslices, flush=True)
-for lds in ([0, 8, -1, 8, -1] if not quad else [0, 8, -1]):
+for lds, rj, dbg in [(-1, 5, 0), (-1, 4, 0), (-1, 5, 0), (-1, 4, 0), (-1, 4, 1), (-1, 4, 4), (-1, 4, 7)]:
     ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(106, dbg)
     ctx.set_option(104, lds)
-    for rep in range(3):
+    ctx.set_option(105, rj)
+    for rep in range(2):
         t = time.perf_counter()
         try:
             it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=int(os.environ.get("ITERS", "200")))
@@ -29,4 +31,6 @@ for lds in ([0, 8, -1, 8, -1] if not quad else [0, 8, -1]):
             msg = "EXC " + str(e)[:150]
         dt = time.perf_counter() - t
         nit = int(os.environ.get("ITERS", "200"))
-        print(f"  lds {lds} rep {rep}: {dt*1e3:8.2f} ms  {dt/nit*1e6:7.2f} us/it  {msg}", flush=True)
+        tm = ctx.timing()
+        msg += f" paths 3k/small/persist {tm['solves_three']}/{tm['solves_small']}/{tm['solves_persist']}"
+        print(f"  lds {lds} rj {rj} dbg {dbg} rep {rep}: {dt*1e3:8.2f} ms  {dt/nit*1e6:7.2f} us/it  {msg}", flush=True)
