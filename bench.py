@@ -41,7 +41,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, HBM section); the D2D probe below reports what
                                 # a plain device copy reaches on the box the bench runs on
 ELEMS_PER_GPU = {"c3d4": 995328, "c3d10": 124416}
-TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/ctx.hpp", "femcy_amd/csrc/pattern.cpp")
+TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/kernels_pcg_persist.hip", "femcy_amd/csrc/ctx.hpp",
+                   "femcy_amd/csrc/pattern.cpp")
 
 
 def log(*a):
@@ -58,9 +59,10 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload):
-    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-    passes, MI355X_MICROARCH.md HBM section) -- refused (None + reason) when the kernel sources changed since."""
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes, MI355X_MICROARCH.md HBM section) -- refused (None + reason) when the kernel sources
+    changed since, or when the passes were taken on a different kernel."""
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if not os.path.exists(tpath):
         return None, "no profiles/spmv_traffic.json"
@@ -72,6 +74,8 @@ def pmc_traffic(workload):
         if doc.get("kernel_source_sha") != kernel_source_sha():
             return None, (f"stale: PMC passes were taken on kernel sources {doc.get('kernel_source_sha')}, "
                           f"tree has {kernel_source_sha()}")
+        if kernel not in entry.get("kernel", ""):
+            return None, f"PMC passes of workload {workload} were taken on {entry.get('kernel', '?')[:60]}, not on {kernel}"
         return entry["hbm_bytes_per_launch"], f"profiles/spmv_traffic.json @ {doc.get('git_head', '?')}"
     except Exception as e:                                      # noqa: BLE001
         return None, f"unreadable profiles/spmv_traffic.json: {e!r}"
@@ -212,6 +216,8 @@ def main():
     ctx = be.Context(local_rank)
     if os.environ.get("FEMCY_BENCH_SIGMA"):                 # tuning knob: SELL sorting window
         ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
+    if os.environ.get("FEMCY_BENCH_PERSIST"):               # 0 = the three-kernel PCG loop (comparison records)
+        ctx.set_option(be.OPT_PCG_PERSIST, int(os.environ["FEMCY_BENCH_PERSIST"]))
     ctx.set_mesh(nodes, el)
     ctx.set_element(Element_quadratic_tetrahedral() if quadratic else Element_linear_tetrahedral())
     ctx.set_material(LinearIsotropic(*elastic))
@@ -299,11 +305,27 @@ def main():
     probe = hbm_copy_probe(torch) if (on_gpu and rank == 0) else None
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    # algorithmic bytes of one SpMV: 8*nnz + 4*nnz/dm^2 + 4*(nn+1) + 16*n, padding never counted
+    # algorithmic bytes (BASELINE.md / SURVEY.md 8d), padding never counted:
+    #   one SpMV          8*nnz + 4*nnz/dm^2 + 4*(nn+1) + 16*n
+    #   one PCG iteration the SpMV + 88*n (the fused vector updates of the reference recurrence)
     spmv_bytes = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * n
+    iter_bytes = spmv_bytes + 88 * n
     spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
-    achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9 if spmv_us > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(args.workload) if not args.cells else (None, "non-standard --cells")
+    persist = tm["persist_launches"] > 0 and tm["spmv_launches"] == 0
+    if persist:
+        # the whole solve is ONE launch of k_pcg_persist (no SpMV launches exist): the unit of one launch is the
+        # iterations it ran; its duration comes from HIP events around the launch on the ctx stream
+        kernel = "k_pcg_persist"
+        kernel_label = f"k_pcg_persist<{ctx.dm}> (one launch = {args.iters} PCG iterations: compute_Ad + the vector updates)"
+        launch_us = tm["persist_ms"] * 1e3 / tm["persist_launches"]
+        launch_bytes = iter_bytes * tm["persist_iters"] / tm["persist_launches"]
+        launches = int(tm["persist_launches"])
+    else:
+        kernel = "k_spmv"
+        kernel_label = f"k_spmv<{ctx.dm}> (compute_Ad)"
+        launch_us, launch_bytes, launches = spmv_us, spmv_bytes, int(tm["spmv_launches"])
+    achieved = launch_bytes / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(args.workload, kernel) if not args.cells else (None, "non-standard --cells")
     cg_only = total_iters / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0
     asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
     per_gpu = ELEMS_PER_GPU[args.workload]
@@ -331,18 +353,25 @@ def main():
         "assembly_ms": asm_ms,
         "pcg_us_per_iter": tm["pcg_ms"] * 1e3 / max(total_iters, 1),
         # algorithmic flop rates: SpMV 2*nnz per launch; assembly 2.9 (C3D4) / 57 (C3D10) kflop per element
-        "spmv_tflops": 2 * info.nnz / (spmv_us * 1e-6) / 1e12 if spmv_us > 0 else 0.0,
+        "spmv_tflops": (2 * info.nnz / (spmv_us * 1e-6) / 1e12 if spmv_us > 0 else
+                        (2 * info.nnz * total_iters / (tm["pcg_ms"] * 1e-3) / 1e12 if tm["pcg_ms"] > 0 else 0.0)),
         "assembly_tflops": kflop_per_elem * 1e3 * ne_global / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
-        "roofline": {"kernel": "k_spmv<3> (compute_Ad)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "peak_source": "spec (MI355X_MICROARCH.md)", "copy_probe_gbs": probe,
-                     "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us,
-                     "launches_timed": int(tm["spmv_launches"]),
-                     "pcg_iteration_gbs": (spmv_bytes + 88 * n) * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9
+                     "bytes_per_launch": int(launch_bytes), "avg_launch_us": launch_us,
+                     "launches_timed": launches,
+                     "pcg_iteration_gbs": iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9
                      if tm["pcg_ms"] > 0 else 0.0,
-                     "pcg_iteration_frac": (spmv_bytes + 88 * n) * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                     "pcg_iteration_frac": iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                      if tm["pcg_ms"] > 0 else 0.0},
     }
+    if persist:
+        # what the persistent kernel keeps on chip: `achieved` counts ALGORITHMIC bytes, of which the register- and
+        # LDS-resident block rows and the vectors never travel after the first iteration
+        result["roofline"]["note"] = ("algorithmic bytes / launch time; the kernel holds the vectors and part of the "
+                                      "matrix in registers / LDS for the whole solve, so the bytes that actually move "
+                                      "per iteration are fewer (see `traffic`) and the figure may exceed the HBM peak")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu
     if rank == 0:

@@ -290,13 +290,18 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->exchange = (int)value;
             break;
         case FEMCY_OPT_PCG_PERSIST:
-            FEMCY_REQUIRE(value == 0 || value == 1, "persistent PCG: 0 (off) or 1 (auto)");
+            FEMCY_REQUIRE(value >= 0 && value <= 2, "persistent PCG: 0 (off), 1 (auto) or 2 (whenever the slices fit)");
             c->opt_persist = (int)value;
             c->persist_failed = false;
             break;
         case 104:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
             c->opt_persist_lds = (int)value;
+            break;
+        case 107:   /* test knob: workgroups of the persistent PCG (0 = one per CU) -- exercises the barrier time-out */
+            FEMCY_REQUIRE(value >= 0 && value <= 4096, "workgroup count out of range");
+            c->opt_persist_wgs = (int)value;
+            c->persist_failed = false;
             break;
         case 106:   /* timing experiments: bit 0 no streamed rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait */
             c->opt_persist_dbg = (int)value;

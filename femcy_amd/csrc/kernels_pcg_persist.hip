@@ -21,8 +21,6 @@
 #include <algorithm>
 #include <cmath>
 #include <vector>
-#include <cstdio>
-#include <cstdlib>
 #include "ctx.hpp"
 
 namespace femcy {
@@ -49,7 +47,6 @@ struct PersistPcg {
     unsigned int* xc;     // [8][32]     per-XCD arrival counters (one cache line apart)
     unsigned int* top;
     PcgState* st;
-    XcdRanges xr;         // slice range of each XCD
     int32_t npad, maxit, lds_rows, dbg;
     double eps;
 };
@@ -103,10 +100,20 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
         const unsigned prev = __hip_atomic_fetch_add(a.xc + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1 == members * (round + 1))                   // last arrival of this XCD group in this round
             __hip_atomic_fetch_add(a.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // bounded wait (a legitimate one is < 100 us): on a time-out the top counter is poisoned, which releases every
+        // other workgroup -- those spinning now and those that reach a barrier later -- with the same verdict
+        constexpr unsigned POISON = 0x80000000u;
         unsigned spins = 0;
-        while (!(a.dbg & 8) && __hip_atomic_load(a.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PNX * (round + 1)) {
+        while (!(a.dbg & 8)) {
+            const unsigned v = __hip_atomic_load(a.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v & POISON) {
+                *s_fail = 1;
+                break;
+            }
+            if (v >= PNX * (round + 1)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 25)) {
+            if (++spins > (1u << 21)) {
+                __hip_atomic_fetch_or(a.top, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_fail = 1;
                 break;
             }
@@ -161,16 +168,26 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             for (int k = 0; k < DD; ++k) rv[t][jj][k] = has ? src[kv_index<DM>(0, k, lane)] : 0.0;
             rcl[t][jj] = has ? a.bcol[(offs[t] + jj) * 64 + lane] : (node[t] >= 0 ? node[t] : 0);
         }
+    // LDS rows are handed out from the LAST slice backwards, so that slice 0 keeps streamed rows: its first batch is
+    // the one prefetched during the synchronisation windows (below).  jl[t] .. je[t]-1 = the slice's rows in LDS.
+    int32_t jl[SPW], je[SPW], ql[SPW];
     {
-        int q = 0;
+        int qn = 0;
 #pragma unroll
-        for (int t = 0; t < SPW; ++t)
-            for (int32_t j = RJ; j < Ls[t] && q < a.lds_rows; ++j, ++q) {
+        for (int t = SPW - 1; t >= 0; --t) {
+            jl[t] = min(RJ, Ls[t]);
+            const int nl = max(0, min(Ls[t] - jl[t], a.lds_rows - qn));
+            ql[t] = qn;
+            je[t] = jl[t] + nl;
+            qn += nl;
+            for (int32_t j = jl[t]; j < je[t]; ++j) {
+                const int q = ql[t] + (j - jl[t]);
                 const double* src = a.vals + (offs[t] + j) * (int64_t)(DD * 64);
 #pragma unroll
                 for (int k = 0; k < DD; ++k) lvals[(q * DD + k) * 64 + lane] = src[kv_index<DM>(0, k, lane)];
                 lcols[q * 64 + lane] = a.bcol[(offs[t] + j) * 64 + lane];
             }
+        }
     }
     // d is gathered with sc1 BUFFER loads: the same cache policy as an agent-scope atomic load (the other XCDs wrote d
     // with sc1 stores), but an ordinary load to the compiler, which may then issue the gathers of several block rows
@@ -185,6 +202,37 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             xv[cc] = __hiloint2double((int)w.y, (int)w.x);
         }
     };
+    // nb (<= CH) consecutive block rows of a slice: columns and values (rows beyond nb: the column of the last one,
+    // so that its gather stays in range; no values)
+    auto load_rows = [&](const int32_t* __restrict__ bc, const double2* __restrict__ vp, const double* __restrict__ vs,
+                         int32_t j, int nb, int32_t (&col)[CH], double (&e)[CH][DD]) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) col[u] = bc[(int64_t)(j + max(0, min(u, nb - 1))) * 64];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (u < nb) {
+#pragma unroll
+                for (int kp = 0; kp < NP; ++kp) {
+                    const double2 v2 = vp[(int64_t)(j + u) * (DD * 32) + kp * 64];
+                    e[u][2 * kp] = v2.x;
+                    e[u][2 * kp + 1] = v2.y;
+                }
+                if (DD & 1) e[u][DD - 1] = vs[(int64_t)(j + u) * (DD * 64)];
+            } else {
+                // defined on every path: a conditionally rewritten loop-carried buffer would keep its old value alive
+                // through the whole iteration (the prefetch buffer then costs 76 registers at the product's peak)
+#pragma unroll
+                for (int k = 0; k < DD; ++k) e[u][k] = 0.0;
+            }
+    };
+    const int32_t* __restrict__ bc0 = a.bcol + offs[0] * 64 + lane;
+    const double2* __restrict__ vp0 = reinterpret_cast<const double2*>(a.vals + offs[0] * (int64_t)(DD * 64)) + lane;
+    const double* __restrict__ vs0 = a.vals + offs[0] * (int64_t)(DD * 64) + NP * 128 + lane;
+    const int npf = (a.dbg & 16) ? 0 : max(0, min(CH, Ls[0] - je[0]));   // rows of the prefetched batch
+    int32_t pcol[CH];
+    double pe[CH][DD];
+    const int32_t jpf = npf > 0 ? je[0] : 0;                               // (npf = 0: row 0's column, unused)
+    load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
     // ---- x0 = 0, r = b, d = M r
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
@@ -247,14 +295,33 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
         // ---- Ad = K d for the wave's rows, d gathered with sc1 loads (the other XCDs wrote it with sc1 stores)
         double dot = 0.0;
-        int q = 0;
 #pragma unroll
         for (int t = 0; t < SPW; ++t) {
             double acc[DM];
 #pragma unroll
             for (int r = 0; r < DM; ++r) acc[r] = 0.0;
             const int32_t L = Ls[t];
-            // block rows held in registers: all their gathers are issued before the first multiply
+            const int32_t* __restrict__ bc = a.bcol + offs[t] * 64 + lane;
+            const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
+            const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
+            int32_t j = je[t];                                               // first streamed block row
+            // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points
+            if (t == 0 && npf > 0 && !(a.dbg & 1)) {
+                double xg[CH][DM];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (u < npf) {
+#pragma unroll
+                        for (int r = 0; r < DM; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < DM; ++cc) acc[r] += pe[u][r * DM + cc] * xg[u][cc];
+                    }
+                j += npf;
+            }
+            // block rows held in registers: their gathers are issued in batches before the first multiply
             if (RJ > 0 && !(a.dbg & 4)) {
                 constexpr int RB = RJ > 4 ? 3 : (RJ > 0 ? RJ : 1);               // rows per batch (register budget)
 #pragma unroll
@@ -275,10 +342,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            int32_t j = RJ;
-            // block rows held in LDS, four at a time (a short batch repeats its last row's gather and skips the multiply)
-            while (j < L && q < a.lds_rows && !(a.dbg & 2)) {
-                const int nb = min(CH, min(L - j, a.lds_rows - q));
+            // block rows held in LDS, CH at a time (a short batch repeats its last row's gather and skips the multiply)
+            for (int32_t jr = jl[t]; jr < je[t] && !(a.dbg & 2); jr += CH) {
+                const int nb = min(CH, je[t] - jr);
+                const int q = ql[t] + (jr - jl[t]);
                 double xg[CH][DM];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(lcols[(q + min(u, nb - 1)) * 64 + lane], poff, xg[u]);
@@ -292,30 +359,13 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                             for (int cc = 0; cc < DM; ++cc)
                                 acc[r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
                     }
-                j += nb;
-                q += nb;
             }
-            // streamed block rows, four at a time: columns, then the values, then the gathers, then the multiplies
-            const int32_t* __restrict__ bc = a.bcol + offs[t] * 64 + lane;
-            const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
-            const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
+            // streamed block rows, CH at a time: columns, then the values, then the gathers, then the multiplies
             while (j < L && !(a.dbg & 1)) {
                 const int nb = min(CH, L - j);
                 int32_t col[CH];
                 double e[CH][DD], xg[CH][DM];
-#pragma unroll
-                for (int u = 0; u < CH; ++u) col[u] = bc[(int64_t)(j + min(u, nb - 1)) * 64];
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (u < nb) {
-#pragma unroll
-                        for (int kp = 0; kp < NP; ++kp) {
-                            const double2 v2 = vp[(int64_t)(j + u) * (DD * 32) + kp * 64];
-                            e[u][2 * kp] = v2.x;
-                            e[u][2 * kp + 1] = v2.y;
-                        }
-                        if (DD & 1) e[u][DD - 1] = vs[(int64_t)(j + u) * (DD * 64)];
-                    }
+                load_rows(bc, vp, vs, j, nb, col, e);
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -335,6 +385,9 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 if (node[t] >= 0) dot += dd[t][r] * acc[r];
             }
         }
+        // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested now and arrives
+        // while the wave waits in the three synchronisation points (registers and memory system are idle there)
+        load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
         dot = pwave_sum(dot);
         if (lane == 0) sm1[wave] = dot;
         __syncthreads();
@@ -369,7 +422,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         double rMr_new = 0.0;
         gather_pairs(a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax);
         ++it;
-        if (a.dbg) rmax = 1.0, rMr_new = 1.0;
+        if (a.dbg & 15) rmax = 1.0, rMr_new = 1.0;   // bits 0-3 skip work: keep iterating on whatever numbers result
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
             done = 2;
         } else if (rmax < a.eps * r0) {
@@ -411,15 +464,16 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
     *handled = false;
     if (!c->opt_persist || c->comm || c->persist_failed) return FEMCY_OK;
-    const int G = (c->persist_cus / PNX) * PNX;                  // one workgroup per CU
+    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;   // one workgroup per CU
     if (G < PNX) return FEMCY_OK;
     const int nwx = (G / PNX) * 4;
     int32_t maxrange = 0;
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    if (getenv("FEMCY_DEBUG"))
-        fprintf(stderr, "[femcy] persistent PCG: %d slices, widest XCD range %d, %d waves per XCD x %d slices\n",
-                (int)c->nslices, (int)maxrange, nwx, maxrange > 3 * nwx ? 4 : 3);
-    if (maxrange > 4 * nwx || c->nslices < G) return FEMCY_OK;  // does not fit / too small to be worth a whole chip
+    // eligible: every wave gets its slices (<= 4), the chip is filled, and the matrix streams from the Infinity Cache
+    // (256 MiB): with one wave per SIMD the streamed part has little latency hiding, and a matrix that comes from
+    // HBM every iteration (124 k C3D10: 380 MB) runs at 139 us per iteration here against 94 with three launches
+    const int64_t kbytes = c->stored_rows * (int64_t)(c->dm * c->dm * 8 + 4) * 64;
+    if (maxrange > 4 * nwx || c->nslices < G || (kbytes > c->persist_max_bytes && c->opt_persist < 2)) return FEMCY_OK;
     const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
@@ -476,7 +530,6 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     a.xc = reinterpret_cast<unsigned int*>(a.part2 + 4 * G);
     a.top = a.xc + 8 * 32;
     a.st = c->d_state;
-    a.xr = c->xcd;
     a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps; a.dbg = c->opt_persist_dbg;
     FEMCY_HIP(hipMemsetAsync(a.xc, 0, sizeof(unsigned int) * (8 * 32 + 32), c->stream));
 #define FEMCY_PERSIST(DM_, SPW_, RJ_)                                                                             \

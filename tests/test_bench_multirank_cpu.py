@@ -125,7 +125,9 @@ class MockContext:
 
     def timing(self):
         return {"geom_ms": 1.0, "geom_launches": 1, "assemble_ms": 1.0, "assemble_launches": 1, "force_ms": 0.0,
-                "force_launches": 0, "spmv_ms": 1.0, "spmv_launches": 1, "pcg_ms": 1.0, "pcg_iters": 1}
+                "force_launches": 0, "spmv_ms": 1.0, "spmv_launches": 1, "pcg_ms": 1.0, "pcg_iters": 1,
+                "persist_ms": 0.0, "persist_launches": 0, "persist_iters": 0, "solves_three": 1, "solves_small": 0,
+                "solves_persist": 0}
 
     def sync(self):
         pass

@@ -49,3 +49,22 @@ def test_bench_c3d10_workload_and_forced_comm():
         assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None       # non-standard --cells
         if "--force-comm" in extra:
             assert d["config"]["interface_exchange"]["exchange"] == extra[-1]
+
+
+def test_bench_headline_workload_runs_the_persistent_pcg():
+    """the 1 M-element configuration the metric is quoted on: the PCG solves are single launches of k_pcg_persist, and
+    the roofline object prices THAT kernel (algorithmic bytes of the iterations it ran / HIP-event time of the launch)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--iters", "100",
+                          "--prewarm", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    assert "995328 elements" in d["config"]["workload"] and d["config"]["cg_iters_per_step"] == 100
+    assert r["kernel"].startswith("k_pcg_persist") and r["launches_timed"] == 2 and r["bound"] == "hbm"
+    spmv_bytes = 8 * 23454045 + 4 * 2606005 + 4 * (182845 + 1) + 16 * 548535          # SURVEY.md 8d at this size
+    assert r["bytes_per_launch"] == 100 * (spmv_bytes + 88 * 548535)
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert 10.0 < r["avg_launch_us"] / 100 < 60.0                                      # us per iteration inside the launch
+    assert abs(d["pcg_us_per_iter"] - r["avg_launch_us"] / 100) < 5.0                  # the solve IS that launch (+ Jacobi, copy-back)

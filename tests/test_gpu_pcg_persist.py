@@ -1,0 +1,170 @@
+"""-m gpu: the persistent one-launch PCG (kernels_pcg_persist.hip; vectors and part of the matrix in registers, part in
+LDS, three grid barriers per iteration) against the three-kernel loop and the numpy restatement of the reference
+recurrence (conjugateGradientSolver.py:103-127), on meshes large enough to fill the chip (>= 256 slices of 64 nodes)."""
+import numpy as np
+import pytest
+
+import oracle.femcy_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(gpu_ctx_factory, mesh, element):
+    from femcy_amd import backend as be
+    from femcy_amd.material_zoo import LinearIsotropic, LinearIsotropicPlaneStrain
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(mesh["nodes"], mesh["elements"])
+    ctx.set_element(element)
+    dm = mesh["nodes"].shape[1]
+    ctx.set_material(LinearIsotropic(*mesh["elastic"]) if dm == 3 else LinearIsotropicPlaneStrain(*mesh["elastic"]))
+    info = ctx.build_pattern()
+    ctx.assemble_K(-1)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in mesh["dirichlet_bc_info"]]))
+    b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+    return be, ctx, info, b
+
+
+def _paths(ctx):
+    t = ctx.timing()
+    return t["solves_three"], t["solves_small"], t["solves_persist"]
+
+
+@pytest.fixture(scope="module")
+def plate(gpu_ctx_factory):
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    m = meshgen.twist_plate(24, 6, 96)                    # 82 944 C3D4, 16 975 nodes = 266 slices, 50 925 DOF
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_linear_tetrahedral())
+    assert info.nslices >= 256
+    K = ctx.get_K_bsr().tocsr()
+    return dict(be=be, ctx=ctx, K=K, b=b, bb=ctx.download(be.VEC_RESIDUAL))
+
+
+def _solve(ctx, be, eps, maxit):
+    r = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=eps, maxit=maxit)
+    return r, ctx.download(be.VEC_X)
+
+
+def test_persistent_pcg_is_the_path_and_equals_the_three_kernel_loop(plate):
+    be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
+    res = {}
+    for persist in (0, 1):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = _paths(ctx)
+        res[persist] = [_solve(ctx, be, eps, maxit) for eps, maxit in ((0.0, 1), (0.0, 7), (0.0, 40), (1e-10, 10 ** 6))]
+        after = _paths(ctx)
+        # the path that ran: four solves, all three-kernel or all persistent, never the small-system kernel
+        assert (after[0] - before[0], after[1] - before[1], after[2] - before[2]) == ((4, 0, 0), (0, 0, 4))[persist]
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(res[0][:3], res[1][:3]), (1e-13, 1e-12, 1e-10)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    # against the numpy restatement of the reference recurrence
+    for ((it, r0, rm), x), maxit, tol in zip(res[1][:3], (1, 7, 40), (1e-13, 1e-12, 1e-10)):
+        xo, ito, r0o, rmo = orc.pcg_reference(K, bb, eps=0.0, maxit=maxit)
+        assert it == ito == maxit and r0 == r0o and abs(rm - rmo) <= tol * rmo
+        assert np.linalg.norm(x - xo) <= tol * np.linalg.norm(xo)
+    (it0, r00, rm0), x0 = res[0][3]
+    (it1, r01, rm1), x1 = res[1][3]
+    assert abs(it0 - it1) <= max(2, it0 // 50) and rm1 < 1e-10 * r01
+    assert np.abs(K @ x1 - bb).max() < 2e-10 * r01 + 1e-9 * r01
+    assert np.linalg.norm(x1 - x0) <= 1e-7 * np.linalg.norm(x0)
+    # run-to-run bit reproducible (fixed summation order, fixed slice-to-wave assignment)
+    (it2, _, rm2), x2 = _solve(ctx, be, 1e-10, 10 ** 6)
+    assert it2 == it1 and rm2 == rm1 and np.array_equal(x2, x1)
+
+
+@pytest.mark.parametrize("knobs", [dict(rj=0, lds=0), dict(rj=0, lds=-1), dict(rj=4, lds=0), dict(rj=5, lds=3),
+                                   dict(rj=4, lds=-1, dbg=16)])
+def test_persistent_pcg_residency_variants_agree(plate, knobs):
+    """where a block row lives (registers, LDS, streamed, prefetched during the barriers) changes the order of a row's
+    partial products, not the recurrence: iterates agree to rounding, the converged solution solves the system"""
+    be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    (itr, _, rmr), xr = _solve(ctx, be, 0.0, 25)
+    ctx.set_option(105, knobs["rj"])
+    ctx.set_option(104, knobs["lds"])
+    ctx.set_option(106, knobs.get("dbg", 0))
+    try:
+        before = _paths(ctx)
+        (it, r0, rm), x = _solve(ctx, be, 0.0, 25)
+        assert it == itr == 25 and abs(rm - rmr) <= 1e-11 * rmr and np.linalg.norm(x - xr) <= 1e-11 * np.linalg.norm(xr)
+        (it, r0, rm), x = _solve(ctx, be, 1e-8, 10 ** 6)
+        assert rm < 1e-8 * r0 and np.abs(K @ x - bb).max() < 2.1e-8 * r0
+        assert _paths(ctx)[2] - before[2] == 2
+    finally:
+        ctx.set_option(105, 4)
+        ctx.set_option(104, -1)
+        ctx.set_option(106, 0)
+
+
+def test_persistent_pcg_edge_cases(plate):
+    be, ctx, b = plate["be"], plate["ctx"], plate["b"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    before = _paths(ctx)
+    try:
+        ctx.vector(be.VEC_RESIDUAL).fill(0.0)                           # b = 0: zero iterations, x = 0
+        it, r0, rm = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        assert it == 0 and r0 == 0.0 and not ctx.download(be.VEC_X).any()
+        bad = plate["bb"].copy()
+        bad[5] = np.nan
+        ctx.upload(be.VEC_RESIDUAL, bad)
+        with pytest.raises(be.FemcyError) as ei:
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        assert ei.value.status == be.FEMCY_ENUMERIC
+        bad[5] = np.inf
+        ctx.upload(be.VEC_RESIDUAL, bad)
+        with pytest.raises(be.FemcyError) as ei:
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        assert ei.value.status == be.FEMCY_ENUMERIC
+        assert _paths(ctx)[2] - before[2] == 3
+        # an eps that the initial residual already meets after one iteration at the latest; r0 is max|b|
+        ctx.upload(be.VEC_RESIDUAL, plate["bb"])
+        it, r0, rm = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=10.0)
+        assert it == 1 and r0 == np.abs(plate["bb"]).max() and rm < 10.0 * r0
+    finally:
+        ctx.upload(be.VEC_RESIDUAL, plate["bb"])
+
+
+def test_barrier_timeout_falls_back_to_the_three_kernel_loop(plate):
+    """more workgroups than can be co-resident (two per CU at 512 registers per lane): the first grid barrier can never
+    complete; the bounded spin poisons the counter, every workgroup leaves, and the solve is redone by the three-kernel
+    loop -- same answer, and the context does not try the persistent kernel again"""
+    be, ctx = plate["be"], plate["ctx"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 0)
+    (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 12)
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(107, 512)
+    try:
+        before = _paths(ctx)
+        (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 12)
+        after = _paths(ctx)
+        assert (after[0] - before[0], after[2] - before[2]) == (1, 0)
+        assert (it1, r01, rm1) == (it0, r00, rm0) and np.array_equal(x1, x0)
+        (it2, _, _), x2 = _solve(ctx, be, 0.0, 12)                      # no second attempt (no second time-out)
+        assert _paths(ctx)[0] - after[0] == 1 and np.array_equal(x2, x0)
+    finally:
+        ctx.set_option(107, 0)                                          # also clears the "failed once" mark
+    before = _paths(ctx)
+    _solve(ctx, be, 0.0, 12)
+    assert _paths(ctx)[2] - before[2] == 1
+
+
+def test_persistent_pcg_two_dimensional_blocks(gpu_ctx_factory):
+    """dm = 2 instantiation (2 x 2 blocks) on a CPE8 beam of 65 k nodes"""
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+    m = meshgen.beam_quad8(nx=360, ny=60)                               # 21 600 CPE8, 65 761 nodes
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_quadratic_quadrilateral())
+    assert info.nslices >= 256
+    out = {}
+    for persist in (0, 1):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = _paths(ctx)
+        out[persist] = [_solve(ctx, be, 0.0, k) for k in (1, 9, 30)]
+        assert _paths(ctx)[2 if persist else 0] - before[2 if persist else 0] == 3
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(out[0], out[1]), (1e-13, 1e-11, 1e-9)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    ctx.close()

@@ -12,19 +12,22 @@ tail -20 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_c3d4.json 2> $OUT/bench_c3d4.err
 cat $OUT/bench_c3d4.json
+FEMCY_BENCH_PERSIST=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c3d4_three_kernel.json 2> $OUT/bench_c3d4_three_kernel.err
+cat $OUT/bench_c3d4_three_kernel.json
 timeout 300 python bench.py --workload c3d10 > $OUT/bench_c3d10.json 2> $OUT/bench_c3d10.err
 cat $OUT/bench_c3d10.json
 timeout 600 python bench.py --no-cpu-baseline --steps 3 --cells 192,24,288 --prewarm 1 > $OUT/bench_8M.json 2> $OUT/bench_8M.err
 cat $OUT/bench_8M.json
 (timeout 300 python tools/microbench.py 12; timeout 300 python tools/microbench.py 6 1) 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/microbench.txt
+(ITERS=500 python tools/persist_debug.py c3d4 2>&1 | grep "lds") > $OUT/persist_breakdown.txt
 (python tools/small_probe.py twist_plate_C3D10.inp; python tools/small_probe.py twist_plate_C3D4.inp; python tools/small_probe.py ellip_dense_CPS3_0d04.inp) 2>&1 | grep "iteration\|n =" > $OUT/small_probe.txt
 cat $OUT/small_probe.txt
 cd /tmp
 for wl in c3d4 c3d10; do
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$wl -o kt -- python $R/bench.py --workload $wl --steps 3 --no-cpu-baseline --prewarm 1 > $OUT/kt_$wl.log 2>&1
   python $R/tools/rocprof_summary.py stats $(find $OUT/kt_$wl -name "*.db" | head -1) > $OUT/kernel_stats_$wl.txt 2>&1
-  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$wl -o pmc -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --prewarm 0 --iters 40 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1
-  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$wl -o pmc -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --prewarm 0 --iters 40 --no-cpu-baseline > $OUT/write_$wl.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$wl -o pmc -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$wl -o pmc -- python $R/bench.py --workload $wl --steps 1 --warmup 1 --prewarm 0 --no-cpu-baseline > $OUT/write_$wl.log 2>&1
   python $R/tools/rocprof_summary.py pmc $(find $OUT/fetch_$wl -name "*.db" | head -1) FETCH_SIZE > $OUT/pmc_fetch_$wl.txt 2>&1
   python $R/tools/rocprof_summary.py pmc $(find $OUT/write_$wl -name "*.db" | head -1) WRITE_SIZE > $OUT/pmc_write_$wl.txt 2>&1
 done

@@ -17,7 +17,7 @@ ctx.assemble_K(-1)
 ctx.upload(be.VEC_RESIDUAL, np.sin(np.arange(ctx.n) * 0.11) * 1e3)
 ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
 print(wl, "maxrow", info.max_row_blocks, "nslices", info.nslices, flush=True)
-for lds, rj, dbg in [(-1, 5, 0), (-1, 4, 0), (-1, 5, 0), (-1, 4, 0), (-1, 4, 1), (-1, 4, 4), (-1, 4, 7)]:
+for lds, rj, dbg in [(-1, 4, 0), (-1, 4, 16), (-1, 5, 0), (-1, 0, 0), (0, 0, 0), (-1, 4, 1), (-1, 4, 4), (-1, 4, 7), (-1, 4, 15)]:
     ctx.set_option(be.OPT_PCG_PERSIST, 1)
     ctx.set_option(106, dbg)
     ctx.set_option(104, lds)
