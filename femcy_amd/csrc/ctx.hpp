@@ -144,6 +144,8 @@ struct Ctx {
     double* d_part2 = nullptr;        // [2*MAX_PARTIALS] (r.M.r, max|r|) partials
     PcgState* d_state = nullptr;
     PcgState* h_state = nullptr;      // pinned
+    char* h_stage = nullptr;          // pinned staging area for small host -> device payloads (stage_h2d)
+    size_t stage_cap = 0, stage_used = 0;
     double* h_scalar = nullptr;       // pinned scratch for reductions
     int32_t* d_idx_scratch = nullptr;
     double* d_val_scratch = nullptr;
@@ -170,6 +172,7 @@ struct Ctx {
     double* d_persist = nullptr;      // d double buffer, partials, barrier counters
     int64_t persist_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
+    int opt_small_rr = -1;            // test knob 108: block rows per wave of the small-system PCG kept in registers
     int opt_small = 1;                // FEMCY_OPT_PCG_SMALL
     int small_max_lds = 65536;        // LDS a workgroup may allocate (device attribute, femcy_ctx_create)
     int small_max_wg = 128;           // workgroups that are certainly co-resident at one per CU

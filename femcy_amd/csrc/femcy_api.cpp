@@ -51,6 +51,34 @@ int ensure_scratch(Ctx* c, int64_t k) {
     return FEMCY_OK;
 }
 
+// Small host -> device payloads (the values of a prescribed-displacement block, index lists of a scatter) go through a
+// pinned staging area: the caller's buffer is copied on the host, the device copy is asynchronous, and the call does
+// not have to wait for the stream (a pageable hipMemcpyAsync + hipStreamSynchronize costs ~40 us per call; a deck run
+// issues tens of thousands of them).  The area is a bump allocator: when it is full the stream is drained once.
+static int stage_h2d(Ctx* c, void* dst, const void* src, size_t bytes) {
+    constexpr size_t CAP = (size_t)1 << 20;
+    if (bytes > CAP / 4) {                                  // large payloads: plain copy, synchronous for the caller
+        FEMCY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        return FEMCY_OK;
+    }
+    if (!c->h_stage) {
+        FEMCY_HIP(hipHostMalloc((void**)&c->h_stage, CAP, hipHostMallocDefault));
+        c->stage_cap = CAP;
+        c->stage_used = 0;
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->stage_used + need > c->stage_cap) {
+        FEMCY_HIP(hipStreamSynchronize(c->stream));         // every copy that reads the area has finished
+        c->stage_used = 0;
+    }
+    char* slot = c->h_stage + c->stage_used;
+    c->stage_used += need;
+    std::memcpy(slot, src, bytes);
+    FEMCY_HIP(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return FEMCY_OK;
+}
+
 // ------------------------------------------------------------------------------------- timing
 static size_t timing_slot(Ctx* c, int cls) {
     if (!c->opt_timing) return (size_t)-1;
@@ -236,6 +264,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
         (void)hipStreamDestroy(c->comm_stream);
     }
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     for (auto& ds : c->dofsets) {
         if (ds.d_dofs) (void)hipFree(ds.d_dofs);
@@ -297,6 +326,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case 104:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
             c->opt_persist_lds = (int)value;
+            break;
+        case 108:   /* test knob: register-resident block rows per wave of the small-system PCG (-1 = a wave's share) */
+            FEMCY_REQUIRE(value >= -1 && value <= 64, "register-resident rows out of range");
+            c->opt_small_rr = (int)value;
             break;
         case 107:   /* test knob: workgroups of the persistent PCG (0 = one per CU) -- exercises the barrier time-out */
             FEMCY_REQUIRE(value >= 0 && value <= 4096, "workgroup count out of range");
@@ -556,11 +589,11 @@ int femcy_vec_scatter(femcy_ctx* ctx, int vec, const int32_t* idx, const double*
     for (int32_t i = 0; i < k; ++i) FEMCY_REQUIRE(idx[i] >= 0 && idx[i] < c->n, "scatter index %d out of range", idx[i]);
     int rc = ensure_scratch(c, k);
     if (rc) return rc;
-    FEMCY_HIP(hipMemcpyAsync(c->d_idx_scratch, idx, sizeof(int32_t) * k, hipMemcpyHostToDevice, c->stream));
-    FEMCY_HIP(hipMemcpyAsync(c->d_val_scratch, vals, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
-    rc = vec_scatter(c, c->d_vec[vec], c->d_idx_scratch, c->d_val_scratch, k);
-    FEMCY_HIP(hipStreamSynchronize(c->stream));   // host buffers are only borrowed for the call
-    return rc;
+    // host buffers are only borrowed for the call: staged (the scratch lists are reused by the next scatter, which the
+    // stream orders behind this one)
+    if ((rc = stage_h2d(c, c->d_idx_scratch, idx, sizeof(int32_t) * k))) return rc;
+    if ((rc = stage_h2d(c, c->d_val_scratch, vals, sizeof(double) * k))) return rc;
+    return vec_scatter(c, c->d_vec[vec], c->d_idx_scratch, c->d_val_scratch, k);
 }
 int femcy_vec_sub(femcy_ctx* ctx, int cv, int a, int b) {
     CTX_OR_FAIL(ctx);
@@ -735,10 +768,9 @@ int femcy_dofset_scatter(femcy_ctx* ctx, int32_t id, int vec, const double* vals
     DOFSET_OR_FAIL(id);
     if (ds.k == 0) return FEMCY_OK;
     FEMCY_REQUIRE(vals, "null values");
-    FEMCY_HIP(hipMemcpyAsync(ds.d_vals, vals, sizeof(double) * ds.k, hipMemcpyHostToDevice, c->stream));
-    int rc = vec_scatter(c, c->d_vec[vec], ds.d_dofs, ds.d_vals, ds.k);
-    FEMCY_HIP(hipStreamSynchronize(c->stream));   // the host buffer is only borrowed for the call
-    return rc;
+    int rc = stage_h2d(c, ds.d_vals, vals, sizeof(double) * ds.k);   // the host buffer is only borrowed for the call
+    if (rc) return rc;
+    return vec_scatter(c, c->d_vec[vec], ds.d_dofs, ds.d_vals, ds.k);
 }
 
 int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int rhs_vec) {

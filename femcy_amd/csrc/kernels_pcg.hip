@@ -26,6 +26,7 @@
 #include <cmath>
 #include <hip/hip_ext.h>
 #include "ctx.hpp"
+#include "wave_reduce.hpp"
 
 namespace femcy {
 
@@ -33,16 +34,7 @@ constexpr int BS = 256;
 constexpr int NXCD = 8;
 
 // ------------------------------------------------------------------------------------ reductions
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
-}
+// wave_sum / wave_max: wave_reduce.hpp (DPP network; the result is in every lane)
 // result broadcast to every thread; sm must hold BS/64 doubles; two calls need distinct sm
 __device__ __forceinline__ double block_sum(double v, double* sm) {
     v = wave_sum(v);
@@ -818,7 +810,11 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 
 // K = ceil(n / 256): thread t owns the entries t, t + 256, ... of r and M and keeps them in REGISTERS for the whole
 // solve (one workgroup per CU: a wave may use the full register file); only d, which the product gathers, lives in LDS
-template <int DM, int K>
+// RR: the first RR block rows of each wave's share of the slice stay in REGISTERS for the whole solve as well (a wave's
+// share is a quarter of the slice's block rows: the register file holds 8-16 of them next to r and M); the rest is streamed from
+// L2 as before.  Keeping those in LDS as well was measured (same time: the iteration is bound by its synchronisation
+// chain, not by the product) and dropped
+template <int DM, int K, int RR>
 __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
     extern __shared__ __attribute__((aligned(16))) double lds_small[];
     double* d_l = lds_small;
@@ -863,14 +859,39 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
     const int32_t* __restrict__ bc = a.bcol + off * SLICE + lane;
     const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + off * (int64_t)(DD * SLICE)) + lane;
     const double* __restrict__ vs = a.vals + off * (int64_t)(DD * SLICE) + NP * (2 * SLICE) + lane;
+    double rv[RR > 0 ? RR : 1][DD];
+    int32_t rcl[RR > 0 ? RR : 1];
+#pragma unroll
+    for (int jj = 0; jj < RR; ++jj) {
+        const bool has = j0 + jj < j1;
+        const int32_t j = has ? j0 + jj : 0;
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+            const double2 t = vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE];
+            rv[jj][2 * kp] = has ? t.x : 0.0;
+            rv[jj][2 * kp + 1] = has ? t.y : 0.0;
+        }
+        if (DD & 1) rv[jj][DD - 1] = has ? vs[(int64_t)j * (DD * SLICE)] : 0.0;
+        rcl[jj] = has ? bc[(int64_t)j * SLICE] : 0;               // a row the wave does not have: zero block on node 0
+    }
     while (!done && it < a.maxit) {
         __syncthreads();                                 // d_l of the previous iteration is complete
         // ---- rows of slice g of K d, four waves share the row (block columns j0 .. j1 each), d gathered from LDS
         double acc[DM];
 #pragma unroll
         for (int r = 0; r < DM; ++r) acc[r] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < RR; ++jj) {
+            double xv[DM];
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) xv[cc] = d_l[rcl[jj] * DM + cc];
+#pragma unroll
+            for (int r = 0; r < DM; ++r)
+#pragma unroll
+                for (int cc = 0; cc < DM; ++cc) acc[r] += rv[jj][r * DM + cc] * xv[cc];
+        }
 #pragma unroll 2
-        for (int32_t j = j0; j < j1; ++j) {
+        for (int32_t j = j0 + RR; j < j1; ++j) {
             const int32_t col = bc[(int64_t)j * SLICE];
             double xv[DM], e[DD];
 #pragma unroll
@@ -1014,18 +1035,22 @@ static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, i
     FEMCY_HIP(hipMemsetAsync(a.counter, 0, 8, c->stream));
     const int kneed = (int)((c->n + BS - 1) / BS);
     // register buckets: thread t keeps entries t + 256 k, k < K, of r and M
-#define FEMCY_SMALL(DM_, K_)                                                                                       \
+#define FEMCY_SMALL(DM_, K_, RR_)                                                                                  \
     do {                                                                                                           \
-        const void* fn = reinterpret_cast<const void*>(&k_pcg_small<DM_, K_>);                                     \
+        const void* fn = reinterpret_cast<const void*>(&k_pcg_small<DM_, K_, RR_>);                                \
         if (lds > 48 * 1024)                                                                                       \
             FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((k_pcg_small<DM_, K_>), dim3(G), dim3(BS), lds, c->stream, a);                          \
+        hipLaunchKernelGGL((k_pcg_small<DM_, K_, RR_>), dim3(G), dim3(BS), lds, c->stream, a);                     \
     } while (0)
-#define FEMCY_SMALL_K(DM_)                        \
-    do {                                          \
-        if (kneed <= 8) FEMCY_SMALL(DM_, 8);      \
-        else if (kneed <= 24) FEMCY_SMALL(DM_, 24); \
-        else FEMCY_SMALL(DM_, 48);                \
+    // register-resident block rows per wave: a wave's share of the longest slice, in buckets the register file holds
+    // next to the K entries of r and M (19 registers per 3 x 3 block row)
+    const int share = c->opt_small_rr < 0 ? ((int)c->max_row_blocks + 3) / 4 : c->opt_small_rr;
+#define FEMCY_SMALL_K(DM_)                                                                       \
+    do {                                                                                         \
+        if (share == 0) { if (kneed <= 8) FEMCY_SMALL(DM_, 8, 0); else if (kneed <= 24) FEMCY_SMALL(DM_, 24, 0); else FEMCY_SMALL(DM_, 48, 0); } \
+        else if (kneed <= 8) { if (share <= 8) FEMCY_SMALL(DM_, 8, 8); else FEMCY_SMALL(DM_, 8, 16); }  \
+        else if (kneed <= 24) { if (share <= 8) FEMCY_SMALL(DM_, 24, 8); else FEMCY_SMALL(DM_, 24, 12); } \
+        else FEMCY_SMALL(DM_, 48, 0);   /* 192 registers of r and M: no room for block rows */   \
     } while (0)
     if (c->dm == 3) FEMCY_SMALL_K(3); else FEMCY_SMALL_K(2);
 #undef FEMCY_SMALL_K

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <vector>
 #include "ctx.hpp"
+#include "wave_reduce.hpp"
 
 namespace femcy {
 
@@ -56,35 +57,6 @@ __device__ __forceinline__ void pst(double* p, double v) {
 }
 __device__ __forceinline__ double pld(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// wave reductions on the DPP network (quad swaps, row mirrors, row broadcasts; ~6 x 8 clocks) instead of 12 dependent
-// ds_bpermute round trips through the LDS crossbar; the result (lane 63's) is returned in every lane, fixed order
-template <int CTRL, int ROWS>
-__device__ __forceinline__ double pdpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double plane63(double v) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-__device__ __forceinline__ double pwave_sum(double v) {
-    v += pdpp<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v += pdpp<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-    v += pdpp<0x141, 0xf>(v);     // row_half_mirror
-    v += pdpp<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row's sum
-    v += pdpp<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 (other rows add the 0 of `old`)
-    v += pdpp<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
-    return plane63(v);
-}
-__device__ __forceinline__ double pwave_max(double v) {   // v >= 0 (absolute values; +inf stands for NaN)
-    v = fmax(v, pdpp<0xB1, 0xf>(v));
-    v = fmax(v, pdpp<0x4E, 0xf>(v));
-    v = fmax(v, pdpp<0x141, 0xf>(v));
-    v = fmax(v, pdpp<0x140, 0xf>(v));
-    v = fmax(v, pdpp<0x142, 0xa>(v));
-    v = fmax(v, pdpp<0x143, 0xc>(v));
-    return plane63(v);
 }
 __device__ __forceinline__ double pabs(double r) {   // fmax() drops NaN; keep it visible
     const double a = fabs(r);
@@ -254,8 +226,8 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         }
     unsigned round = 0;
     auto reduce_pair_publish = [&](double s, double m, double* slot2) {
-        s = pwave_sum(s);
-        m = pwave_max(m);
+        s = wave_sum(s);
+        m = wave_max(m);
         if (lane == 0) {
             sm1[wave] = s;
             sm2[wave] = m;
@@ -272,8 +244,8 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             ps += pld(base + 2 * k);
             pm = fmax(pm, pld(base + 2 * k + 1));
         }
-        ps = pwave_sum(ps);
-        pm = pwave_max(pm);
+        ps = wave_sum(ps);
+        pm = wave_max(pm);
         __syncthreads();                                                     // sm1 / sm2 free again
         if (lane == 0) {
             sm1[wave] = ps;
@@ -388,7 +360,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested now and arrives
         // while the wave waits in the three synchronisation points (registers and memory system are idle there)
         load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
-        dot = pwave_sum(dot);
+        dot = wave_sum(dot);
         if (lane == 0) sm1[wave] = dot;
         __syncthreads();
         if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
@@ -396,7 +368,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         // ---- alpha; x, r; partials of (r.M.r, max|r|)
         double ps = 0.0;
         for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
-        ps = pwave_sum(ps);
+        ps = wave_sum(ps);
         __syncthreads();
         if (lane == 0) sm1[wave] = ps;
         __syncthreads();

@@ -484,6 +484,12 @@ def test_one_launch_small_pcg_equals_three_kernel_loop(gpu_ctx_factory, name):
     xs = x1.copy()
     ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-12, maxit=10 * ctx.n)
     assert np.array_equal(ctx.download(be.VEC_X), xs)                   # run-to-run bit reproducible
+    # where the block rows live (registers / streamed from L2) does not change a bit: same order of a row's products
+    for rr in (0, 8, 16):
+        ctx.set_option(108, rr)
+        r7 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=7)
+        assert r7 == res[1][1][0] and np.array_equal(ctx.download(be.VEC_X), res[1][1][1])
+    ctx.set_option(108, -1)
     ctx.vector(be.VEC_RESIDUAL).fill(0.0)                               # b = 0: zero iterations, x = 0
     assert ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)[0] == 0 and not ctx.download(be.VEC_X).any()
     bad = b.copy()

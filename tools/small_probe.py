@@ -26,13 +26,15 @@ b = np.sin(np.arange(ctx.n) * 0.11) * 1e3
 ctx.upload(be.VEC_RESIDUAL, b)
 ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
 print(f"{name}: n = {ctx.n}, nslices = {info.nslices}, nnzb = {info.nnzb}")
-for label, small, graph in (("one-launch", 1, 1), ("3 kernels + graph", 0, 2), ("3 kernels eager", 0, 0)):
+for label, small, graph, rr in (("one-launch", 1, 1, -1), ("one-launch, matrix streamed", 1, 1, 0),
+                                ("3 kernels + graph", 0, 2, -1), ("3 kernels eager", 0, 0, -1)):
     ctx.set_option(be.OPT_PCG_SMALL, small)
+    ctx.set_option(108, rr)
     ctx.set_option(be.OPT_PCG_GRAPH, graph)
     ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-12, maxit=10 * ctx.n)
     t = time.perf_counter()
     it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-12, maxit=10 * ctx.n)
     dt = time.perf_counter() - t
     x = ctx.download(be.VEC_X)
-    print(f"  {label:<20} {it:6d} iterations, {dt*1e3:8.2f} ms, {dt/it*1e6:6.2f} us/iteration, rmax/r0 = {rmax/r0:.2e}, |x| = {np.linalg.norm(x):.12e}")
+    print(f"  {label:<28} {it:6d} iterations, {dt*1e3:8.2f} ms, {dt/it*1e6:6.2f} us/iteration, rmax/r0 = {rmax/r0:.2e}, |x| = {np.linalg.norm(x):.12e}")
 ctx.close()
