@@ -366,6 +366,11 @@ def main():
                      "pcg_iteration_frac": iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                      if tm["pcg_ms"] > 0 else 0.0},
     }
+    if traffic is not None and launch_us > 0:
+        # the rate of the bytes that actually moved between the L2s and the fabric (HBM + Infinity Cache), for comparison
+        # with `achieved` (algorithmic bytes): the two differ by what the kernel kept on chip, or re-read
+        result["roofline"]["traffic_gbs"] = traffic / (launch_us * 1e-6) / 1e9
+        result["roofline"]["traffic_over_algorithmic"] = traffic / launch_bytes if launch_bytes else None
     if persist:
         # what the persistent kernel keeps on chip: `achieved` counts ALGORITHMIC bytes, of which the register- and
         # LDS-resident block rows and the vectors never travel after the first iteration

@@ -443,7 +443,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
     // eligible: every wave gets its slices (<= 4), the chip is filled, and the matrix streams from the Infinity Cache
     // (256 MiB): with one wave per SIMD the streamed part has little latency hiding, and a matrix that comes from
-    // HBM every iteration (124 k C3D10: 380 MB) runs at 139 us per iteration here against 94 with three launches
+    // HBM every iteration (124 k C3D10: 380 MB) runs at 99-103 us per iteration here against 93 with three launches
     const int64_t kbytes = c->stored_rows * (int64_t)(c->dm * c->dm * 8 + 4) * 64;
     if (maxrange > 4 * nwx || c->nslices < G || (kbytes > c->persist_max_bytes && c->opt_persist < 2)) return FEMCY_OK;
     const int64_t npad = (c->n + 1) & ~(int64_t)1;

@@ -70,10 +70,22 @@ def test_fullsize_against_c_oracle(full):
     co.zero_rows_cols_unit_diag(cons)
     f[cons] = 0.0
     assert rel(ctx.download(be.VEC_RESIDUAL), f) < 1e-11
-    it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
     xo, ito, r0o, rmaxo = co.cg(f, eps=0.0, maxit=30)
-    assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
-    assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+    # both forms of the recurrence at this size: the persistent one-launch solve (default here) and three launches
+    # per iteration (what a rank of a multi-GPU run executes)
+    xs = {}
+    for persist in (1, 0):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = ctx.timing()
+        it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+        after = ctx.timing()
+        key = "solves_persist" if persist else "solves_three"
+        assert after[key] - before[key] == 1
+        assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
+        xs[persist] = ctx.download(be.VEC_X)
+        assert np.linalg.norm(xs[persist] - xo) / np.linalg.norm(xo) < 1e-8
+    assert np.linalg.norm(xs[1] - xs[0]) / np.linalg.norm(xs[0]) < 1e-10
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
 
 
 def test_fullsize_properties(full):

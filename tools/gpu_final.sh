@@ -44,6 +44,12 @@ for p in A B C D E G; do
   if [ -n "$db" ]; then python $R/tools/rocprof_summary.py pmc_all $db k_assemble_rows2 > $OUT/pmc_rows2_$p.txt 2>&1; fi
   rm -rf $OUT/pmcr_$p
 done
+for p in A B C G; do
+  timeout 300 rocprofv3 --kernel-trace --pmc ${PASS[$p]} -d $OUT/pmcp_$p -o pmc -- python $R/tools/persist_pmc_driver.py 3 200 > $OUT/pmcp_$p.log 2>&1
+  db=$(find $OUT/pmcp_$p -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $R/tools/rocprof_summary.py pmc_all $db k_pcg_persist > $OUT/pmc_persist_$p.txt 2>&1; fi
+  rm -rf $OUT/pmcp_$p
+done
 cd $R
 python tools/make_traffic_json.py $HEAD_SHA c3d4:$(find $OUT/fetch_c3d4 -name "*.db" | head -1):$(find $OUT/write_c3d4 -name "*.db" | head -1) c3d10:$(find $OUT/fetch_c3d10 -name "*.db" | head -1):$(find $OUT/write_c3d10 -name "*.db" | head -1) > $OUT/traffic.log 2>&1
 cp profiles/spmv_traffic.json $OUT/spmv_traffic.json
