@@ -1,23 +1,27 @@
-// Jacobi-PCG as ONE persistent launch for systems that fit one wavefront-task per SIMD (<= ~6e5 DOF on MI355X: the
-// headline 1 M-element C3D4 configuration), single rank.
+// Jacobi-PCG as ONE persistent launch for single-rank systems that fit one wavefront-task per SIMD (<= 4 slices of
+// 64 rows per wave: ~7e5 DOF on MI355X) and whose matrix streams from the Infinity Cache (<= 240 MiB stored): the
+// headline 1 M-element C3D4 configuration.  DESIGN.md section 3 has the measurements.
 //
 // Why: with three launches per iteration (kernels_pcg.hip) the product streams the whole matrix from the Infinity
 // Cache every iteration (198 MB, 31 us) and the two vector kernels are latency-bound launches of 5.6 us each.  Here
-//   * one workgroup per CU stays resident for the whole solve; wave w of XCD k owns up to SPW slices (64 rows each)
-//     of that XCD's contiguous slice range, lane = row, and keeps x, r, d, M of its rows in REGISTERS -- no vector
-//     kernel, no vector traffic except the d the other waves gather (written once, 8 n bytes per iteration);
-//   * the first `lds_rows` block rows of every wave live in LDS for the whole solve (160 KB per CU = 40 MB of the
-//     198 MB matrix), the rest is streamed as before;
+//   * one workgroup of four waves per CU stays resident for the whole solve (one wave per SIMD = 512 registers per
+//     lane); a wave owns up to SPW slices of its XCD's contiguous slice range (handed out longest first, host side),
+//     lane = row, and keeps x, r, d, M, Ad of its rows in REGISTERS -- no vector kernel, no vector traffic except the
+//     d the other waves gather (written once, 8 n bytes per iteration);
+//   * block rows 0 .. RJ-1 of every slice live in registers (AGPRs) and the next `lds_rows` block rows of the wave in
+//     LDS for the whole solve (47 % of the 198 MB matrix at RJ = 4); the first streamed batch of the next product is
+//     requested right after the current one and arrives during the barrier waits; the rest is streamed in batches
+//     of CH block rows (columns, values, then the gathers as sc1 buffer loads, then the multiplies);
 //   * the three synchronisation points of the recurrence (d.Ad before alpha, r.M.r before beta, the new d before the
 //     next product) are grid barriers: per-XCD arrival counters + one top counter, relaxed agent-scope atomics, data
 //     exchanged with sc1 (write-through) stores and sc1 loads -- no fences (cdna_hip_programming.md Guideline 16, R1).
-//     Measured (tools/micro/barrier_probe.hip): 2.3 us per barrier at 256 workgroups, against 1.7-1.9 us for a
+//     Measured (tools/micro/barrier_probe.hip): 2.2-2.4 us per barrier at 256 workgroups, against 1.7-1.9 us for a
 //     kernel boundary plus the ramp of a new launch.
 // Recurrence, preconditioner and stopping rule are those of pcg_solve / the reference
 // (conjugateGradientSolver.py:103-127); partial sums are combined in a fixed order, so a solve is bit-reproducible.
 // d is double-buffered by iteration parity (a wave may gather d_k while a faster one already publishes d_k+1), as are
-// the partial arrays.  Every spin is bounded: a timeout ends the launch with state.done = 3 and the host falls back to
-// the three-kernel loop.
+// the partial arrays.  Every spin is bounded: the workgroup that times out poisons the top counter (which releases
+// all others), the launch ends with state.done = 3 and the host falls back to the three-kernel loop.
 #include <algorithm>
 #include <cmath>
 #include <vector>
