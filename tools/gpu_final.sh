@@ -19,7 +19,7 @@ cat $OUT/bench_c3d10.json
 timeout 600 python bench.py --no-cpu-baseline --steps 3 --cells 192,24,288 --prewarm 1 > $OUT/bench_8M.json 2> $OUT/bench_8M.err
 cat $OUT/bench_8M.json
 (timeout 300 python tools/microbench.py 12; timeout 300 python tools/microbench.py 6 1) 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/microbench.txt
-(ITERS=500 python tools/persist_debug.py c3d4 2>&1 | grep "lds") > $OUT/persist_breakdown.txt
+(ITERS=500 python tools/persist_breakdown.py c3d4 2>&1 | grep "lds") > $OUT/persist_breakdown.txt
 (python tools/small_probe.py twist_plate_C3D10.inp; python tools/small_probe.py twist_plate_C3D4.inp; python tools/small_probe.py ellip_dense_CPS3_0d04.inp) 2>&1 | grep "iteration\|n =" > $OUT/small_probe.txt
 cat $OUT/small_probe.txt
 cd /tmp

@@ -1,6 +1,15 @@
-import os, sys, time
+"""where the time of one iteration of the persistent PCG goes: the same 500-iteration solve with parts of the kernel
+switched off through the test knobs 104 (LDS rows per wave), 105 (register rows per slice) and 106 (bit 0 no streamed
+rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait, 4 no prefetch; bits 0-3 give meaningless numbers, only the
+time counts) -> profiles/r02_persist_pcg_breakdown.txt
+usage: ITERS=500 python tools/persist_breakdown.py c3d4|c3d10"""
+import os
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from femcy_amd import backend as be, meshgen
 from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
 from femcy_amd.material_zoo import LinearIsotropic
