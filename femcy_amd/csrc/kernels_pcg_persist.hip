@@ -68,12 +68,18 @@ __device__ __forceinline__ double pabs(double r) {   // fmax() drops NaN; keep i
 }
 
 // all workgroups of the launch; `round` counts the barriers since the launch (0, 1, 2, ...)
-__device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round, int* s_fail) {
+// `mid` runs in every thread between the arrival and the wait: loads issued there travel while the workgroup waits
+// (issued before the arrival they would sit in front of it in the in-order return queue: s_waitcnt vmcnt(0))
+template <class Mid>
+__device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round, int* s_fail, Mid&& mid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's sc1 stores have left
     __syncthreads();
+    const unsigned G = gridDim.x, k = blockIdx.x % PNX, members = G / PNX;
+    unsigned prev = 0;
+    if (threadIdx.x == 0)
+        prev = __hip_atomic_fetch_add(a.xc + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mid();
     if (threadIdx.x == 0) {
-        const unsigned G = gridDim.x, k = blockIdx.x % PNX, members = G / PNX;
-        const unsigned prev = __hip_atomic_fetch_add(a.xc + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev + 1 == members * (round + 1))                   // last arrival of this XCD group in this round
             __hip_atomic_fetch_add(a.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // bounded wait (a legitimate one is < 100 us): on a time-out the top counter is poisoned, which releases every
@@ -97,6 +103,9 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
     }
     __syncthreads();
     return *s_fail == 0;
+}
+__device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round, int* s_fail) {
+    return grid_barrier(a, round, s_fail, [] {});
 }
 
 template <int DM, int SPW, int RJ>
@@ -361,14 +370,14 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 if (node[t] >= 0) dot += dd[t][r] * acc[r];
             }
         }
-        // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested now and arrives
-        // while the wave waits in the three synchronisation points (registers and memory system are idle there)
-        load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
+        // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested inside the first
+        // barrier (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
+        // synchronisation points (registers and memory system are idle there)
         dot = wave_sum(dot);
         if (lane == 0) sm1[wave] = dot;
         __syncthreads();
         if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
-        if (!grid_barrier(a, round++, &s_fail)) { done = 3; break; }
+        if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe); })) { done = 3; break; }
         // ---- alpha; x, r; partials of (r.M.r, max|r|)
         double ps = 0.0;
         for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
