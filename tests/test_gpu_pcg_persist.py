@@ -168,3 +168,41 @@ def test_persistent_pcg_two_dimensional_blocks(gpu_ctx_factory):
         assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
         assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
     ctx.close()
+
+
+def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
+    """above 3 x 128 slices per XCD range a wave owns up to FOUR slices (SPW = 4 instantiation, 3 register rows per
+    slice): a 1.09 M-element C3D4 plate (200 889 nodes = 3 139 slices, 217 MB of matrix: still Infinity-Cache size).
+    And the 124 k C3D10 plate (380 MB) is NOT taken by default -- its matrix streams from HBM -- but runs when forced."""
+    import time
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
+    m = meshgen.twist_plate(100, 12, 152)
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_linear_tetrahedral())
+    assert 3072 < info.nslices <= 4096
+    out, us = {}, {}
+    for persist in (0, 1):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = _paths(ctx)
+        out[persist] = [_solve(ctx, be, 0.0, k) for k in (1, 9, 30)]
+        assert _paths(ctx)[2 if persist else 0] - before[2 if persist else 0] == 3
+        t = time.perf_counter()
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)
+        us[persist] = (time.perf_counter() - t) / 300 * 1e6
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(out[0], out[1]), (1e-13, 1e-12, 1e-10)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    print(f"[1.09 M C3D4, 4 slices per wave] three launches {us[0]:.1f} us / iteration, persistent {us[1]:.1f}")
+    assert us[1] < us[0]                                   # the form that is chosen by default is the faster one
+    ctx.close()
+    mq = meshgen.twist_plate(48, 6, 72, quadratic=True)
+    be, ctx, info, b = _system(gpu_ctx_factory, mq, Element_quadratic_tetrahedral())
+    before = _paths(ctx)
+    (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 20)
+    assert _paths(ctx)[0] - before[0] == 1                 # default: three launches (matrix beyond the Infinity Cache)
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
+    (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 20)
+    assert _paths(ctx)[2] - before[2] == 1
+    assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= 1e-11 * rm0
+    assert np.linalg.norm(x1 - x0) <= 1e-11 * np.linalg.norm(x0)
+    ctx.close()
