@@ -158,7 +158,8 @@ struct Ctx {
     int opt_graph = 1;
     // ---- persistent one-launch PCG for systems of one wavefront-task per SIMD (k_pcg_persist)
     int opt_persist = 1;              // FEMCY_OPT_PCG_PERSIST
-    int64_t persist_max_bytes = (int64_t)240 << 20;   // matrix size limit of the persistent PCG (Infinity Cache)
+    int64_t persist_max_bytes = (int64_t)240 << 20;   // limit on the STREAMED part of the matrix in the persistent PCG
+                                                      // (Infinity Cache size)
     int opt_persist_rj = 4;           // block rows per slice kept in registers (test knob 105)
     int opt_persist_wgs = 0;          // test knob 107: workgroups of the launch (0 = one per CU; more than that cannot
                                       // be co-resident, the barrier times out and the solve falls back)

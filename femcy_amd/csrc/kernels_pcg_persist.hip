@@ -454,16 +454,21 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     const int nwx = (G / PNX) * 4;
     int32_t maxrange = 0;
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    // eligible: every wave gets its slices (<= 4), the chip is filled, and the matrix streams from the Infinity Cache
-    // (256 MiB): with one wave per SIMD the streamed part has little latency hiding, and a matrix that comes from
-    // HBM every iteration (124 k C3D10: 380 MB) runs at 99-103 us per iteration here against 93 with three launches
-    const int64_t kbytes = c->stored_rows * (int64_t)(c->dm * c->dm * 8 + 4) * 64;
-    if (maxrange > 4 * nwx || c->nslices < G || (kbytes > c->persist_max_bytes && c->opt_persist < 2)) return FEMCY_OK;
+    if (maxrange > 4 * nwx || c->nslices < G) return FEMCY_OK;    // every wave gets its slices (<= 4); the chip is filled
     const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
     const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
     lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
+    // ... and the part of the matrix that is STREAMED every iteration has to come from the Infinity Cache (256 MiB):
+    // with one wave per SIMD there is little latency hiding for HBM.  Measured: 1.4 M C3D4 elements (277 MB stored,
+    // 100 MB of it resident) 41.7 us per iteration here against 63.1 with three launches; 124 k C3D10 (380 MB stored,
+    // 280 MB streamed) 99-103 us here against 93.
+    const int rj = c->dm == 3 ? (SPW == 3 ? c->opt_persist_rj : (c->opt_persist_rj ? 3 : 0)) : (c->opt_persist_rj ? 5 : 0);
+    const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
+    const int64_t kbytes = c->stored_rows * row_bytes;
+    const int64_t resident = (int64_t)G * 4 * (SPW * rj + lds_rows) * row_bytes;   // upper bound (short slices hold less)
+    if (kbytes - resident > c->persist_max_bytes && c->opt_persist < 2) return FEMCY_OK;
     const size_t lds = (size_t)4 * lds_rows * 64 * (DD * 8 + 4) + 16;
     const int64_t need = 2 * npad + 2 * G + 4 * G + 160;          // + 8 x 32 + 32 barrier counters (4 bytes each)
     if (!c->d_persist || c->persist_cap < need) {

@@ -104,12 +104,12 @@ enum femcy_option {
     FEMCY_OPT_EXCHANGE = 8,     /* multi-rank interface exchange: 0 = all-reduce of the packed global interface vector
                                    (default), 1 = send/recv with the neighbouring ranks (needs
                                    femcy_comm_set_neighbours); femcy_comm_tune measures both and sets it */
-    FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (up to ~7e5 DOF
-                                   on MI355X) and whose matrix fits the Infinity Cache are solved by one persistent
-                                   launch -- vectors and part of the matrix in registers, another part in LDS, grid
-                                   barriers at the three synchronisation points of the recurrence; 2 = also when the
-                                   matrix is larger than the cache (slower than three launches; tests); 0 = three
-                                   launches per iteration */
+    FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (up to ~7.8e5
+                                   DOF on MI355X) and whose matrix, less the part the kernel keeps on chip, fits the
+                                   Infinity Cache are solved by one persistent launch -- vectors and part of the matrix
+                                   in registers, another part in LDS, grid barriers at the three synchronisation points
+                                   of the recurrence; 2 = also when the streamed part is larger than the cache (slower
+                                   than three launches; tests); 0 = three launches per iteration */
     FEMCY_OPT_PCG_SMALL = 10,   /* 1 (default): systems whose two work vectors fit the LDS of a workgroup (~1e4 DOF on
                                    MI355X) are solved by ONE persistent launch with one grid barrier per iteration
                                    instead of three launches per iteration; 0 = always the three-kernel loop */
