@@ -454,7 +454,9 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     const int nwx = (G / PNX) * 4;
     int32_t maxrange = 0;
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    if (maxrange > 4 * nwx || c->nslices < G) return FEMCY_OK;    // every wave gets its slices (<= 4); the chip is filled
+    // every wave gets its slices (<= 4), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
+    // synchronisation per iteration exceed the (graph-replayed) three-launch iteration (size sweep in DESIGN.md)
+    if (maxrange > 4 * nwx || c->nslices < G || (c->nslices < G + G / 2 && c->opt_persist < 2)) return FEMCY_OK;
     const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;

@@ -37,7 +37,7 @@ def plate(gpu_ctx_factory):
     from femcy_amd.element_zoo import Element_linear_tetrahedral
     m = meshgen.twist_plate(24, 6, 96)                    # 82 944 C3D4, 16 975 nodes = 266 slices, 50 925 DOF
     be, ctx, info, b = _system(gpu_ctx_factory, m, Element_linear_tetrahedral())
-    assert info.nslices >= 256
+    assert 256 <= info.nslices < 384      # fills the chip once: below the default threshold (1.5 x), so PERSIST = 2
     K = ctx.get_K_bsr().tocsr()
     return dict(be=be, ctx=ctx, K=K, b=b, bb=ctx.download(be.VEC_RESIDUAL))
 
@@ -51,12 +51,17 @@ def test_persistent_pcg_is_the_path_and_equals_the_three_kernel_loop(plate):
     be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
     res = {}
     for persist in (0, 1):
-        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        ctx.set_option(be.OPT_PCG_PERSIST, 2 * persist)
         before = _paths(ctx)
         res[persist] = [_solve(ctx, be, eps, maxit) for eps, maxit in ((0.0, 1), (0.0, 7), (0.0, 40), (1e-10, 10 ** 6))]
         after = _paths(ctx)
         # the path that ran: four solves, all three-kernel or all persistent, never the small-system kernel
         assert (after[0] - before[0], after[1] - before[1], after[2] - before[2]) == ((4, 0, 0), (0, 0, 4))[persist]
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)                  # default rule at this size: three launches
+    before = _paths(ctx)
+    _solve(ctx, be, 0.0, 3)
+    assert _paths(ctx)[0] - before[0] == 1
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
     for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(res[0][:3], res[1][:3]), (1e-13, 1e-12, 1e-10)):
         assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
         assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
@@ -81,7 +86,7 @@ def test_persistent_pcg_residency_variants_agree(plate, knobs):
     """where a block row lives (registers, LDS, streamed, prefetched during the barriers) changes the order of a row's
     partial products, not the recurrence: iterates agree to rounding, the converged solution solves the system"""
     be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
-    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
     (itr, _, rmr), xr = _solve(ctx, be, 0.0, 25)
     ctx.set_option(105, knobs["rj"])
     ctx.set_option(104, knobs["lds"])
@@ -101,7 +106,7 @@ def test_persistent_pcg_residency_variants_agree(plate, knobs):
 
 def test_persistent_pcg_edge_cases(plate):
     be, ctx, b = plate["be"], plate["ctx"], plate["b"]
-    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
     before = _paths(ctx)
     try:
         ctx.vector(be.VEC_RESIDUAL).fill(0.0)                           # b = 0: zero iterations, x = 0
@@ -134,7 +139,7 @@ def test_barrier_timeout_falls_back_to_the_three_kernel_loop(plate):
     be, ctx = plate["be"], plate["ctx"]
     ctx.set_option(be.OPT_PCG_PERSIST, 0)
     (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 12)
-    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
     ctx.set_option(107, 512)
     try:
         before = _paths(ctx)
