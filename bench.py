@@ -124,10 +124,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still create the torch.distributed (nccl) group and use its barrier / broadcast / all-reduce (exercises the N>1 host code on one GPU)")
-    ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="allreduce",
-                    help="N>1: interface exchange per CG iteration.  allreduce = the packed global interface vector "
-                         "(default: the form verified with a live RCCL communicator); neighbour = send/recv with the "
-                         "slab neighbours; auto = measure both at start-up (femcy_comm_tune) and keep the faster")
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="auto",
+                    help="N>1: interface exchange per CG iteration.  auto (default) = measure both forms at start-up "
+                         "(femcy_comm_tune: cross-checks their sums, takes the maximum time over the ranks) and keep "
+                         "the faster, falling back to the all-reduce if the measurement fails; allreduce = the packed "
+                         "global interface vector; neighbour = send/recv with the slab neighbours (overlapped with "
+                         "the product of the interior rows)")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
     args = ap.parse_args()
 
@@ -233,7 +235,19 @@ def main():
         if hasattr(ctx, "comm_set_neighbours"):
             ctx.comm_set_neighbours(part)
             if args.exchange == "auto":
-                exchange = ctx.comm_tune(20)
+                try:
+                    exchange = ctx.comm_tune(20)
+                    failed = 0
+                except be.FemcyError as e:                  # the send/recv form is the newer one: never let it take the
+                    log(f"[bench] rank {rank}: comm_tune failed ({e}); using the all-reduce exchange")     # run down
+                    failed = 1
+                if use_dist:                                # every rank must run the same exchange
+                    flag = torch.tensor([failed], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    failed = int(flag.item())
+                if failed:
+                    ctx.set_option(be.OPT_EXCHANGE, 0)
+                    exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None, "tune": "failed"}
             else:
                 ctx.set_option(be.OPT_EXCHANGE, 1 if args.exchange == "neighbour" else 0)
                 exchange["exchange"] = args.exchange
@@ -256,11 +270,6 @@ def main():
         ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
         return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
 
-    # untimed pre-warm on top of the W warmup steps: a fresh box needs ~1 s of load before the GPU sits at its
-    # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work), and an
-    # external utilisation sampler needs seconds, not the 0.5 s of the timed region, to see the device busy.  A step
-    # holds collectives, so the ranks must agree on the number of pre-warm steps: the stop test uses the MAX of the
-    # elapsed time over the ranks.
     def agreed_elapsed(t0):
         dt = time.perf_counter() - t0
         if use_dist:
@@ -269,6 +278,35 @@ def main():
             dt = float(box.item())
         return dt
 
+    # --exchange auto, second half: femcy_comm_tune compared the bare exchanges (and cross-checked their sums); what
+    # counts is the whole iteration -- the send/recv form splits the product and adds launches, the all-reduce form
+    # moves the whole interface vector through every rank -- so one untimed step is run with each, the maximum over the
+    # ranks is taken, and every rank keeps the faster form.
+    def timed_step_all_ranks():
+        barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        step()
+        ctx.sync()
+        return agreed_elapsed(t0)
+
+    if use_comm and args.exchange == "auto" and exchange is not None and exchange.get("tune") != "failed" \
+            and exchange.get("neighbour_us") is not None and exchange["neighbour_us"] >= 0:
+        trial = {}
+        for name, code in (("allreduce", 0), ("neighbour", 1)):
+            ctx.set_option(be.OPT_EXCHANGE, code)
+            step()                                           # connections, split lists, clocks
+            trial[name] = min(timed_step_all_ranks(), timed_step_all_ranks())
+        pick = "neighbour" if trial["neighbour"] < trial["allreduce"] else "allreduce"
+        ctx.set_option(be.OPT_EXCHANGE, 1 if pick == "neighbour" else 0)
+        exchange["exchange"] = pick
+        exchange["step_ms"] = {k: v * 1e3 for k, v in trial.items()}
+
+    # untimed pre-warm on top of the W warmup steps: a fresh box needs ~1 s of load before the GPU sits at its
+    # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work), and an
+    # external utilisation sampler needs seconds, not the 0.5 s of the timed region, to see the device busy.  A step
+    # holds collectives, so the ranks must agree on the number of pre-warm steps: the stop test uses the MAX of the
+    # elapsed time over the ranks.
     t_warm = time.perf_counter()
     while args.warmup > 0:
         step()
