@@ -173,6 +173,8 @@ struct Ctx {
     double* d_persist = nullptr;      // d double buffer, partials, barrier counters
     int64_t persist_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
+    int spmv_keep_permille = 0;       // NT SpMV: share of every XCD's slice range kept on the default cache policy
+    int opt_spmv_keep = -1;           // -1 auto (235 MB of the matrix), else per mille (tuning knob 110)
     int opt_small_rr = -1;            // test knob 108: block rows per wave of the small-system PCG kept in registers
     int opt_small = 1;                // FEMCY_OPT_PCG_SMALL
     int small_max_lds = 65536;        // LDS a workgroup may allocate (device attribute, femcy_ctx_create)

@@ -327,6 +327,14 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
             c->opt_persist_lds = (int)value;
             break;
+        case 110:   /* tuning: per-mille of every XCD's slice range that keeps the default cache policy in the NT SpMV */
+            FEMCY_REQUIRE(value >= -1 && value <= 1000, "per-mille out of range (-1 = auto)");
+            c->opt_spmv_keep = (int)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
+            break;
         case 108:   /* test knob: register-resident block rows per wave of the small-system PCG (-1 = a wave's share) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "register-resident rows out of range");
             c->opt_small_rr = (int)value;

@@ -24,6 +24,7 @@
 // dm doubles at a time.  Workgroups are remapped so that each XCD (private 4 MiB L2) walks one
 // contiguous range of slices and the x-gathers of neighbouring slices hit the same L2.
 #include <cmath>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "ctx.hpp"
 #include "wave_reduce.hpp"
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
                                              const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done,
-                                             const int32_t* __restrict__ slice_list) {
+                                             const int32_t* __restrict__ slice_list, int32_t keep_permille) {
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
@@ -122,27 +123,37 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
 #ifndef FEMCY_SPMV_UNROLL
 #define FEMCY_SPMV_UNROLL 2
 #endif
+            // NT (matrix beyond the Infinity Cache): the first keep_permille/1000 of every XCD's slice range is still
+            // loaded with the default policy, so that this part stays in the Infinity Cache from one product to the
+            // next while the rest streams past it without allocating
+            auto rows = [&](auto nt_tag) {
+                constexpr bool N = decltype(nt_tag)::value;
 #pragma unroll FEMCY_SPMV_UNROLL
-            for (int32_t j = j0; j < j1; ++j) {
-                const int64_t col = NT ? __builtin_nontemporal_load(&bc[(int64_t)j * SLICE]) : bc[(int64_t)j * SLICE];
-                double xv[DM];
+                for (int32_t j = j0; j < j1; ++j) {
+                    const int64_t col = N ? __builtin_nontemporal_load(&bc[(int64_t)j * SLICE]) : bc[(int64_t)j * SLICE];
+                    double xv[DM];
 #pragma unroll
-                for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
-                double e[DD];
+                    for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
+                    double e[DD];
 #pragma unroll
-                for (int kp = 0; kp < NP; ++kp) {
-                    typedef double nt_d2 __attribute__((ext_vector_type(2)));
-                    const nt_d2* tp = reinterpret_cast<const nt_d2*>(&vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE]);
-                    const nt_d2 t = NT ? __builtin_nontemporal_load(tp) : *tp;
-                    e[2 * kp] = t.x;
-                    e[2 * kp + 1] = t.y;
+                    for (int kp = 0; kp < NP; ++kp) {
+                        typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                        const nt_d2* tp = reinterpret_cast<const nt_d2*>(&vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE]);
+                        const nt_d2 t = N ? __builtin_nontemporal_load(tp) : *tp;
+                        e[2 * kp] = t.x;
+                        e[2 * kp + 1] = t.y;
+                    }
+                    if (DD & 1) e[DD - 1] = N ? __builtin_nontemporal_load(&vs[(int64_t)j * (DD * SLICE)]) : vs[(int64_t)j * (DD * SLICE)];
+#pragma unroll
+                    for (int r = 0; r < DM; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
                 }
-                if (DD & 1) e[DD - 1] = NT ? __builtin_nontemporal_load(&vs[(int64_t)j * (DD * SLICE)]) : vs[(int64_t)j * (DD * SLICE)];
-#pragma unroll
-                for (int r = 0; r < DM; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
-            }
+            };
+            if (NT && (int64_t)(spos - xr.start[k]) * 1000 >= (int64_t)keep_permille * (s_end - xr.start[k]))
+                rows(std::true_type{});
+            else
+                rows(std::false_type{});
         }
         if (WPS > 1) {
             __syncthreads();                         // previous task's readers are done with `red`
@@ -668,7 +679,8 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
     if (ev && c->opt_timing_fence) hipLaunchKernelGGL(k_fence_noop, dim3(1), dim3(64), 0, c->stream);
 #define SPMV_ARGS                                                                                              \
     c->nn, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,      \
-        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list
+        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list,              \
+        (int32_t)c->spmv_keep_permille
 #define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \

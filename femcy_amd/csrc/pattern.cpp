@@ -62,9 +62,20 @@ void spmv_split(Ctx* c) {
     const int64_t matrix_bytes = stored_rows * SLICE * ((int64_t)c->dm * c->dm * 8 + 4);
     const bool beyond_mall = matrix_bytes > (int64_t)256 * 1024 * 1024;
     c->spmv_nt = c->opt_spmv_nt < 0 ? beyond_mall : c->opt_spmv_nt != 0;
-    // the PCG vector kernels likewise: 44.7 -> 47.3 us per iteration at 1 M elements (vectors are re-read from the
-    // cache there), 332.8 -> 312.2 us at 8 M
-    c->vec_nt = c->opt_vec_nt < 0 ? beyond_mall : c->opt_vec_nt != 0;
+    // ... but not all of it: the leading share of every XCD's slice range (235 MB in total) keeps the default policy
+    // and is then found in the Infinity Cache by the next product, while the rest streams past it without allocating.
+    // Measured per PCG iteration: 124 k C3D10 (379 MB) 100.7 us all non-temporal, 88.3 / 85.9 us with 209 / 247 MB kept,
+    // 93.9 with 303 MB; 2 M C3D4 (400 MB) 90.9 -> 86.8 / 87.2 / 87.9 with 180 / 220 / 260 MB kept.
+    if (c->opt_spmv_keep >= 0)
+        c->spmv_keep_permille = c->opt_spmv_keep;
+    else
+        c->spmv_keep_permille = matrix_bytes > 0 ? (int)std::min<int64_t>(1000, (int64_t)235 * 1000 * 1000 * 1000 / matrix_bytes) : 0;
+    // the PCG vector kernels likewise, but by the size of the VECTORS: 44.7 -> 47.3 us per iteration at 1 M C3D4
+    // elements, 84.1 -> 85.1 on the 124 k C3D10 plate (380 MB of matrix, 4.4 MB per vector) and 85.3 -> 87.1 at 2 M
+    // C3D4 (8.7 MB per vector): small vectors are re-read from the caches; 176.5 -> 167.0 us at 4 M (17.4 MB per
+    // vector), 332.8 -> 312.2 at 8 M
+    const bool big_vectors = (int64_t)c->n * 8 > (int64_t)12 * 1000 * 1000;
+    c->vec_nt = c->opt_vec_nt < 0 ? (beyond_mall && big_vectors) : c->opt_vec_nt != 0;
     const int spb = WAVES / wps;   // slices per workgroup
     int32_t s = 0;
     c->xcd.start[0] = 0;

@@ -417,6 +417,11 @@ def test_pcg_matches_reference_recurrence(gpu_ctx_factory, name):
     ctx.set_option(103, 1)
     it_p, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
     assert it_p == it_g and np.array_equal(ctx.download(be.VEC_X), x_g)
+    for keep in (0, 400, 1000):             # ... nor does the share of the slice ranges that stays cacheable (knob 110)
+        ctx.set_option(110, keep)
+        it_p, _, _ = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
+        assert it_p == it_g and np.array_equal(ctx.download(be.VEC_X), x_g)
+    ctx.set_option(110, -1)
     ctx.set_option(102, -1)
     ctx.set_option(103, -1)
     # maxit honoured, poll interval irrelevant to the result
