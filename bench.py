@@ -13,6 +13,10 @@ of 995 328 elements each (weak scaling; N=1 is BASELINE's 1M mesh k=12, N=8 is i
 the interface exchange + two scalar reductions per CG iteration over RCCL; every rank generates only its
 own slab (femcy_amd.partition.plate_slab_part), never the global mesh.
 
+`python bench.py --gpus N` with N > 1 and no launcher environment starts its own N ranks (it re-executes itself
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); launched BY
+torch.distributed.run (WORLD_SIZE set) it is one rank of the job.  Rank 0 prints the one JSON line either way.
+
 `--workload c3d10` runs the same step on BASELINE configs[4] (C3D10 plate 48x6x72: 124 416 quadratic tets on
 the same 182 845 nodes) -- single GPU only; the default `c3d4` is the configuration the metric is quoted on.
 
@@ -20,9 +24,23 @@ the same 182 845 nodes) -- single GPU only; the default `c3d4` is the configurat
 global_elements/elements-per-GPU (= N) so that it is a whole-job aggregate; `cg_iters_per_s` (PCG only) and
 `assemblies_per_s` (elements/s, geometry + assembly kernels) come from HIP events on the ctx stream.
 
-Order of the run (so that an external GPU-utilisation sampler sees one contiguous busy stretch of >= 5 s at the
-end): mesh -> CPU baseline leg (rank 0, N = 1) -> device set-up -> pre-warm (`--prewarm` seconds of untimed
-steps) -> W warm-up steps -> K timed steps -> HBM copy probe -> one JSON line.
+The JSON line carries, besides the contract's keys:
+  roofline     the dominant kernel of the timed region against the ceiling that binds it.  On the headline workload
+               that kernel is k_pcg_persist, whose matrix stream comes from the Infinity Cache: `achieved` = the bytes
+               its layout makes it move per launch / launch time, `peak` = what a read-only sweep of the same footprint
+               reaches in the kernel's own launch shape on this GPU (femcy_probe_stream), `frac` <= 1; a time model
+               (stream + 3 grid-wide exchanges, both probed) says how much of an iteration is accounted for; the
+               ALGORITHMIC bytes / s of SURVEY.md 8d (which exceed the HBM peak because 47 % of the matrix and all
+               vectors never leave the chip) are kept in separately named fields.
+  hbm_bound    (N = 1, default workload) the same invocation then runs the two HBM-bound configurations --
+               BASELINE configs[3]'s 7 962 624-element plate on this one GPU and configs[4]'s C3D10 plate -- and
+               reports SpMV and PCG-iteration rates against 8 TB/s and against the copy probe of this GPU.
+  cpu_baseline the as-written C/OpenMP port of the reference on the host, in a child process pinned one thread per
+               physical core (OMP_PLACES=cores, OMP_PROC_BIND=spread; arrays first-touched by the threads that use them).
+
+Order of the run (so that an external GPU-utilisation sampler sees one contiguous busy stretch at the end):
+mesh -> CPU baseline leg (rank 0, N = 1) -> device set-up -> pre-warm (`--prewarm` seconds of untimed steps) ->
+W warm-up steps -> K timed steps -> ceiling probes -> HBM-bound records -> one JSON line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--iters ITERS] [--workload c3d4|c3d10] [--no-cpu-baseline]
 """
@@ -30,7 +48,11 @@ import argparse
 import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -106,12 +128,142 @@ def hbm_copy_probe(torch):
         return None
 
 
-def main():
-    # the contract is ONE JSON line on rank 0's stdout: libraries (RCCL prints a version banner on init) must not
-    # be able to add to it, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd
-    real_stdout = os.fdopen(os.dup(1), "w")
+class Watchdog:
+    """hard time-out around a phase that can hang on a broken node (RCCL communicator set-up, the exchange tuning):
+    the rank exits with code 3, torch.distributed.run then tears the job down, the self-launcher returns non-zero"""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def __enter__(self):
+        def fire():
+            log(f"[bench] rank {os.environ.get('RANK', '0')}: '{self.what}' did not finish within {self.seconds} s -- giving up")
+            os._exit(3)
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer:
+            self.timer.cancel()
+        return False
+
+
+def self_launch(n, argv, timeout):
+    """`python bench.py --gpus N` typed without a launcher: start N ranks of this script under torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port), pass rank 0's JSON line through, return the job's
+    exit code (non-zero if any rank failed or the job exceeded `timeout` seconds)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log(f"[bench] --gpus {n} without a launcher environment: starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL across processes on this driver)
+    env["FEMCY_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] the {n}-rank job did not finish within {timeout} s: killing it")
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)                 # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 4
+    lines = [l for l in out.splitlines() if l.strip().startswith("{")]
+    if proc.returncode == 0 and len(lines) != 1:
+        log(f"[bench] expected one JSON line from rank 0, got {len(lines)}")
+        return 5
+    for l in lines:
+        sys.stdout.write(l + "\n")
     sys.stdout.flush()
-    os.dup2(2, 1)
+    return proc.returncode
+
+
+def s1_state(nodes, bcs, user_dirichletBC_values):
+    """state S1: the prescribed values of the first increment (t = 0.05) written into dof, zero
+    elsewhere, and the sorted list of constrained DOFs"""
+    u = np.zeros(nodes.size)
+    cons = []
+    for bc in bcs:
+        ids = np.asarray(bc["node_set"], dtype=np.int64)
+        cons.append(ids * 3 + bc["dof"])
+        if bc["user"] and ids.size:
+            user_dirichletBC_values(u, ids, 3, bc["dof"], nodes, 0.05)
+    return u, np.unique(np.concatenate(cons)).astype(np.int32)
+
+
+def algorithmic_bytes(info, nn, n):
+    """SURVEY.md 8d, padding never counted: one SpMV = 8 nnz + 4 nnz/dm^2 + 4 (nn + 1) + 16 n; one PCG iteration = the
+    SpMV + 88 n (the fused vector updates of the reference recurrence)"""
+    spmv = 8 * info.nnz + 4 * info.nnzb + 4 * (nn + 1) + 16 * n
+    return spmv, spmv + 88 * n
+
+
+def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iters=100, spmv_reps=40):
+    """one HBM-bound configuration on this GPU: SpMV (dispatch-attached HIP events on every launch) and the PCG
+    iteration (whole solves of `iters` iterations, every 16th SpMV sampled) with their algorithmic-byte rates"""
+    t0 = time.time()
+    ctx = be.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        nodes, el = mesh["nodes"], mesh["elements"]
+        ctx.set_mesh(nodes, el)
+        ctx.set_element(element)
+        ctx.set_material(material)
+        info = ctx.build_pattern()
+        u, cons = s1_state(nodes, mesh["dirichlet_bc_info"], user_values)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.vector(be.VEC_RHS).fill(0.0)
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+        cs = ctx.dofset(cons)
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.dofset_dirichlet_newton(cs, be.VEC_RESIDUAL)
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)          # warm: clocks, caches, lazy allocations
+        spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
+        ctx.set_option(be.OPT_TIMING, 1)
+        ctx.timing_reset()
+        for _ in range(spmv_reps):
+            ctx.spmv(be.VEC_RESIDUAL, be.VEC_TMP0)
+        tm = ctx.timing()
+        spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
+        ctx.set_option(be.OPT_TIMING, 16)
+        ctx.timing_reset()
+        its = 0
+        for _ in range(3):
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.dofset_dirichlet_newton(cs, be.VEC_RESIDUAL)
+            its += ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)[0]
+        tm = ctx.timing()
+        ctx.set_option(be.OPT_TIMING, 0)
+        iter_us = tm["pcg_ms"] * 1e3 / max(its, 1)
+        asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
+        path = ("persistent" if tm["solves_persist"] else "three-kernel")
+        spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
+        iter_gbs = iter_b / (iter_us * 1e-6) / 1e9
+        rec = {"workload": name, "elements": int(ctx.ne), "dof": int(ctx.n), "stored_matrix_mb": info.stored_blocks * 76 / 1e6,
+               "pcg_path": path,
+               "spmv": {"kernel": f"k_spmv<{ctx.dm}>", "bound": "hbm", "avg_launch_us": spmv_us,
+                        "launches_timed": int(spmv_reps), "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                        "frac_of_copy_probe": (spmv_gbs / probe) if probe else None},
+               "pcg_iteration": {"us": iter_us, "iterations_timed": int(its), "bytes": int(iter_b), "achieved": iter_gbs,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbs / HBM_PEAK_GBS,
+                                 "frac_of_copy_probe": (iter_gbs / probe) if probe else None},
+               "assembly_ms": asm_ms, "assemblies_per_s": ctx.ne / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
+               "wall_s": time.time() - t0}
+        return rec
+    finally:
+        ctx.close()
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -122,6 +274,11 @@ def main():
     ap.add_argument("--sample", type=int, default=16, help="time every k-th SpMV launch with HIP events (1 = all)")
     ap.add_argument("--prewarm", type=float, default=4.0, help="seconds of untimed steps before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("tuned", "both"), default="tuned",
+                    help="tuned = one pinned thread per physical core (default); both = also the unpinned all-threads run")
+    ap.add_argument("--hbm-bound", choices=("auto", "off"), default="auto",
+                    help="auto: an N = 1 run of the default workload also measures the HBM-bound configurations "
+                         "(8 M C3D4 on this GPU, 124 k C3D10) and reports them under `hbm_bound`")
     ap.add_argument("--force-comm", action="store_true", help="N=1: still run the RCCL exchange path (1-rank communicator)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still create the torch.distributed (nccl) group and use its barrier / broadcast / all-reduce (exercises the N>1 host code on one GPU)")
     ap.add_argument("--exchange", choices=("auto", "allreduce", "neighbour"), default="auto",
@@ -131,7 +288,24 @@ def main():
                          "global interface vector; neighbour = send/recv with the slab neighbours (overlapped with "
                          "the product of the interior rows)")
     ap.add_argument("--cells", type=str, default=None, help="override nx,ny,nz (debug / small runs)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched N > 1 job: kill after this many seconds")
+    ap.add_argument("--comm-timeout", type=float, default=300.0, help="seconds allowed for communicator set-up / tuning")
+    ap.add_argument("--cpu-leg", type=str, default=None, help=argparse.SUPPRESS)   # internal: the pinned child process
     args = ap.parse_args()
+
+    if args.cpu_leg:                                            # child of cpu_baseline_subprocess(): host work only
+        return cpu_leg_main(args.cpu_leg)
+
+    world_env = os.environ.get("WORLD_SIZE")
+    N = args.gpus
+    if world_env is None and N > 1:                             # typed as documented, without a launcher: start the ranks
+        sys.exit(self_launch(N, sys.argv[1:], args.launch_timeout))
+
+    # the contract is ONE JSON line on rank 0's stdout: libraries (RCCL prints a version banner on init) must not
+    # be able to add to it, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved fd
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -140,14 +314,10 @@ def main():
     from femcy_amd.material_zoo import LinearIsotropic
     from femcy_amd.user_defined import user_dirichletBC_values
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    N = args.gpus
     if world != N:
-        if world == 1 and N > 1:
-            raise SystemExit(f"--gpus {N} needs {N} ranks: launch with python -m torch.distributed.run "
-                             f"--nnodes=1 --nproc-per-node {N} --master-addr 127.0.0.1 bench.py --gpus {N}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {N}")
     quadratic = args.workload == "c3d10"
     if quadratic and (N > 1 or args.force_comm):
@@ -155,17 +325,22 @@ def main():
     # test hooks (tests/test_bench_multirank_cpu.py runs the N>1 host logic on CPU with gloo and a mock Context):
     dist_backend = os.environ.get("FEMCY_BENCH_DIST_BACKEND", "nccl")
     on_gpu = os.environ.get("FEMCY_BENCH_DEVICE", "cuda") == "cuda"
+    if os.environ.get("FEMCY_BENCH_MOCK"):                      # "module:Class" standing in for backend.Context (CPU tests)
+        import importlib
+        mod, cls = os.environ["FEMCY_BENCH_MOCK"].split(":")
+        be.Context = getattr(importlib.import_module(mod), cls)
     if on_gpu:
         torch.cuda.set_device(local_rank)
     use_dist = N > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if on_gpu:
-            dist.init_process_group(dist_backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(dist_backend, rank=rank, world_size=world)
+        with Watchdog(args.comm_timeout, "torch.distributed process group"):
+            if on_gpu:
+                dist.init_process_group(dist_backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     def barrier():
         if use_dist:
@@ -196,22 +371,14 @@ def main():
                                    renumber=quadratic and os.environ.get("FEMCY_BENCH_RENUM", "0") == "1")
         nodes, el, bcs, elastic = mesh["nodes"], mesh["elements"], mesh["dirichlet_bc_info"], mesh["elastic"]
         ne_global, n_global = el.shape[0], nodes.size
-    # state S1: prescribed values of the first increment (t = 0.05) written into dof, zero elsewhere
-    u = np.zeros(nodes.size)
-    cons = []
-    for bc in bcs:
-        ids = np.asarray(bc["node_set"], dtype=np.int64)
-        cons.append(ids * 3 + bc["dof"])
-        if bc["user"] and ids.size:
-            user_dirichletBC_values(u, ids, 3, bc["dof"], nodes, 0.05)
-    cons = np.unique(np.concatenate(cons)).astype(np.int32)
+    u, cons = s1_state(nodes, bcs, user_dirichletBC_values)
 
     # ------------------------------------------------------------------ CPU baseline leg (rank 0, N = 1 only), FIRST:
-    # it is host work (10-20 s); running it before the device leg keeps the GPU-busy part of the command contiguous
+    # it is host work (20-40 s); running it before the device leg keeps the GPU-busy part of the command contiguous
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(nodes, el, elastic, u, cons, "C3D10" if quadratic else "C3D4")
+            cpu = cpu_baseline_subprocess(nx, ny, nz, "C3D10" if quadratic else "C3D4", args.cpu_baseline == "both")
         except Exception as e:   # the checker must never take the GPU number down with it
             log(f"[bench] cpu_baseline failed: {e!r}")
 
@@ -220,6 +387,8 @@ def main():
         ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
     if os.environ.get("FEMCY_BENCH_PERSIST"):               # 0 = the three-kernel PCG loop (comparison records)
         ctx.set_option(be.OPT_PCG_PERSIST, int(os.environ["FEMCY_BENCH_PERSIST"]))
+    if os.environ.get("FEMCY_BENCH_VARIANT"):               # persistent PCG variant bits (comparison records)
+        ctx.set_option(be.TUNE_PERSIST_VARIANT, int(os.environ["FEMCY_BENCH_VARIANT"]))
     ctx.set_mesh(nodes, el)
     ctx.set_element(Element_quadratic_tetrahedral() if quadratic else Element_linear_tetrahedral())
     ctx.set_material(LinearIsotropic(*elastic))
@@ -228,7 +397,8 @@ def main():
         uid = [be.Context.comm_unique_id() if rank == 0 else None]
         if use_dist:
             dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
+        with Watchdog(args.comm_timeout, "femcy_comm_init (RCCL communicator)"):
+            ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
         # interface exchange: measure the packed all-reduce against send/recv with the slab neighbours and keep the
         # faster one (all ranks decide alike from the maximum over the ranks); --exchange pins it
         exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None}
@@ -236,7 +406,8 @@ def main():
             ctx.comm_set_neighbours(part)
             if args.exchange == "auto":
                 try:
-                    exchange = ctx.comm_tune(20)
+                    with Watchdog(args.comm_timeout, "femcy_comm_tune"):
+                        exchange = ctx.comm_tune(20)
                     failed = 0
                 except be.FemcyError as e:                  # the send/recv form is the newer one: never let it take the
                     log(f"[bench] rank {rank}: comm_tune failed ({e}); using the all-reduce exchange")     # run down
@@ -293,10 +464,11 @@ def main():
     if use_comm and args.exchange == "auto" and exchange is not None and exchange.get("tune") != "failed" \
             and exchange.get("neighbour_us") is not None and exchange["neighbour_us"] >= 0:
         trial = {}
-        for name, code in (("allreduce", 0), ("neighbour", 1)):
-            ctx.set_option(be.OPT_EXCHANGE, code)
-            step()                                           # connections, split lists, clocks
-            trial[name] = min(timed_step_all_ranks(), timed_step_all_ranks())
+        with Watchdog(2 * args.comm_timeout, "exchange trial steps"):
+            for name, code in (("allreduce", 0), ("neighbour", 1)):
+                ctx.set_option(be.OPT_EXCHANGE, code)
+                step()                                           # connections, split lists, clocks
+                trial[name] = min(timed_step_all_ranks(), timed_step_all_ranks())
         pick = "neighbour" if trial["neighbour"] < trial["allreduce"] else "allreduce"
         ctx.set_option(be.OPT_EXCHANGE, 1 if pick == "neighbour" else 0)
         exchange["exchange"] = pick
@@ -343,28 +515,31 @@ def main():
     probe = hbm_copy_probe(torch) if (on_gpu and rank == 0) else None
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    # algorithmic bytes (BASELINE.md / SURVEY.md 8d), padding never counted:
-    #   one SpMV          8*nnz + 4*nnz/dm^2 + 4*(nn+1) + 16*n
-    #   one PCG iteration the SpMV + 88*n (the fused vector updates of the reference recurrence)
-    spmv_bytes = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * n
-    iter_bytes = spmv_bytes + 88 * n
+    spmv_bytes, iter_bytes = algorithmic_bytes(info, ctx.nn, n)
     spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
     persist = tm["persist_launches"] > 0 and tm["spmv_launches"] == 0
+    cg_only = total_iters / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0
+    iter_gbs = iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9 if tm["pcg_ms"] > 0 else 0.0
     if persist:
-        # the whole solve is ONE launch of k_pcg_persist (no SpMV launches exist): the unit of one launch is the
-        # iterations it ran; its duration comes from HIP events around the launch on the ctx stream
+        roof = persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank)
         kernel = "k_pcg_persist"
-        kernel_label = f"k_pcg_persist<{ctx.dm}> (one launch = {args.iters} PCG iterations: compute_Ad + the vector updates)"
-        launch_us = tm["persist_ms"] * 1e3 / tm["persist_launches"]
-        launch_bytes = iter_bytes * tm["persist_iters"] / tm["persist_launches"]
-        launches = int(tm["persist_launches"])
     else:
         kernel = "k_spmv"
-        kernel_label = f"k_spmv<{ctx.dm}> (compute_Ad)"
-        launch_us, launch_bytes, launches = spmv_us, spmv_bytes, int(tm["spmv_launches"])
-    achieved = launch_bytes / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+        achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9 if spmv_us > 0 else 0.0
+        roof = {"kernel": f"k_spmv<{ctx.dm}> (compute_Ad)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "peak_source": "spec (MI355X_MICROARCH.md)",
+                "frac_of_copy_probe": (achieved / probe) if probe else None,
+                "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us, "launches_timed": int(tm["spmv_launches"])}
     traffic, traffic_src = pmc_traffic(args.workload, kernel) if not args.cells else (None, "non-standard --cells")
-    cg_only = total_iters / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0
+    roof["traffic"], roof["traffic_source"] = traffic, traffic_src
+    roof["copy_probe_gbs"] = probe
+    roof["pcg_iteration_gbs"] = iter_gbs
+    roof["pcg_iteration_frac_of_hbm_peak"] = iter_gbs / HBM_PEAK_GBS
+    if traffic is not None and roof.get("avg_launch_us", 0) > 0:
+        # the rate of the bytes that actually moved between the L2s and the fabric (HBM + Infinity Cache): PMC counters
+        roof["traffic_gbs"] = traffic / (roof["avg_launch_us"] * 1e-6) / 1e9
+        roof["traffic_over_moved"] = traffic / roof["bytes_per_launch"] if roof.get("bytes_per_launch") else None
+
     asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
     per_gpu = ELEMS_PER_GPU[args.workload]
     scale = ne_global / per_gpu
@@ -385,6 +560,8 @@ def main():
                                f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
                    "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters,
                    "parallelism": f"element z-slabs x{N}, slab-local mesh generation" if N > 1 else "single GPU",
+                   "launcher": "self-launched torch.distributed.run" if os.environ.get("FEMCY_BENCH_SELF_LAUNCHED") else
+                               ("torch.distributed.run" if world_env is not None else "single process"),
                    "interface_exchange": exchange},
         "cg_iters_per_s": cg_only * scale,
         "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
@@ -394,41 +571,152 @@ def main():
         "spmv_tflops": (2 * info.nnz / (spmv_us * 1e-6) / 1e12 if spmv_us > 0 else
                         (2 * info.nnz * total_iters / (tm["pcg_ms"] * 1e-3) / 1e12 if tm["pcg_ms"] > 0 else 0.0)),
         "assembly_tflops": kflop_per_elem * 1e3 * ne_global / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
-        "roofline": {"kernel": kernel_label, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "peak_source": "spec (MI355X_MICROARCH.md)", "copy_probe_gbs": probe,
-                     "bytes_per_launch": int(launch_bytes), "avg_launch_us": launch_us,
-                     "launches_timed": launches,
-                     "pcg_iteration_gbs": iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9
-                     if tm["pcg_ms"] > 0 else 0.0,
-                     "pcg_iteration_frac": iter_bytes * total_iters / (tm["pcg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                     if tm["pcg_ms"] > 0 else 0.0},
+        "roofline": roof,
     }
-    if traffic is not None and launch_us > 0:
-        # the rate of the bytes that actually moved between the L2s and the fabric (HBM + Infinity Cache), for comparison
-        # with `achieved` (algorithmic bytes): the two differ by what the kernel kept on chip, or re-read
-        result["roofline"]["traffic_gbs"] = traffic / (launch_us * 1e-6) / 1e9
-        result["roofline"]["traffic_over_algorithmic"] = traffic / launch_bytes if launch_bytes else None
-    if persist:
-        # what the persistent kernel keeps on chip: `achieved` counts ALGORITHMIC bytes, of which the register- and
-        # LDS-resident block rows and the vectors never travel after the first iteration
-        result["roofline"]["note"] = ("algorithmic bytes / launch time; the kernel holds the vectors and part of the "
-                                      "matrix in registers / LDS for the whole solve, so the bytes that actually move "
-                                      "per iteration are fewer (see `traffic`) and the figure may exceed the HBM peak")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu
+    ctx.close()
+
+    # ------------------------------------------------------------------ the HBM-bound configurations, same invocation
+    if rank == 0 and N == 1 and on_gpu and args.hbm_bound == "auto" and not args.cells and not quadratic \
+            and not args.force_comm and not args.force_dist:
+        recs = []
+        for name, gen, ele in (
+                ("twist plate C3D4 192x24x288 cells (BASELINE configs[3]'s 7 962 624 elements on ONE GPU)",
+                 lambda: meshgen.twist_plate(192, 24, 288), Element_linear_tetrahedral()),
+                ("twist plate C3D10 48x6x72 cells (BASELINE configs[4], 124 416 elements)",
+                 lambda: meshgen.twist_plate(48, 6, 72, quadratic=True), Element_quadratic_tetrahedral())):
+            try:
+                msh = gen()
+                recs.append(hbm_bound_record(be, name, msh, ele, LinearIsotropic(*msh["elastic"]),
+                                             user_dirichletBC_values, probe))
+                del msh
+            except Exception as e:                               # noqa: BLE001  (never lose the headline line)
+                log(f"[bench] hbm_bound record '{name[:40]}' failed: {e!r}")
+                recs.append({"workload": name, "error": repr(e)})
+        result["hbm_bound"] = recs
+
     if rank == 0:
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()
-    ctx.close()
     if use_dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(nodes, el, elastic, u, cons, etype):
+def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):
+    """k_pcg_persist against the ceiling that binds it.  The kernel keeps the vectors and the register / LDS-resident
+    block rows on chip for the whole solve; per iteration its layout makes it move
+        the streamed block rows (femcy_persist_streamed_bytes: stored - resident, values + block columns)
+      + 8 n bytes of d published + 8 n bytes of d read at least once by the gathers
+    from / to the Infinity Cache (the matrix of this configuration lives there).  `peak` is what a read-only sweep of a
+    buffer of the streamed size reaches in the kernel's own launch shape on this GPU, `achieved / peak` <= 1 is the
+    roofline fraction.  The time model adds the price of the three grid-wide exchanges of an iteration, probed with the
+    kernel's own exchange code: floor = streamed / peak + 3 x exchange."""
+    launches = int(tm["persist_launches"])
+    launch_us = tm["persist_ms"] * 1e3 / launches
+    iters_per_launch = tm["persist_iters"] / launches
+    streamed = ctx.persist_streamed_bytes() if hasattr(ctx, "persist_streamed_bytes") else 0
+    moved_iter = streamed + 16 * n
+    moved_launch = moved_iter * iters_per_launch
+    achieved = moved_launch / (launch_us * 1e-6) / 1e9
+    alg_launch = iter_bytes * iters_per_launch
+    alg_gbs = alg_launch / (launch_us * 1e-6) / 1e9
+    peak = exch = None
+    variant = int(os.environ.get("FEMCY_BENCH_VARIANT", "-1"))
+    if hasattr(ctx, "probe_stream") and streamed > 0:
+        try:
+            peak = max(ctx.probe_stream(max(streamed, 1 << 20), 30, 0)[0] for _ in range(3))
+            form = 1 if (variant >= 0 and (variant & 2)) else int(os.environ.get("FEMCY_BENCH_EXCHANGE_FORM", "0"))
+            exch = min(ctx.probe_exchange(2000, form) for _ in range(3))
+        except be.FemcyError as e:
+            log(f"[bench] ceiling probes failed: {e}")
+    us_iter = launch_us / iters_per_launch
+    roof = {"kernel": f"k_pcg_persist<{ctx.dm}> (one launch = {args.iters} PCG iterations: compute_Ad + the vector updates "
+                      f"+ 3 grid-wide exchanges per iteration)",
+            "bound": "infinity-cache", "unit": "GB/s",
+            "achieved": achieved, "peak": peak, "frac": (achieved / peak) if peak else None,
+            "peak_source": "femcy_probe_stream: read-only sweep of the streamed footprint in the kernel's launch shape "
+                           "(256 workgroups x 4 waves, 16-byte loads), this GPU, this run",
+            "bytes_per_launch": int(moved_launch), "bytes_per_iteration": int(moved_iter),
+            "streamed_matrix_bytes_per_iteration": int(streamed),
+            "avg_launch_us": launch_us, "launches_timed": launches, "us_per_iteration": us_iter,
+            # SURVEY.md 8d's storage-independent figure (what BASELINE's metric prices): above the HBM peak because the
+            # bytes the kernel keeps on chip are counted
+            "algorithmic_bytes_per_launch": int(alg_launch), "algorithmic_gbs": alg_gbs,
+            "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS, "hbm_peak": HBM_PEAK_GBS}
+    if peak and exch:
+        stream_us = streamed / (peak * 1e9) * 1e6
+        floor = stream_us + 3 * exch
+        roof["time_model"] = {"stream_us": stream_us, "exchange_us": exch, "exchanges_per_iteration": 3,
+                              "floor_us_per_iteration": floor, "measured_us_per_iteration": us_iter,
+                              "frac": floor / us_iter,
+                              "not_in_the_floor": "gathers of d, resident-row multiplies, wave / workgroup reductions, vector updates"}
+    return roof
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def physical_cores():
+    """(cpu ids, one per physical core) among the CPUs this process may run on"""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, pick = set(), []
+    for cpu in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            key = (open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip())
+        except OSError:
+            key = ("?", str(cpu))
+        if key not in seen:
+            seen.add(key)
+            pick.append(cpu)
+    return pick
+
+
+def cpu_baseline_subprocess(nx, ny, nz, etype, both):
+    """runs cpu_leg_main in child processes whose OpenMP runtime is configured BEFORE it starts: one thread per
+    physical core, bound (OMP_PLACES=cores, OMP_PROC_BIND=spread); the ELL arrays and CG vectors are first touched
+    inside the same static parallel loops that later use them (oracle/femcy_oracle.c), so pages sit on the NUMA node of
+    their thread.  `both`: also the round-2 configuration (all hardware threads, unbound) for comparison."""
+    cores = physical_cores()
+
+    def run(env_extra, label):
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{nx},{ny},{nz},{etype}"],
+                             capture_output=True, text=True, env=env, timeout=1200)
+        if out.returncode != 0:
+            raise RuntimeError(f"cpu leg ({label}) failed: {out.stderr[-800:]}")
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        rec["omp"] = {k: env_extra.get(k) for k in ("OMP_NUM_THREADS", "OMP_PLACES", "OMP_PROC_BIND")}
+        return rec
+
+    tuned = run({"OMP_NUM_THREADS": str(len(cores)), "OMP_PLACES": "cores", "OMP_PROC_BIND": "spread"}, "pinned")
+    tuned["physical_cores"] = len(cores)
+    if both:
+        try:
+            un = run({"OMP_NUM_THREADS": str(os.cpu_count() or 1)}, "unpinned")
+            tuned["unpinned_all_threads"] = {k: un[k] for k in ("value", "cores", "gbs", "assemblies_per_s", "sample")}
+        except Exception as e:                                   # noqa: BLE001
+            tuned["unpinned_all_threads"] = {"error": repr(e)}
+    return tuned
+
+
+def cpu_leg_main(spec):
     """oracle/femcy_oracle.c (the reference's algorithm as written: ELL n x W, per-entry linear search +
-    atomic adds, thread-per-row SpMV, 8 vector passes + 4 reductions per CG iteration) with OpenMP on all
-    host cores, on a bounded sample of the same workload: 1 assembly + ~10 s of CG iterations."""
+    atomic adds, thread-per-row SpMV, 8 vector passes + 4 reductions per CG iteration) with OpenMP, on a bounded sample
+    of the same workload: 1 assembly + ~10 s of CG iterations.  Prints one JSON object."""
+    nx, ny, nz, etype = spec.split(",")
+    nx, ny, nz = int(nx), int(ny), int(nz)
+    from femcy_amd import meshgen
+    from femcy_amd.user_defined import user_dirichletBC_values
+    mesh = meshgen.twist_plate(nx, ny, nz, quadratic=(etype == "C3D10"))
+    u, cons = s1_state(mesh["nodes"], mesh["dirichlet_bc_info"], user_dirichletBC_values)
+    rec = cpu_baseline(mesh["nodes"], mesh["elements"], mesh["elastic"], u, cons, etype)
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def cpu_baseline(nodes, el, elastic, u, cons, etype):
     from oracle.c_oracle import COracle
     from oracle.elements import elem_def
     from oracle.femcy_oracle import Material
@@ -437,7 +725,7 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
     co = COracle(nodes, el, ed.dN_table(), ed.gauss_weights, Material("lin3d", elastic).C)
     setup = time.time() - t0
     co.get_dsdx_and_vol(u)
-    co.assemble()                                    # warm (page faults of the ELL array)
+    co.assemble()                                    # warm (page faults of the ELL array: first touch, in parallel)
     t = time.perf_counter()
     co.get_dsdx_and_vol(u)
     co.assemble()
@@ -449,10 +737,13 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
     t = time.perf_counter()
     co.cg(f, eps=0.0, maxit=10)
     per_it = (time.perf_counter() - t) / 10
-    its = int(max(20, min(2000, 10.0 / per_it)))
+    its = int(max(20, min(20000, 10.0 / per_it)))
     t = time.perf_counter()
     _, it, _, _ = co.cg(f, eps=0.0, maxit=its)
     dt = time.perf_counter() - t
+    # as-written bytes of one CG iteration: the ELL arrays (8 + 4 bytes per slot, padding included: the port reads
+    # them) + 17 vector passes of 8 n bytes (SpMV + 136 n)
+    bytes_it = co.n * co.W * 12 + 4 * co.n + 16 * co.n + 136 * co.n
     # second, implementation-independent anchor: single-thread scipy CSR A @ x
     Kcsr = co.to_csr()
     xs = np.random.default_rng(0).standard_normal(co.n)
@@ -470,6 +761,7 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
     except OSError:
         pass
     return {"value": it / dt, "unit": "CG iters/s", "cores": co.threads(), "kind": "port",
+            "gbs": bytes_it * it / dt / 1e9,
             "assemblies_per_s": co.ne / t_asm, "assembly_ms": t_asm * 1e3,
             "cpu_model": cpu_model, "host_threads_available": os.cpu_count(),
             "scipy_csr_spmv_per_s_1thread": 1.0 / t_scipy,

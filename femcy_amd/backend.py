@@ -30,6 +30,9 @@ OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent 
 OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neighbour send/recv
 OPT_PCG_PERSIST = 11     # 1 (default) = persistent one-launch PCG (single rank, <= ~7e5 DOF, matrix <= Infinity Cache); 2 = any matrix size
 OPT_PCG_SMALL = 10       # 1 (default) = one persistent launch per solve for systems that fit LDS
+TUNE_PERSIST_VARIANT = 109   # persistent PCG variant bits (-1 default; femcy.h)
+TUNE_SKIP_OCCUPANCY_CHECK = 111
+TUNE_BARRIER_SPIN_LIMIT = 112
 OPT_OVERLAP = 9          # multi-rank, neighbour exchange: 1 (default) = exchange overlapped with the interior product
 ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2 = 0, 1, 2, 3, 4, 5, 6
 
@@ -44,6 +47,7 @@ EXPORTS = [
     "femcy_get_K_ell", "femcy_get_K_bsr", "femcy_get_gp_field", "femcy_timing",
     "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_comm_info", "femcy_comm_set_neighbours",
     "femcy_comm_tune", "femcy_iface_sum",
+    "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
 ]
 
 
@@ -71,7 +75,8 @@ class Timing(C.Structure):
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64),
                 ("pcg_ms", C.c_double), ("pcg_iters", C.c_int64),
                 ("persist_ms", C.c_double), ("persist_launches", C.c_int64), ("persist_iters", C.c_int64),
-                ("solves_three", C.c_int64), ("solves_small", C.c_int64), ("solves_persist", C.c_int64)]
+                ("solves_three", C.c_int64), ("solves_small", C.c_int64), ("solves_persist", C.c_int64),
+                ("barrier_timeouts", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -120,6 +125,9 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_comm_unique_id": [p], "femcy_comm_local_id": [p], "femcy_comm_info": [p, p, p, p],
         "femcy_comm_set_neighbours": [p, i32, p, p, p], "femcy_comm_tune": [p, i32, C.POINTER(i32), p], "femcy_comm_init": [p, i32, i32, p, i32, p, p, i32, p],
         "femcy_iface_sum": [p, cint],
+        "femcy_probe_stream": [p, i64, i32, i32, C.POINTER(f64), C.POINTER(i64)],
+        "femcy_probe_exchange": [p, i32, i32, C.POINTER(f64)],
+        "femcy_persist_streamed_bytes": [p, C.POINTER(i64)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -393,6 +401,23 @@ class Context:
         tail = {GP_DSDX: (self.npe, self.dm), GP_VOL: (), GP_F: mat, GP_SIGMA: mat, GP_STRAIN: mat, GP_MISES: (),
                 GP_ENERGY: ()}[which]
         return GaussField(self, which, tail)
+
+    def probe_stream(self, nbytes: int, reps: int = 20, mode: int = 0):
+        """(GB/s, bytes per pass) of a read-only sweep in the persistent PCG's launch shape (femcy.h)"""
+        us, moved = C.c_double(), C.c_int64()
+        self._call("femcy_probe_stream", int(nbytes), int(reps), int(mode), C.byref(us), C.byref(moved))
+        return moved.value / (us.value * 1e-6) / 1e9, moved.value
+
+    def probe_exchange(self, rounds: int = 2000, form: int = 0) -> float:
+        """microseconds per grid-wide exchange of one value per workgroup (femcy.h)"""
+        us = C.c_double()
+        self._call("femcy_probe_exchange", int(rounds), int(form), C.byref(us))
+        return us.value
+
+    def persist_streamed_bytes(self) -> int:
+        out = C.c_int64()
+        self._call("femcy_persist_streamed_bytes", C.byref(out))
+        return out.value
 
     def timing(self) -> dict:
         t = Timing()

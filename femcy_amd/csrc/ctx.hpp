@@ -163,15 +163,23 @@ struct Ctx {
     int opt_persist_rj = 4;           // block rows per slice kept in registers (test knob 105)
     int opt_persist_wgs = 0;          // test knob 107: workgroups of the launch (0 = one per CU; more than that cannot
                                       // be co-resident, the barrier times out and the solve falls back)
+    int opt_persist_variant = -1;     // FEMCY_TUNE_PERSIST_VARIANT bits (-1 = defaults)
     int opt_persist_dbg = 0;          // timing experiments only (test knob 106): skip parts of the iteration
     int opt_persist_lds = -1;         // block rows per wave kept in LDS (-1: as many as fit; test knob 104)
     int persist_cus = 0;              // compute units of the device
     bool persist_failed = false;      // a grid barrier timed out once: do not try again on this context
+    bool small_failed = false;        // the same for k_pcg_small
+    int opt_skip_occupancy = 0;       // FEMCY_TUNE_SKIP_OCCUPANCY_CHECK
+    uint32_t barrier_spin_limit = 1u << 20;   // polls (s_sleep 1 each, ~0.3 us) before a grid barrier gives up: ~0.5 s
     int32_t* d_persist_assign = nullptr;   // [waves][SPW] slices of each wave (LPT-balanced per XCD range), -1 = none
     std::vector<int64_t> persist_assign_key;
     int64_t pattern_serial = 0;       // bumped by femcy_build_pattern
-    double* d_persist = nullptr;      // d double buffer, partials, barrier counters
+    double* d_persist = nullptr;      // d double buffer, partials, granules, barrier counters
     int64_t persist_cap = 0;
+    int32_t* d_bcolp = nullptr;       // block columns as storage positions (persistent PCG with d in storage order)
+    int64_t bcolp_serial = -1;
+    char* d_probe = nullptr;          // femcy_probe_stream's buffer
+    int64_t probe_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
     int spmv_keep_permille = 0;       // NT SpMV: share of every XCD's slice range kept on the default cache policy
     int opt_spmv_keep = -1;           // -1 auto (235 MB of the matrix), else per mille (tuning knob 110)
@@ -271,6 +279,10 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 // d_partials[part_off ...]); split_prepare builds the slice list once per pattern + communicator
 int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d_partials, int part_off, int* nblocks_out);
 int split_prepare(Ctx* c);
+bool coresident(Ctx* c, const void* fn, int block, size_t lds, int grid);
+int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass, int64_t* bytes_per_pass);
+int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange);
+int64_t persist_streamed_bytes(Ctx* c);
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,

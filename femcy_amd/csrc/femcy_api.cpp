@@ -257,6 +257,8 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_small);
     dev_free(&c->d_persist);
     dev_free(&c->d_persist_assign);
+    dev_free(&c->d_bcolp);
+    dev_free(&c->d_probe);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
     if (c->comm_stream) {
@@ -305,7 +307,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             pcg_graph_reset(c);
             c->ew_cap = (int)value;
             break;
-        case 101:   /* test knob: SpMV workgroups per XCD (1 forces the in-kernel loop on small meshes) */
+        case FEMCY_TUNE_SPMV_WG_PER_XCD:   /* test knob: SpMV workgroups per XCD (1 forces the in-kernel loop on small meshes) */
             FEMCY_REQUIRE(value >= 1 && value <= 512, "workgroups per XCD out of range");
             c->spmv_bpx_cap = (int32_t)value;
             if (c->have_pattern) {
@@ -323,11 +325,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->opt_persist = (int)value;
             c->persist_failed = false;
             break;
-        case 104:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
+        case FEMCY_TUNE_PERSIST_LDS_ROWS:   /* test knob: block rows per wave of the persistent PCG kept in LDS (-1 = as many as fit) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "resident block rows out of range");
             c->opt_persist_lds = (int)value;
             break;
-        case 110:   /* tuning: per-mille of every XCD's slice range that keeps the default cache policy in the NT SpMV */
+        case FEMCY_TUNE_SPMV_KEEP:   /* tuning: per-mille of every XCD's slice range that keeps the default cache policy in the NT SpMV */
             FEMCY_REQUIRE(value >= -1 && value <= 1000, "per-mille out of range (-1 = auto)");
             c->opt_spmv_keep = (int)value;
             if (c->have_pattern) {
@@ -335,25 +337,46 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 spmv_split(c);
             }
             break;
-        case 108:   /* test knob: register-resident block rows per wave of the small-system PCG (-1 = a wave's share) */
+        case FEMCY_TUNE_SMALL_REG_ROWS:   /* test knob: register-resident block rows per wave of the small-system PCG (-1 = a wave's share) */
             FEMCY_REQUIRE(value >= -1 && value <= 64, "register-resident rows out of range");
             c->opt_small_rr = (int)value;
             break;
-        case 107:   /* test knob: workgroups of the persistent PCG (0 = one per CU) -- exercises the barrier time-out */
+        case FEMCY_TUNE_PERSIST_WGS:   /* test knob: workgroups of the persistent PCG (0 = one per CU) -- exercises the barrier time-out */
             FEMCY_REQUIRE(value >= 0 && value <= 4096, "workgroup count out of range");
             c->opt_persist_wgs = (int)value;
             c->persist_failed = false;
             break;
-        case 106:   /* timing experiments: bit 0 no streamed rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait */
+        case FEMCY_TUNE_SKIP_OCCUPANCY_CHECK:
+            c->opt_skip_occupancy = value ? 1 : 0;
+            c->persist_failed = c->small_failed = false;
+            break;
+        case FEMCY_TUNE_BARRIER_SPIN_LIMIT:
+            FEMCY_REQUIRE(value >= 0 && value <= (1ll << 30), "spin limit out of range");
+            c->barrier_spin_limit = (uint32_t)value;
+            c->persist_failed = c->small_failed = false;
+            break;
+        case FEMCY_TUNE_PERSIST_VARIANT:
+            FEMCY_REQUIRE(value >= -1 && value <= 7, "variant bits: -1 (default) or 0..7");
+            c->opt_persist_variant = (int)value;
+            break;
+        case FEMCY_TUNE_PERSIST_PROBE:   /* timing experiments: bit 0 no streamed rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait */
+#ifdef FEMCY_PERSIST_PROBE
             c->opt_persist_dbg = (int)value;
             break;
-        case 105:   /* test knob: block rows per slice of the persistent PCG kept in registers (0, 4 or 5) */
+#else
+            FEMCY_REQUIRE(value == 0 || value == 16, "option 106: the work-skipping timing switches (bits 0-3) exist only in a "
+                                                     "-DFEMCY_PERSIST_PROBE build; 16 (no prefetch during the barriers) is always available");
+            c->opt_persist_dbg = (int)value;
+            break;
+#endif
+        case FEMCY_TUNE_PERSIST_REG_ROWS:   /* test knob: block rows per slice of the persistent PCG kept in registers (0, 4 or 5) */
             FEMCY_REQUIRE(value == 0 || value == 4 || value == 5, "register-resident block rows: 0, 4 or 5");
             c->opt_persist_rj = (int)value;
             break;
         case FEMCY_OPT_PCG_SMALL:
             FEMCY_REQUIRE(value == 0 || value == 1, "small-system PCG: 0 (off) or 1 (auto)");
             c->opt_small = (int)value;
+            c->small_failed = false;
             break;
         case FEMCY_OPT_OVERLAP:
             FEMCY_REQUIRE(value == 0 || value == 1, "overlap: 0 (one stream) or 1 (exchange overlapped with the interior product)");
@@ -363,7 +386,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || value == 1, "tangent: 0 (reference) or 1 (consistent)");
             c->opt_tangent = (int)value;
             break;
-        case 103:   /* test knob: PCG vector kernels with non-temporal loads / stores */
+        case FEMCY_TUNE_VEC_NT:   /* test knob: PCG vector kernels with non-temporal loads / stores */
             FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
             c->opt_vec_nt = (int)value;
             if (c->have_pattern) {
@@ -371,7 +394,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 spmv_split(c);
             }
             break;
-        case 102:   /* test knob: SpMV matrix loads non-temporal (-1 auto: matrix larger than the Infinity Cache) */
+        case FEMCY_TUNE_SPMV_NT:   /* test knob: SpMV matrix loads non-temporal (-1 auto: matrix larger than the Infinity Cache) */
             FEMCY_REQUIRE(value >= -1 && value <= 1, "non-temporal switch must be -1, 0 or 1");
             c->opt_spmv_nt = (int)value;
             if (c->have_pattern) {
@@ -379,7 +402,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
                 spmv_split(c);
             }
             break;
-        case 100:   /* undocumented debugging knob: empty kernel before a sampled SpMV dispatch */
+        case FEMCY_TUNE_TIMING_FENCE:   /* debugging knob: empty kernel before a sampled SpMV dispatch */
             c->opt_timing_fence = value ? 1 : 0;
             break;
         case FEMCY_OPT_SELL_SIGMA:
@@ -507,6 +530,12 @@ int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C, const doub
     const bool ok_dm = kind == FEMCY_MAT_NEOHOOKE || ((kind == FEMCY_MAT_LIN3D) == (c->dm == 3));
     FEMCY_REQUIRE(ok_dm, "material kind %d does not match dm=%d", kind, c->dm);
     FEMCY_REQUIRE(nparams >= 2 && params, "material needs 2 parameters");
+    // F / sigma "of the last force evaluation" are kept lazily (Ctx::gp_lazy): materialise them with the material they
+    // were evaluated with before it changes
+    if (c->gp_lazy && c->have_material && c->have_element) {
+        int rcl = ensure_gp_stress(c);
+        if (rcl) return rcl;
+    }
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     const int s = (c->dm == 2) ? 3 : 6;
     int rc;
@@ -1071,6 +1100,26 @@ int femcy_timing_reset(femcy_ctx* ctx) {
     CTX_OR_FAIL(ctx);
     timing_collect(c);
     c->timing = femcy_timing_t{};
+    return FEMCY_OK;
+}
+
+// ------------------------------------------------------------------------------------ ceilings
+int femcy_probe_stream(femcy_ctx* ctx, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass,
+                       int64_t* bytes_per_pass) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(us_per_pass, "null output");
+    return probe_stream(c, bytes, reps, mode, us_per_pass, bytes_per_pass);
+}
+int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* us_per_exchange) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(us_per_exchange, "null output");
+    return probe_exchange(c, rounds, form, us_per_exchange);
+}
+int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(bytes, "null output");
+    FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
+    *bytes = persist_streamed_bytes(c);
     return FEMCY_OK;
 }
 

@@ -1515,16 +1515,39 @@ int launch_assemble(Ctx* c) {
         const int T = c->npe - 1, EPC = 64 / T, RD = c->nGP * c->npe * 3;
         const int volw = (EPC * c->nGP + 1) & ~1, codew = (EPC + 1) / 2 * 2 / 2 + 1, accw = (c->max_row_blocks * 9 + 1) & ~1;
         const size_t lds = (size_t)4 * (EPC * RD + volw + accw + 2 * codew) * sizeof(double);
+        // the accumulator of a row grows with the longest row of the mesh (288 B per block): an unstructured mesh with
+        // high-valence nodes can exceed what a workgroup may allocate -- AUTO then takes ROWS (its LDS is 4 rows only)
+        if (lds + 512 > (size_t)c->small_max_lds) {
+            FEMCY_REQUIRE(c->opt_assembly == FEMCY_ASM_AUTO, "ROWS2 assembly needs %zu B of LDS per workgroup (longest row: %d "
+                          "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
+            mode = FEMCY_ASM_ROWS;
+        }
 #define FEMCY_ROWS2(NPE_, NGP_, CUB_)                                                                                  \
-    hipLaunchKernelGGL((k_assemble_rows2<NPE_, NGP_, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,    \
-                       c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of, c->d_slice_off, \
-                       c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2], c->d_Kvals)
-        if (c->npe == 10) { if (c->C_is_cubic) FEMCY_ROWS2(10, 4, true); else FEMCY_ROWS2(10, 4, false); }
-        else              { if (c->C_is_cubic) FEMCY_ROWS2(4, 1, true); else FEMCY_ROWS2(4, 1, false); }
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows2<NPE_, NGP_, CUB_>),          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL((k_assemble_rows2<NPE_, NGP_, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices, \
+                           c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,         \
+                           c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
+                           c->d_Kvals);                                                                                \
+    } while (0)
+        if (mode == FEMCY_ASM_ROWS2) {
+            if (c->npe == 10) { if (c->C_is_cubic) FEMCY_ROWS2(10, 4, true); else FEMCY_ROWS2(10, 4, false); }
+            else              { if (c->C_is_cubic) FEMCY_ROWS2(4, 1, true); else FEMCY_ROWS2(4, 1, false); }
+        }
 #undef FEMCY_ROWS2
+    }
+    if (mode == FEMCY_ASM_ROWS2) {
     } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);
+        FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS assembly: a row of %d blocks does not fit the LDS",
+                      c->max_row_blocks);
+        if (lds > 48 * 1024)
+            FEMCY_HIP(hipFuncSetAttribute(c->dm == 3 ? reinterpret_cast<const void*>(&k_assemble_rows<3>)
+                                                     : reinterpret_cast<const void*>(&k_assemble_rows<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (c->dm == 3)
             hipLaunchKernelGGL((k_assemble_rows<3>), dim3(grid), dim3(bs), lds, c->stream, c->nn, c->npe, c->nGP,
                                c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_pos, c->d_slice_off,

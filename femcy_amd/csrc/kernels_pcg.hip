@@ -660,9 +660,11 @@ int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1
 __global__ void k_fence_noop() {}
 
 static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out,
-                            const XcdRanges& xr, int grid, const int32_t* slice_list) {
-    if (grid > MAX_PARTIALS) {
-        set_error("SpMV grid %d exceeds MAX_PARTIALS %d", grid, MAX_PARTIALS);
+                            const XcdRanges& xr, int grid, const int32_t* slice_list, int part_off = 0) {
+    // the partials of a launch go to d_partials[part_off .. part_off + grid): the two halves of a split product share
+    // one array of MAX_PARTIALS entries
+    if (part_off + grid > MAX_PARTIALS) {
+        set_error("SpMV grid %d at partial offset %d exceeds MAX_PARTIALS %d", grid, part_off, MAX_PARTIALS);
         return FEMCY_EINVAL;
     }
     const int32_t* done = d_partials ? &c->d_state->done : nullptr;
@@ -749,9 +751,10 @@ int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d
     for (int k = 0; k <= NXCD; ++k) xr.start[k] = p0 + (int32_t)((int64_t)(p1 - p0) * k / NXCD);
     int per = 1;
     for (int k = 0; k < NXCD; ++k) per = std::max(per, (xr.start[k + 1] - xr.start[k] + spb - 1) / spb);
-    const int grid = std::min(per, std::max(1, c->spmv_bpx_cap)) * NXCD;
+    // the two halves together must fit the partial array: each half gets at most half of it
+    const int grid = std::min(std::min(per, std::max(1, c->spmv_bpx_cap)), MAX_PARTIALS / (2 * NXCD)) * NXCD;
     return launch_spmv_impl(c, d_x, d_y, d_partials ? d_partials + part_off : nullptr, nblocks_out, xr, grid,
-                            c->d_split_list);
+                            c->d_split_list, d_partials ? part_off : 0);
 }
 
 // sum a sub-assembled vector over the ranks that share each interface DOF
@@ -810,6 +813,7 @@ struct SmallPcg {
     unsigned int* counter;
     PcgState* st;
     int32_t n, npad, maxit;
+    uint32_t spin_limit;   // polls of the grid barrier before a workgroup gives up and poisons the counter
     double eps;
 };
 
@@ -945,12 +949,24 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+            // bounded wait (a legitimate one is a few microseconds): the workgroup that times out poisons the counter,
+            // which releases every other workgroup -- those spinning now and those that arrive later -- with the same
+            // verdict (the scheme of k_pcg_persist's grid_barrier); the host then redoes the solve with the
+            // three-kernel loop and does not try this kernel again on the context
+            constexpr unsigned int POISON = 0x80000000u;
             __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int target = (unsigned int)G * (unsigned int)(it + 1);
             unsigned int spins = 0;
-            while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            for (;;) {
+                const unsigned int v = __hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & POISON) {
+                    s_fail = 1;
+                    break;
+                }
+                if (v >= target) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 26)) {              // seconds: a workgroup is missing (not resident / died)
+                if (++spins > a.spin_limit) {            // a workgroup is missing (not resident / died)
+                    __hip_atomic_fetch_or(a.counter, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_fail = 1;
                     break;
                 }
@@ -1020,11 +1036,28 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
     }
 }
 
+// A hand-rolled grid barrier needs every workgroup of the launch resident at once.  The occupancy query answers for an
+// otherwise idle device (MI355X_MICROARCH.md "Residency": the API may be one workgroup per CU high at 81-96 SGPRs, so
+// a grid is accepted only with a margin of one per CU unless the kernel needs the whole CU anyway); a busy device is
+// what the bounded spin + poison in the kernels is for.  FEMCY_TUNE_SKIP_OCCUPANCY_CHECK = 1 skips the query (tests of
+// the time-out path).
+bool coresident(Ctx* c, const void* fn, int block, size_t lds, int grid) {
+    if (c->opt_skip_occupancy) return true;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (per_cu > 1) per_cu -= 1;                         // margin for the API's optimism
+    return (int64_t)per_cu * c->persist_cus >= grid;
+}
+
 // eligibility + launch; returns FEMCY_OK with *handled = false when the system does not qualify
 static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
     *handled = false;
     constexpr int KMAX = 48;                               // 48 * 256 = 12 288 DOF (K = 80 spills the register file)
-    if (!c->opt_small || c->comm || c->opt_timing || c->nslices > c->small_max_wg || c->n > (int64_t)KMAX * BS)
+    if (!c->opt_small || c->small_failed || c->comm || c->opt_timing || c->nslices > c->small_max_wg ||
+        c->n > (int64_t)KMAX * BS)
         return FEMCY_OK;
     const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const size_t lds = (size_t)(npad + 4 * c->dm * 64 + 2 * (BS / 64)) * sizeof(double);
@@ -1044,6 +1077,7 @@ static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, i
     a.counter = reinterpret_cast<unsigned int*>(c->d_small + 2 * npad + 2 * G);
     a.st = c->d_state;
     a.n = (int32_t)c->n; a.npad = (int32_t)npad; a.maxit = maxit; a.eps = eps;
+    a.spin_limit = c->barrier_spin_limit;
     FEMCY_HIP(hipMemsetAsync(a.counter, 0, 8, c->stream));
     const int kneed = (int)((c->n + BS - 1) / BS);
     // register buckets: thread t keeps entries t + 256 k, k < K, of r and M
@@ -1052,6 +1086,7 @@ static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, i
         const void* fn = reinterpret_cast<const void*>(&k_pcg_small<DM_, K_, RR_>);                                \
         if (lds > 48 * 1024)                                                                                       \
             FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        if (!coresident(c, fn, BS, lds, G)) return FEMCY_OK;   /* not all workgroups fit at once: three launches */ \
         hipLaunchKernelGGL((k_pcg_small<DM_, K_, RR_>), dim3(G), dim3(BS), lds, c->stream, a);                     \
     } while (0)
     // register-resident block rows per wave: a wave's share of the longest slice, in buckets the register file holds
@@ -1116,20 +1151,20 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         if (!handled) {
             if ((rc = pcg_persist_solve(c, d_b, d_x, eps, maxit, &handled))) return rc;
             persist = handled;
-            if (handled) {       // a barrier time-out (a workgroup was not resident) falls back to the three-kernel loop
-                FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
-                FEMCY_HIP(hipStreamSynchronize(c->stream));
-                if (c->h_state->done == 3) {
-                    c->persist_failed = true;
-                    handled = persist = false;
-                }
+        }
+        if (handled) {
+            FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+            FEMCY_HIP(hipStreamSynchronize(c->stream));
+            // a grid-barrier time-out (a workgroup was not resident: shared GPU, CU mask, another persistent kernel): every
+            // workgroup left with the same verdict; the solve is redone by the three-kernel loop below, which
+            // re-initialises x, r and d, and the context does not try the one-launch form again
+            if (c->h_state->done == 3) {
+                if (persist) c->persist_failed = true; else c->small_failed = true;
+                c->timing.barrier_timeouts++;
+                handled = persist = false;
             }
         }
         if (handled) {
-            if (!persist) {
-                FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
-                FEMCY_HIP(hipStreamSynchronize(c->stream));
-            }
             timing_end(c, th);
             if (iters) *iters = c->h_state->iters;
             if (r0) *r0 = c->h_state->r0;
@@ -1140,10 +1175,6 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
                 if (c->opt_timing) c->timing.persist_iters += c->h_state->iters;
             } else {
                 c->timing.solves_small++;
-            }
-            if (c->h_state->done == 3) {
-                set_error("small-system PCG: grid barrier timed out after %d iterations (a workgroup was not resident)", c->h_state->iters);
-                return FEMCY_EHIP;
             }
             if (c->h_state->done == 2) {
                 set_error("PCG breakdown: NaN/Inf residual after %d iterations (r0 = %g)", c->h_state->iters, c->h_state->r0);

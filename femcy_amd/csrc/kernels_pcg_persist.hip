@@ -13,20 +13,38 @@
 //     requested right after the current one and arrives during the barrier waits; the rest is streamed in batches
 //     of CH block rows (columns, values, then the gathers as sc1 buffer loads, then the multiplies);
 //   * the three synchronisation points of the recurrence (d.Ad before alpha, r.M.r before beta, the new d before the
-//     next product) are grid barriers: per-XCD arrival counters + one top counter, relaxed agent-scope atomics, data
-//     exchanged with sc1 (write-through) stores and sc1 loads -- no fences (cdna_hip_programming.md Guideline 16, R1).
-//     Measured (tools/micro/barrier_probe.hip): 2.2-2.4 us per barrier at 256 workgroups, against 1.7-1.9 us for a
-//     kernel boundary plus the ramp of a new launch.
+//     next product) are grid-wide exchanges without fences (cdna_hip_programming.md Guideline 16, R1 / R2), in one of
+//     two forms chosen per launch (FEMCY_TUNE_PERSIST_VARIANT, measured in DESIGN.md section 3):
+//       - counters: per-XCD arrival counters + one top counter, relaxed agent-scope atomics, data exchanged with sc1
+//         (write-through) stores and sc1 loads (round 2);
+//       - tagged granules (VAR & 2): every workgroup publishes {value, round} as ONE 16-byte sc1 store and one wave per
+//         workgroup sweeps all G granules until every tag shows the round -- barrier and exchange in one store
+//         latency + one load latency instead of store-ack + two atomics + poll + data load.
+// Round 3 variants (template parameter VAR, bits):
+//   1  the streamed block rows are swept in alternating direction on odd / even iterations: the tail of one sweep is
+//      the head of the next and is re-read from the XCD's 4 MiB L2 instead of the Infinity Cache;
+//   2  tagged-granule synchronisation (above);
+//   4  d is published in STORAGE order (position = slice * 64 + lane) so that a lane's dm values are contiguous for
+//      the whole wave: one 16-byte + one 8-byte store / gather per node instead of three 8-byte ones (a third fewer
+//      texture-address cycles on the largest non-matrix item of the iteration).
 // Recurrence, preconditioner and stopping rule are those of pcg_solve / the reference
 // (conjugateGradientSolver.py:103-127); partial sums are combined in a fixed order, so a solve is bit-reproducible.
 // d is double-buffered by iteration parity (a wave may gather d_k while a faster one already publishes d_k+1), as are
-// the partial arrays.  Every spin is bounded: the workgroup that times out poisons the top counter (which releases
-// all others), the launch ends with state.done = 3 and the host falls back to the three-kernel loop.
+// the partial arrays.  Every spin is bounded: the workgroup that times out poisons the exchange (which releases all
+// others), the launch ends with state.done = 3 and the host falls back to the three-kernel loop.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 #include "ctx.hpp"
 #include "wave_reduce.hpp"
+
+// The inter-workgroup protocol below (sc1 write-through stores, sc1 loads, relaxed agent-scope counters, no fences)
+// rests on the cache-policy semantics of the multi-XCD CDNA3 / CDNA4 parts (MI355X_MICROARCH.md "Workgroup dispatch,
+// XCD placement & inter-workgroup visibility"); another --offload-arch must not silently lose coherence.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_pcg_persist: the sc1-only hand-off protocol is validated for gfx942 / gfx950 only"
+#endif
 
 namespace femcy {
 
@@ -35,11 +53,22 @@ namespace {
 constexpr int PBS = 256;        // 4 waves per workgroup, one workgroup per CU
 constexpr int PNX = 8;
 constexpr int CH = 4;         // block rows per batch of the LDS-resident and the streamed part
+constexpr int V_ALT = 1, V_A2A = 2, V_WIDE = 4;
+constexpr unsigned long long TAG_POISON = ~0ull;
+
+// Work-skipping switches for timing experiments (tools/persist_breakdown.py) exist only in a probe build
+// (FEMCY_EXTRA_FLAGS=-DFEMCY_PERSIST_PROBE FEMCY_OUT=../libfemcy_hip_probe.so csrc/build.sh): the shipped library
+// has no path that skips work.
+#ifdef FEMCY_PERSIST_PROBE
+#define PDBG(a_, bit_) ((a_).dbg & (bit_))
+#else
+#define PDBG(a_, bit_) false
+#endif
 
 struct PersistPcg {
     const int32_t* slice_len;
     const int64_t* slice_off;
-    const int32_t* bcol;
+    const int32_t* bcol;    // block columns as node numbers, or as storage positions (VAR & 4)
     const int32_t* node_of;
     const int32_t* assign;  // [8 * waves per XCD][SPW] slices of each wave, -1 = none
     const double* vals;
@@ -49,10 +78,12 @@ struct PersistPcg {
     double* dbuf;         // [2][npad]
     double* part1;        // [2][G]      d.Ad partials
     double* part2;        // [2][2 G]    (r.M.r, max|r|) pairs
+    double* slots;        // tagged granules {value, tag}: [G] d.Ad, [2 G] (r.M.r, max|r|), [G] d published
     unsigned int* xc;     // [8][32]     per-XCD arrival counters (one cache line apart)
     unsigned int* top;
     PcgState* st;
     int32_t npad, maxit, lds_rows, dbg;
+    uint32_t spin_limit;  // polls before a barrier gives up and poisons the exchange
     double eps;
 };
 
@@ -66,6 +97,10 @@ __device__ __forceinline__ double pabs(double r) {   // fmax() drops NaN; keep i
     const double a = fabs(r);
     return (a != a) ? INFINITY : a;
 }
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;     // gfx940+ buffer cache-policy bit 4: sc1 = write-through store / L2-served load
 
 // all workgroups of the launch; `round` counts the barriers since the launch (0, 1, 2, ...)
 // `mid` runs in every thread between the arrival and the wait: loads issued there travel while the workgroup waits
@@ -86,7 +121,7 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
         // other workgroup -- those spinning now and those that reach a barrier later -- with the same verdict
         constexpr unsigned POISON = 0x80000000u;
         unsigned spins = 0;
-        while (!(a.dbg & 8)) {
+        while (!PDBG(a, 8)) {
             const unsigned v = __hip_atomic_load(a.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v & POISON) {
                 *s_fail = 1;
@@ -94,7 +129,7 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
             }
             if (v >= PNX * (round + 1)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21)) {
+            if (++spins > a.spin_limit) {
                 __hip_atomic_fetch_or(a.top, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_fail = 1;
                 break;
@@ -108,11 +143,62 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
     return grid_barrier(a, round, s_fail, [] {});
 }
 
-template <int DM, int SPW, int RJ>
+// ---- tagged-granule exchange (wave 0 of every workgroup).  A granule is one naturally aligned 16-byte {f64 value,
+// u64 tag} written by ONE sc1 store (observed untorn on gfx950, MI355X_MICROARCH.md "Valid forms": R2); tags are
+// the launch-wide round number (1, 2, 3, ...; the arrays are zeroed before the launch), so a slot needs no re-arming
+// and no second buffer: a workgroup can write round k + 1 of an array only after every workgroup has read round k
+// of it (the two other exchanges of the iteration lie in between).
+__device__ __forceinline__ void granule_store(const __amdgpu_buffer_rsrc_t rs, int idx, double v, unsigned long long tag) {
+    u32x4 w;
+    w.x = (unsigned)__double2loint(v);
+    w.y = (unsigned)__double2hiint(v);
+    w.z = (unsigned)tag;
+    w.w = (unsigned)(tag >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, idx * 16, 0, AUX_SC1);
+}
+// NV granules per workgroup, stored [G][NV]; lane sweeps workgroups lane, lane + 64, ...; sums / maxima in a fixed
+// order (the same in every workgroup).  op[v]: 0 = sum, 1 = max.  Returns false on poison or time-out (the caller's
+// workgroup then poisons its own granules, which every other sweep sees).
+template <int NV>
+__device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, int base, int G, unsigned long long tag,
+                                              uint32_t spin_limit, double (&out)[NV], const int (&op)[NV]) {
+    const int lane = threadIdx.x & 63;
+    uint32_t spins = 0;
+    for (;;) {
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        bool ok = true, poison = false;
+        for (int k = lane; k < G; k += 64) {
+            u32x4 w[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) w[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (base + k * NV + v) * 16, 0, AUX_SC1);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const unsigned long long t = ((unsigned long long)w[v].w << 32) | w[v].z;
+                ok = ok && (t == tag);
+                poison = poison || (t == TAG_POISON);
+                const double val = __hiloint2double((int)w[v].y, (int)w[v].x);
+                acc[v] = op[v] ? fmax(acc[v], val) : acc[v] + val;
+            }
+        }
+        if (__any(poison)) return false;
+        if (__all(ok)) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) out[v] = op[v] ? wave_max(acc[v]) : wave_sum(acc[v]);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit) return false;
+    }
+}
+
+template <int DM, int SPW, int RJ, int VAR>
 __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
+    constexpr bool ALT = (VAR & V_ALT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
     extern __shared__ __attribute__((aligned(16))) char lds_persist[];
-    __shared__ double sm1[PBS / 64], sm2[PBS / 64];
+    __shared__ double sm1[PBS / 64], sm2[PBS / 64], bc[2];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and known to be so: scalar registers
@@ -126,7 +212,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     const int xk = blockIdx.x % PNX;
     const int nwx = (G / PNX) * 4;                               // waves per XCD
     const int wx = (blockIdx.x / PNX) * 4 + wave;                // this wave among them
-    int32_t sl[SPW], Ls[SPW], node[SPW];
+    int32_t sl[SPW], Ls[SPW], node[SPW], dpos[SPW];
     int64_t offs[SPW];
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
@@ -138,6 +224,8 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         offs[t] = ((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o);
         node[t] = act ? a.node_of[(int64_t)s * 64 + lane] : -1;
+        // where this lane's d lives in the published vector: its node (round 2), or its storage position (VAR & 4)
+        dpos[t] = WIDE ? (act ? s * 64 + lane : 0) : (node[t] >= 0 ? node[t] : 0);
     }
     // ---- resident part of the matrix (once per solve): block rows 0 .. RJ-1 of every slice -> registers (a row the
     // slice does not have is a zero block on the lane's own node), the next lds_rows block rows of the wave -> LDS
@@ -151,7 +239,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             const double* src = a.vals + (offs[t] + (has ? jj : 0)) * (int64_t)(DD * 64);
 #pragma unroll
             for (int k = 0; k < DD; ++k) rv[t][jj][k] = has ? src[kv_index<DM>(0, k, lane)] : 0.0;
-            rcl[t][jj] = has ? a.bcol[(offs[t] + jj) * 64 + lane] : (node[t] >= 0 ? node[t] : 0);
+            rcl[t][jj] = has ? a.bcol[(offs[t] + jj) * 64 + lane] : dpos[t];
         }
     // LDS rows are handed out from the LAST slice backwards, so that slice 0 keeps streamed rows: its first batch is
     // the one prefetched during the synchronisation windows (below).  jl[t] .. je[t]-1 = the slice's rows in LDS.
@@ -180,19 +268,52 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.dbuf, 0, (int)((size_t)2 * a.npad * sizeof(double)), 0x00020000);
     auto gather_d = [&](int32_t col, int32_t parity_off, double (&xv)[DM]) {
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        if (WIDE) {     // dm contiguous doubles at 8-byte alignment: 16 B (+ 8 B for dm = 3); dword alignment suffices
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(drsrc, col * (DM * 8), parity_off, AUX_SC1);
+            xv[0] = __hiloint2double((int)w.y, (int)w.x);
+            xv[1] = __hiloint2double((int)w.w, (int)w.z);
+            if (DM == 3) {
+                const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(drsrc, col * (DM * 8) + 16, parity_off, AUX_SC1);
+                xv[DM - 1] = __hiloint2double((int)w2.y, (int)w2.x);
+            }
+        } else {
 #pragma unroll
-        for (int cc = 0; cc < DM; ++cc) {
-            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(drsrc, (col * DM + cc) * 8, parity_off, 16 /* sc1 */);
-            xv[cc] = __hiloint2double((int)w.y, (int)w.x);
+            for (int cc = 0; cc < DM; ++cc) {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(drsrc, (col * DM + cc) * 8, parity_off, AUX_SC1);
+                xv[cc] = __hiloint2double((int)w.y, (int)w.x);
+            }
+        }
+    };
+    auto publish_d = [&](int32_t p, int32_t parity_off, const double (&dv)[DM]) {
+        if (WIDE) {
+            u32x4 w;
+            w.x = (unsigned)__double2loint(dv[0]);
+            w.y = (unsigned)__double2hiint(dv[0]);
+            w.z = (unsigned)__double2loint(dv[1]);
+            w.w = (unsigned)__double2hiint(dv[1]);
+            __builtin_amdgcn_raw_buffer_store_b128(w, drsrc, p * (DM * 8), parity_off, AUX_SC1);
+            if (DM == 3) {
+                u32x2 w2;
+                w2.x = (unsigned)__double2loint(dv[DM - 1]);
+                w2.y = (unsigned)__double2hiint(dv[DM - 1]);
+                __builtin_amdgcn_raw_buffer_store_b64(w2, drsrc, p * (DM * 8) + 16, parity_off, AUX_SC1);
+            }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < DM; ++cc) {
+                u32x2 w2;
+                w2.x = (unsigned)__double2loint(dv[cc]);
+                w2.y = (unsigned)__double2hiint(dv[cc]);
+                __builtin_amdgcn_raw_buffer_store_b64(w2, drsrc, (p * DM + cc) * 8, parity_off, AUX_SC1);
+            }
         }
     };
     // nb (<= CH) consecutive block rows of a slice: columns and values (rows beyond nb: the column of the last one,
     // so that its gather stays in range; no values)
-    auto load_rows = [&](const int32_t* __restrict__ bc, const double2* __restrict__ vp, const double* __restrict__ vs,
+    auto load_rows = [&](const int32_t* __restrict__ bc_, const double2* __restrict__ vp, const double* __restrict__ vs,
                          int32_t j, int nb, int32_t (&col)[CH], double (&e)[CH][DD]) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) col[u] = bc[(int64_t)(j + max(0, min(u, nb - 1))) * 64];
+        for (int u = 0; u < CH; ++u) col[u] = bc_[(int64_t)(j + max(0, min(u, nb - 1))) * 64];
 #pragma unroll
         for (int u = 0; u < CH; ++u)
             if (u < nb) {
@@ -213,7 +334,11 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     const int32_t* __restrict__ bc0 = a.bcol + offs[0] * 64 + lane;
     const double2* __restrict__ vp0 = reinterpret_cast<const double2*>(a.vals + offs[0] * (int64_t)(DD * 64)) + lane;
     const double* __restrict__ vs0 = a.vals + offs[0] * (int64_t)(DD * 64) + NP * 128 + lane;
-    const int npf = (a.dbg & 16) ? 0 : max(0, min(CH, Ls[0] - je[0]));   // rows of the prefetched batch
+    // rows of the batch prefetched during the synchronisation windows.  bit 4 of dbg: no prefetch (a layout variant, not
+    // work skipping).  Tagged-granule form: wave 0 sweeps the granules during those windows, and VMEM returns in order
+    // -- a prefetch of its own would sit in front of every sweep -- so wave 0 does not prefetch (the host hands it
+    // one batch less of streamed rows instead)
+    const int npf = ((a.dbg & 16) || (A2A && wave == 0)) ? 0 : max(0, min(CH, Ls[0] - je[0]));
     int32_t pcol[CH];
     double pe[CH][DD];
     const int32_t jpf = npf > 0 ? je[0] : 0;                               // (npf = 0: row 0's column, unused)
@@ -222,7 +347,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
 #pragma unroll
-    for (int t = 0; t < SPW; ++t)
+    for (int t = 0; t < SPW; ++t) {
 #pragma unroll
         for (int c = 0; c < DM; ++c) {
             const bool in = node[t] >= 0;
@@ -233,12 +358,25 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             mm[t][c] = mi;
             dd[t][c] = mi * bi;
             Ad[t][c] = 0.0;
-            if (in) pst(a.dbuf + i, dd[t][c]);
             accs += bi * mi * bi;
             accm = fmax(accm, pabs(bi));
         }
+        if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], 0, dd[t]);
+    }
     unsigned round = 0;
-    auto reduce_pair_publish = [&](double s, double m, double* slot2) {
+    // granule arrays: [0, G) d.Ad, [G, 3 G) (r.M.r, max|r|), [3 G, 4 G) "d published"
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.slots, 0, G * 4 * 16, 0x00020000);
+    auto poison_granules = [&]() {
+        if (lane == 0) {
+            granule_store(srsrc, blockIdx.x, 0.0, TAG_POISON);
+            granule_store(srsrc, G + 2 * blockIdx.x, 0.0, TAG_POISON);
+            granule_store(srsrc, G + 2 * blockIdx.x + 1, 0.0, TAG_POISON);
+            granule_store(srsrc, 3 * G + blockIdx.x, 0.0, TAG_POISON);
+        }
+    };
+    // (sum, max) of one pair per workgroup over the grid; the result is in every thread on return; false = time-out /
+    // poison
+    auto exchange_pair = [&](double s, double m, double* part2_base, double& s_out, double& m_out) -> bool {
         s = wave_sum(s);
         m = wave_max(m);
         if (lane == 0) {
@@ -246,68 +384,114 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             sm2[wave] = m;
         }
         __syncthreads();
-        if (tid == 0) {
-            pst(slot2, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
-            pst(slot2 + 1, fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3])));
+        if (A2A) {
+            if (wave == 0) {
+                const double ws = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+                const double wm = fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3]));
+                const unsigned long long tag = round + 1;
+                if (lane == 0) granule_store(srsrc, G + 2 * blockIdx.x, ws, tag);
+                if (lane == 1) granule_store(srsrc, G + 2 * blockIdx.x + 1, wm, tag);
+                double o[2];
+                const int op[2] = {0, 1};
+                const bool okx = granule_sweep<2>(srsrc, G, G, tag, a.spin_limit, o, op);
+                if (!okx) poison_granules();
+                if (lane == 0) {
+                    bc[0] = o[0];
+                    bc[1] = o[1];
+                    if (!okx) s_fail = 1;
+                }
+            }
+            ++round;
+            __syncthreads();
+            s_out = bc[0];
+            m_out = bc[1];
+            return s_fail == 0;
+        } else {
+            if (tid == 0) {
+                pst(part2_base + 2 * blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
+                pst(part2_base + 2 * blockIdx.x + 1, fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3])));
+            }
+            if (!grid_barrier(a, round++, &s_fail)) return false;
+            double ps = 0.0, pm = 0.0;
+            for (int k = tid; k < G; k += PBS) {                                 // every workgroup: the same order
+                ps += pld(part2_base + 2 * k);
+                pm = fmax(pm, pld(part2_base + 2 * k + 1));
+            }
+            ps = wave_sum(ps);
+            pm = wave_max(pm);
+            __syncthreads();                                                     // sm1 / sm2 free again
+            if (lane == 0) {
+                sm1[wave] = ps;
+                sm2[wave] = pm;
+            }
+            __syncthreads();
+            s_out = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+            m_out = fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3]));
+            return true;
         }
     };
-    auto gather_pairs = [&](const double* base, double& s, double& m) {     // every workgroup: the same order
-        double ps = 0.0, pm = 0.0;
-        for (int k = tid; k < G; k += PBS) {
-            ps += pld(base + 2 * k);
-            pm = fmax(pm, pld(base + 2 * k + 1));
-        }
-        ps = wave_sum(ps);
-        pm = wave_max(pm);
-        __syncthreads();                                                     // sm1 / sm2 free again
-        if (lane == 0) {
-            sm1[wave] = ps;
-            sm2[wave] = pm;
-        }
-        __syncthreads();
-        s = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
-        m = fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3]));
-    };
-    reduce_pair_publish(accs, accm, a.part2 + 2 * blockIdx.x);
-    bool ok = grid_barrier(a, round++, &s_fail);
     double rMr = 0.0, r0 = 0.0;
-    gather_pairs(a.part2, rMr, r0);
+    // the initial d is published with the first exchange: its stores are drained before anybody passes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool ok0 = exchange_pair(accs, accm, a.part2, rMr, r0);
     double rmax = r0;
-    int done = !ok ? 3 : ((r0 == 0.0) ? 1 : ((r0 != r0 || isinf(r0)) ? 2 : 0));
+    int done = !ok0 ? 3 : ((r0 == 0.0) ? 1 : ((r0 != r0 || isinf(r0)) ? 2 : 0));
     int it = 0;
-    while (!done && it < a.maxit) {
-        __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
-        const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
-        // ---- Ad = K d for the wave's rows, d gathered with sc1 loads (the other XCDs wrote it with sc1 stores)
-        double dot = 0.0;
+
+    // ---- Ad = K d for the wave's rows (d gathered with sc1 loads: the other XCDs wrote it with sc1 stores); returns
+    // the lane's part of d.Ad.  REV: slices and streamed rows in descending order (VAR & 1, odd iterations)
+    auto product = [&](const int32_t poff, auto rev_tag) -> double {
+        constexpr bool REV = decltype(rev_tag)::value;
+        double acc[SPW][DM];
 #pragma unroll
-        for (int t = 0; t < SPW; ++t) {
-            double acc[DM];
+        for (int t = 0; t < SPW; ++t)
 #pragma unroll
-            for (int r = 0; r < DM; ++r) acc[r] = 0.0;
+            for (int r = 0; r < DM; ++r) acc[t][r] = 0.0;
+        // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points; it is
+        // multiplied first in either direction, so that its registers are free for the streaming loop
+        if (npf > 0 && !PDBG(a, 1)) {
+            double xg[CH][DM];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (u < npf) {
+#pragma unroll
+                    for (int r = 0; r < DM; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < DM; ++cc) acc[0][r] += pe[u][r * DM + cc] * xg[u][cc];
+                }
+        }
+#pragma unroll
+        for (int tt = 0; tt < SPW; ++tt) {
+            const int t = REV ? SPW - 1 - tt : tt;
             const int32_t L = Ls[t];
-            const int32_t* __restrict__ bc = a.bcol + offs[t] * 64 + lane;
+            const int32_t* __restrict__ bcp = a.bcol + offs[t] * 64 + lane;
             const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
             const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
-            int32_t j = je[t];                                               // first streamed block row
-            // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points
-            if (t == 0 && npf > 0 && !(a.dbg & 1)) {
-                double xg[CH][DM];
+            const int32_t js = je[t] + ((t == 0) ? npf : 0);                 // first streamed block row of this sweep
+            // one batch of streamed block rows: columns, then the values, then the gathers, then the multiplies
+            auto batch = [&](int32_t j, int nb) {
+                int32_t col[CH];
+                double e[CH][DD], xg[CH][DM];
+                load_rows(bcp, vp, vs, j, nb, col, e);
 #pragma unroll
-                for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
+                for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
-                    if (u < npf) {
+                    if (u < nb) {
 #pragma unroll
                         for (int r = 0; r < DM; ++r)
 #pragma unroll
-                            for (int cc = 0; cc < DM; ++cc) acc[r] += pe[u][r * DM + cc] * xg[u][cc];
+                            for (int cc = 0; cc < DM; ++cc) acc[t][r] += e[u][r * DM + cc] * xg[u][cc];
                     }
-                j += npf;
-            }
+            };
+            if (REV && !PDBG(a, 1))
+                for (int32_t j1 = L; j1 > js; j1 -= CH) batch(max(js, j1 - CH), min(CH, j1 - js));
             // block rows held in registers: their gathers are issued in batches before the first multiply
-            if (RJ > 0 && !(a.dbg & 4)) {
+            if (RJ > 0 && !PDBG(a, 4)) {
                 constexpr int RB = RJ > 4 ? 3 : (RJ > 0 ? RJ : 1);               // rows per batch (register budget)
 #pragma unroll
                 for (int j0 = 0; j0 < RJ; j0 += RB) {
@@ -322,13 +506,13 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                             for (int r = 0; r < DM; ++r)
 #pragma unroll
-                                for (int cc = 0; cc < DM; ++cc) acc[r] += rv[t][j0 + u][r * DM + cc] * xg[u][cc];
+                                for (int cc = 0; cc < DM; ++cc) acc[t][r] += rv[t][j0 + u][r * DM + cc] * xg[u][cc];
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // block rows held in LDS, CH at a time (a short batch repeats its last row's gather and skips the multiply)
-            for (int32_t jr = jl[t]; jr < je[t] && !(a.dbg & 2); jr += CH) {
+            for (int32_t jr = jl[t]; jr < je[t] && !PDBG(a, 2); jr += CH) {
                 const int nb = min(CH, je[t] - jr);
                 const int q = ql[t] + (jr - jl[t]);
                 double xg[CH][DM];
@@ -342,50 +526,75 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                         for (int r = 0; r < DM; ++r)
 #pragma unroll
                             for (int cc = 0; cc < DM; ++cc)
-                                acc[r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
+                                acc[t][r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
                     }
             }
-            // streamed block rows, CH at a time: columns, then the values, then the gathers, then the multiplies
-            while (j < L && !(a.dbg & 1)) {
-                const int nb = min(CH, L - j);
-                int32_t col[CH];
-                double e[CH][DD], xg[CH][DM];
-                load_rows(bc, vp, vs, j, nb, col, e);
+            if (!REV && !PDBG(a, 1))
+                for (int32_t j = js; j < L; j += CH) batch(j, min(CH, L - j));
+        }
+        double dot = 0.0;
 #pragma unroll
-                for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (u < nb) {
-#pragma unroll
-                        for (int r = 0; r < DM; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < DM; ++cc) acc[r] += e[u][r * DM + cc] * xg[u][cc];
-                    }
-                j += nb;
-            }
+        for (int t = 0; t < SPW; ++t)
 #pragma unroll
             for (int r = 0; r < DM; ++r) {
-                Ad[t][r] = acc[r];
-                if (node[t] >= 0) dot += dd[t][r] * acc[r];
+                Ad[t][r] = acc[t][r];
+                if (node[t] >= 0) dot += dd[t][r] * acc[t][r];
             }
-        }
+        return dot;
+    };
+
+    // one iteration; with VAR & 1 the loop below holds two copies of it (even: ascending sweep, odd: descending) --
+    // as two alternatives inside ONE loop body the register allocator spilled 350 bytes per lane
+    auto iteration = [&](auto rev_tag) {
+        __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
+        const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
+        double dot = product(poff, rev_tag);
         // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested inside the first
-        // barrier (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
+        // exchange (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
         // synchronisation points (registers and memory system are idle there)
         dot = wave_sum(dot);
         if (lane == 0) sm1[wave] = dot;
         __syncthreads();
-        if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
-        if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe); })) { done = 3; break; }
+        double dAd;
+        if (A2A) {
+            if (wave == 0) {
+                const double ws = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+                const unsigned long long tag = round + 1;
+                if (lane == 0) granule_store(srsrc, blockIdx.x, ws, tag);
+                double o[1];
+                const int op[1] = {0};
+                const bool okx = granule_sweep<1>(srsrc, 0, G, tag, a.spin_limit, o, op);
+                if (!okx) poison_granules();
+                if (lane == 0) {
+                    bc[0] = o[0];
+                    if (!okx) s_fail = 1;
+                }
+                // defined on every path (see load_rows): wave 0 holds no prefetched batch
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    pcol[u] = 0;
+#pragma unroll
+                    for (int k = 0; k < DD; ++k) pe[u][k] = 0.0;
+                }
+            } else {
+                load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
+            }
+            ++round;
+            __syncthreads();
+            if (s_fail) { done = 3; return; }
+            dAd = bc[0];
+        } else {
+            if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
+            if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe); })) { done = 3; return; }
+            double ps = 0.0;
+            for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
+            ps = wave_sum(ps);
+            __syncthreads();
+            if (lane == 0) sm1[wave] = ps;
+            __syncthreads();
+            dAd = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+        }
         // ---- alpha; x, r; partials of (r.M.r, max|r|)
-        double ps = 0.0;
-        for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
-        ps = wave_sum(ps);
-        __syncthreads();
-        if (lane == 0) sm1[wave] = ps;
-        __syncthreads();
-        const double dAd = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
         const double alpha = rMr / dAd;
         accs = 0.0;
         accm = 0.0;
@@ -402,12 +611,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 }
             }
         __syncthreads();
-        reduce_pair_publish(accs, accm, a.part2 + (size_t)((it + 1) & 1) * 2 * G + 2 * blockIdx.x);
-        if (!grid_barrier(a, round++, &s_fail)) { done = 3; break; }
         double rMr_new = 0.0;
-        gather_pairs(a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax);
+        if (!exchange_pair(accs, accm, a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax)) { done = 3; return; }
         ++it;
-        if (a.dbg & 15) rmax = 1.0, rMr_new = 1.0;   // bits 0-3 skip work: keep iterating on whatever numbers result
+        if (PDBG(a, 15)) rmax = 1.0, rMr_new = 1.0;   // bits 0-3 skip work: keep iterating on whatever numbers result
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
             done = 2;
         } else if (rmax < a.eps * r0) {
@@ -415,18 +622,41 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         } else {
             // ---- d = M r + beta d, published for the next product
             const double beta = rMr_new / rMr;
-            double* dnext = a.dbuf + (size_t)(it & 1) * a.npad;
+            const int32_t noff = (it & 1) * a.npad * 8;
 #pragma unroll
-            for (int t = 0; t < SPW; ++t)
+            for (int t = 0; t < SPW; ++t) {
 #pragma unroll
-                for (int c = 0; c < DM; ++c) {
-                    dd[t][c] = mm[t][c] * rr[t][c] + beta * dd[t][c];
-                    if (node[t] >= 0) pst(dnext + (int64_t)node[t] * DM + c, dd[t][c]);
-                }
+                for (int c = 0; c < DM; ++c) dd[t][c] = mm[t][c] * rr[t][c] + beta * dd[t][c];
+                if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], noff, dd[t]);
+            }
             rMr = rMr_new;
-            if (it < a.maxit && !grid_barrier(a, round++, &s_fail)) { done = 3; break; }
+            if (it < a.maxit) {
+                if (A2A) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's part of d has left
+                    __syncthreads();
+                    if (wave == 0) {
+                        const unsigned long long tag = round + 1;
+                        if (lane == 0) granule_store(srsrc, 3 * G + blockIdx.x, 0.0, tag);
+                        double o[1];
+                        const int op[1] = {0};
+                        const bool okx = granule_sweep<1>(srsrc, 3 * G, G, tag, a.spin_limit, o, op);
+                        if (!okx) poison_granules();
+                        if (lane == 0 && !okx) s_fail = 1;
+                    }
+                    ++round;
+                    __syncthreads();
+                    if (s_fail) { done = 3; return; }
+                } else if (!grid_barrier(a, round++, &s_fail)) {
+                    done = 3;
+                    return;
+                }
+            }
         }
         if (done) rMr = rMr_new;
+    };
+    while (!done && it < a.maxit) {
+        iteration(std::false_type{});
+        if (ALT && !done && it < a.maxit) iteration(std::true_type{});
     }
 #pragma unroll
     for (int t = 0; t < SPW; ++t)
@@ -443,7 +673,123 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     }
 }
 
+// block columns as storage positions (VAR & 4): bcolp[i] = pos[bcol[i]]
+__global__ void k_bcol_to_pos(int64_t n, const int32_t* __restrict__ bcol, const int32_t* __restrict__ pos,
+                              int32_t* __restrict__ bcolp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bcolp[i] = pos[bcol[i]];
+}
+
+// ------------------------------------------------------------------------------------------------ ceiling probes
+// What the persistent kernel runs against (bench.py's roofline): (1) the rate at which the chip streams a read-only
+// buffer of the size of the kernel's streamed matrix part, in the kernel's launch shape (one workgroup of four waves
+// per CU, 16-byte loads, XCD-contiguous ranges), repeated so that it comes from wherever a buffer of that size lives
+// (Infinity Cache below ~200 MB); (2) the price of one grid-wide exchange of the form the solver uses.
+__global__ void __launch_bounds__(PBS) k_probe_stream(const double2* __restrict__ buf, int64_t n16, int reps, int nt,
+                                                      double* __restrict__ sink) {
+    const int G = gridDim.x, xk = blockIdx.x % PNX, per = G / PNX;
+    const int64_t chunk = (n16 / G) & ~(int64_t)(PBS * 8 - 1);   // 16-byte elements per workgroup, whole tiles
+    const int64_t wg = (int64_t)xk * per + blockIdx.x / PNX;     // XCD k walks a contiguous range
+    const double2* __restrict__ p = buf + wg * chunk + threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+    for (int r = 0; r < reps; ++r) {
+        for (int64_t i = 0; i < chunk; i += PBS * 8) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (nt) {
+                    const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p + i + u * PBS));
+                    v[u] = make_double2(t.x, t.y);
+                } else {
+                    v[u] = p[i + u * PBS];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += v[u].x;
+                s1 += v[u].y;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s0 + s1 == 1.2345e-300) sink[0] = s0;                    // keeps the loads alive
+}
+
+template <int A2A>
+__global__ void __launch_bounds__(PBS) k_probe_exchange(PersistPcg a, int rounds, double* __restrict__ out) {
+    __shared__ double sm1[PBS / 64], bc[2];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = gridDim.x;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.slots, 0, G * 4 * 16, 0x00020000);
+    double acc = 0.0;
+    for (int r = 0; r < rounds; ++r) {
+        const double mine = (double)(blockIdx.x + r);
+        double total;
+        if (A2A) {
+            if (wave == 0) {
+                if (lane == 0) granule_store(srsrc, blockIdx.x, mine, (unsigned long long)r + 1);
+                double o[1];
+                const int op[1] = {0};
+                const bool okx = granule_sweep<1>(srsrc, 0, G, (unsigned long long)r + 1, a.spin_limit, o, op);
+                if (lane == 0) {
+                    bc[0] = o[0];
+                    if (!okx) s_fail = 1;
+                }
+            }
+            __syncthreads();
+            total = bc[0];
+            __syncthreads();
+        } else {
+            if (tid == 0) pst(a.part1 + (size_t)(r & 1) * G + blockIdx.x, mine);
+            if (!grid_barrier(a, (unsigned)r, &s_fail)) break;
+            double ps = 0.0;
+            for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(r & 1) * G + k);
+            ps = wave_sum(ps);
+            __syncthreads();
+            if (lane == 0) sm1[wave] = ps;
+            __syncthreads();
+            total = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
+        }
+        if (s_fail) break;
+        acc += total;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        out[0] = acc;
+        out[1] = s_fail ? -1.0 : 0.0;
+    }
+}
+
+int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
+    const int64_t need = 2 * npad + 2 * G + 4 * G + 8 * G + 160;  // + granules (4 G x 16 B) + 8 x 32 + 32 counters
+    if (!c->d_persist || c->persist_cap < need) {
+        if (c->d_persist) (void)hipFree(c->d_persist);
+        c->d_persist = nullptr;
+        c->persist_cap = need;
+        FEMCY_HIP(hipMalloc((void**)&c->d_persist, sizeof(double) * need));
+    }
+    a->dbuf = c->d_persist;
+    a->part1 = c->d_persist + 2 * npad;
+    a->part2 = a->part1 + 2 * G;
+    a->slots = a->part2 + 4 * G;
+    a->xc = reinterpret_cast<unsigned int*>(a->slots + 8 * G);
+    a->top = a->xc + 8 * 32;
+    a->spin_limit = c->barrier_spin_limit;
+    a->dbg = c->opt_persist_dbg;
+    // granules and counters start at zero (tags / rounds count from 1)
+    FEMCY_HIP(hipMemsetAsync(a->slots, 0, sizeof(double) * 8 * G + sizeof(unsigned int) * (8 * 32 + 32), c->stream));
+    return FEMCY_OK;
+}
+
 }  // namespace
+
+// default variant of the persistent kernel (FEMCY_TUNE_PERSIST_VARIANT = -1), chosen by the round-3 measurements
+// 
+#ifndef FEMCY_PERSIST_DEFAULT_VARIANT
+#define FEMCY_PERSIST_DEFAULT_VARIANT 0
+#endif
 
 // eligibility + launch; *handled = false when the system does not qualify (too small, too large, multi-rank)
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
@@ -457,7 +803,6 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     // every wave gets its slices (<= 4), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
     // synchronisation per iteration exceed the (graph-replayed) three-launch iteration (size sweep in DESIGN.md)
     if (maxrange > 4 * nwx || c->nslices < G || (c->nslices < G + G / 2 && c->opt_persist < 2)) return FEMCY_OK;
-    const int64_t npad = (c->n + 1) & ~(int64_t)1;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
     const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
@@ -472,18 +817,21 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     const int64_t resident = (int64_t)G * 4 * (SPW * rj + lds_rows) * row_bytes;   // upper bound (short slices hold less)
     if (kbytes - resident > c->persist_max_bytes && c->opt_persist < 2) return FEMCY_OK;
     const size_t lds = (size_t)4 * lds_rows * 64 * (DD * 8 + 4) + 16;
-    const int64_t need = 2 * npad + 2 * G + 4 * G + 160;          // + 8 x 32 + 32 barrier counters (4 bytes each)
-    if (!c->d_persist || c->persist_cap < need) {
-        if (c->d_persist) (void)hipFree(c->d_persist);
-        c->d_persist = nullptr;
-        c->persist_cap = need;
-        FEMCY_HIP(hipMalloc((void**)&c->d_persist, sizeof(double) * need));
+    const int var = c->opt_persist_variant < 0 ? FEMCY_PERSIST_DEFAULT_VARIANT : c->opt_persist_variant;
+    const bool wide = (var & V_WIDE) != 0, a2a = (var & V_A2A) != 0;
+    // d in storage order covers the padding lanes of the last slice as well
+    const int64_t npad = wide ? (((int64_t)c->nslices * SLICE * c->dm + 1) & ~(int64_t)1) : ((c->n + 1) & ~(int64_t)1);
+    PersistPcg a;
+    {
+        int rc = persist_buffers(c, G, npad, &a);
+        if (rc) return rc;
     }
     // slices of each wave: XCD k's waves share the slice range xcd[k] .. xcd[k+1] (the ranges are balanced by stored
     // block rows); inside it the slices go longest first to the wave with the least rows so far (LPT) -- the sigma-
-    // sorted windows would otherwise hand all long slices to the same waves
+    // sorted windows would otherwise hand all long slices to the same waves.  Tagged-granule form: wave 0 of every
+    // workgroup sweeps the granules and does not prefetch, so it starts with a handicap of one batch
     {
-        std::vector<int64_t> key = {G, SPW, c->pattern_serial};
+        std::vector<int64_t> key = {G, SPW, c->pattern_serial, a2a ? 1 : 0};
         for (int k = 0; k <= PNX; ++k) key.push_back(c->xcd.start[k]);
         if (key != c->persist_assign_key || !c->d_persist_assign) {
             std::vector<int32_t> assign((size_t)PNX * nwx * SPW, -1);
@@ -493,7 +841,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
                 for (int32_t s = c->xcd.start[k]; s < c->xcd.start[k + 1]; ++s) order.push_back(s);
                 std::stable_sort(order.begin(), order.end(),
                                  [&](int32_t x, int32_t y) { return c->h_slice_len[x] > c->h_slice_len[y]; });
-                std::fill(load.begin(), load.end(), 0);
+                for (int w = 0; w < nwx; ++w) load[w] = (a2a && (w % 4) == 0) ? CH : 0;
                 std::fill(cnt.begin(), cnt.end(), 0);
                 for (int32_t s : order) {
                     int best = -1;
@@ -512,44 +860,182 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
             c->persist_assign_key = key;
         }
     }
-    PersistPcg a;
+    if (wide && (c->bcolp_serial != c->pattern_serial || !c->d_bcolp)) {
+        if (c->d_bcolp) (void)hipFree(c->d_bcolp);
+        c->d_bcolp = nullptr;
+        const int64_t nb = c->stored_rows * SLICE;
+        FEMCY_HIP(hipMalloc((void**)&c->d_bcolp, std::max<int64_t>(nb, 1) * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_bcol_to_pos, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb,
+                           (const int32_t*)c->d_bcol, (const int32_t*)c->d_pos, c->d_bcolp);
+        FEMCY_HIP(hipGetLastError());
+        c->bcolp_serial = c->pattern_serial;
+    }
     a.assign = c->d_persist_assign;
-    a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = c->d_bcol; a.node_of = c->d_node_of;
+    a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = wide ? c->d_bcolp : c->d_bcol; a.node_of = c->d_node_of;
     a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
-    a.dbuf = c->d_persist;
-    a.part1 = c->d_persist + 2 * npad;
-    a.part2 = a.part1 + 2 * G;
-    a.xc = reinterpret_cast<unsigned int*>(a.part2 + 4 * G);
-    a.top = a.xc + 8 * 32;
     a.st = c->d_state;
-    a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps; a.dbg = c->opt_persist_dbg;
-    FEMCY_HIP(hipMemsetAsync(a.xc, 0, sizeof(unsigned int) * (8 * 32 + 32), c->stream));
-#define FEMCY_PERSIST(DM_, SPW_, RJ_)                                                                             \
+    a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
+    size_t tp = (size_t)-1;
+#define FEMCY_PERSIST(DM_, SPW_, RJ_, VAR_)                                                                       \
     do {                                                                                                          \
-        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_>);                           \
+        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_, VAR_>);                     \
         if (lds > 48 * 1024)                                                                                      \
             FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_>), dim3(G), dim3(PBS), lds, c->stream, a);               \
+        if (!coresident(c, fn, PBS, lds, G)) return FEMCY_OK;   /* the grid barrier needs all G workgroups resident */ \
+        tp = timing_begin(c, T_PERSIST);                                                                          \
+        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_, VAR_>), dim3(G), dim3(PBS), lds, c->stream, a);         \
     } while (0)
-    const size_t tp = timing_begin(c, T_PERSIST);
+#ifdef FEMCY_PERSIST_ALL_VARIANTS
+#define FEMCY_PERSIST_V(DM_, SPW_, RJ_)                                                                           \
+    switch (var & 7) {                                                                                            \
+        case 0: FEMCY_PERSIST(DM_, SPW_, RJ_, 0); break;                                                          \
+        case 1: FEMCY_PERSIST(DM_, SPW_, RJ_, 1); break;                                                          \
+        case 2: FEMCY_PERSIST(DM_, SPW_, RJ_, 2); break;                                                          \
+        case 3: FEMCY_PERSIST(DM_, SPW_, RJ_, 3); break;                                                          \
+        case 4: FEMCY_PERSIST(DM_, SPW_, RJ_, 4); break;                                                          \
+        case 5: FEMCY_PERSIST(DM_, SPW_, RJ_, 5); break;                                                          \
+        case 6: FEMCY_PERSIST(DM_, SPW_, RJ_, 6); break;                                                          \
+        default: FEMCY_PERSIST(DM_, SPW_, RJ_, 7); break;                                                         \
+    }
+#else
+    // the shipped library carries the default variant and the round-2 form (0) of every shape
+#define FEMCY_PERSIST_V(DM_, SPW_, RJ_)                                                                           \
+    if ((var & 7) == FEMCY_PERSIST_DEFAULT_VARIANT) FEMCY_PERSIST(DM_, SPW_, RJ_, FEMCY_PERSIST_DEFAULT_VARIANT); \
+    else if ((var & 7) == 0) FEMCY_PERSIST(DM_, SPW_, RJ_, 0);                                                    \
+    else { set_error("persistent PCG variant %d is not in this build (default %d, 0; all with "                   \
+                     "-DFEMCY_PERSIST_ALL_VARIANTS)", var, FEMCY_PERSIST_DEFAULT_VARIANT); return FEMCY_EINVAL; }
+#endif
     // register-resident block rows per slice: what 512 VGPRs per lane hold next to the vectors and the streaming
     // buffers (dm 3: 5 rows x 3 slices or 3 rows x 4 slices of 19 registers each)
+#ifdef FEMCY_PERSIST_ONLY_334     // compile-time experiments: one shape only
+    if (c->dm == 3 && SPW == 3 && c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) } else return FEMCY_OK;
+#else
     if (c->dm == 3 && SPW == 3) {
-        if (c->opt_persist_rj == 5) FEMCY_PERSIST(3, 3, 5);
-        else if (c->opt_persist_rj == 4) FEMCY_PERSIST(3, 3, 4);
-        else FEMCY_PERSIST(3, 3, 0);
+        if (c->opt_persist_rj == 5) { FEMCY_PERSIST_V(3, 3, 5) }
+        else if (c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) }
+        else { FEMCY_PERSIST_V(3, 3, 0) }
     } else if (c->dm == 3) {
-        if (c->opt_persist_rj) FEMCY_PERSIST(3, 4, 3); else FEMCY_PERSIST(3, 4, 0);
+        if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
     } else if (SPW == 3) {
-        if (c->opt_persist_rj) FEMCY_PERSIST(2, 3, 5); else FEMCY_PERSIST(2, 3, 0);
+        if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }
     } else {
-        if (c->opt_persist_rj) FEMCY_PERSIST(2, 4, 5); else FEMCY_PERSIST(2, 4, 0);
+        if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 4, 5) } else { FEMCY_PERSIST_V(2, 4, 0) }
     }
+#endif
+#undef FEMCY_PERSIST_V
 #undef FEMCY_PERSIST
     timing_end(c, tp);
     FEMCY_HIP(hipGetLastError());
     *handled = true;
     return FEMCY_OK;
+}
+
+// ---- ceiling probes (femcy_probe_stream / femcy_probe_exchange)
+// mode 0: the persistent kernel's launch shape (one workgroup of four waves per CU); mode 1: the same with
+// non-temporal loads; mode 2: 8 workgroups per CU (what the chip streams at full occupancy); mode 3: mode 2 + nt
+int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass, int64_t* bytes_per_pass) {
+    FEMCY_REQUIRE(bytes >= (1 << 20) && reps >= 1 && mode >= 0 && mode <= 3, "probe_stream: bytes >= 1 MiB, reps >= 1, mode 0..3");
+    const int per_cu = mode >= 2 ? 8 : 1;
+    const int G = (c->persist_cus / PNX) * PNX * per_cu;
+    FEMCY_REQUIRE(G >= PNX, "device reports %d compute units", c->persist_cus);
+    const int64_t n16 = bytes / 16;
+    const int64_t chunk = (n16 / G) & ~(int64_t)(PBS * 8 - 1);
+    FEMCY_REQUIRE(chunk > 0, "probe_stream: %lld bytes are less than one tile per workgroup", (long long)bytes);
+    if (!c->d_probe || c->probe_cap < bytes) {
+        if (c->d_probe) (void)hipFree(c->d_probe);
+        c->d_probe = nullptr;
+        c->probe_cap = bytes;
+        FEMCY_HIP(hipMalloc((void**)&c->d_probe, (size_t)bytes + 64));
+        FEMCY_HIP(hipMemsetAsync(c->d_probe, 0, (size_t)bytes, c->stream));
+    }
+    const size_t lds = per_cu == 1 ? (size_t)(c->small_max_lds - 1024) : 0;   // one workgroup per CU, as the solver
+    const void* fn = reinterpret_cast<const void*>(&k_probe_stream);
+    if (lds > 48 * 1024) FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    FEMCY_HIP(hipEventCreate(&e0));
+    FEMCY_HIP(hipEventCreate(&e1));
+    const int nt = mode & 1;
+    hipLaunchKernelGGL(k_probe_stream, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, 2, nt, c->d_part1);
+    FEMCY_HIP(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_probe_stream, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, (int)reps, nt, c->d_part1);
+    FEMCY_HIP(hipEventRecord(e1, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    FEMCY_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    FEMCY_HIP(hipGetLastError());
+    *us_per_pass = (double)ms * 1e3 / reps;
+    if (bytes_per_pass) *bytes_per_pass = chunk * G * 16;
+    return FEMCY_OK;
+}
+
+// one grid-wide exchange of an 8-byte value per workgroup (publish, synchronise, every workgroup sums all G), in the
+// solver's launch shape; form 0 = counters + data (grid_barrier), 1 = tagged granules
+int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange) {
+    FEMCY_REQUIRE(rounds >= 1 && rounds <= (1 << 20) && (form == 0 || form == 1), "probe_exchange: rounds 1..2^20, form 0 / 1");
+    const int G = (c->persist_cus / PNX) * PNX;
+    FEMCY_REQUIRE(G >= PNX, "device reports %d compute units", c->persist_cus);
+    PersistPcg a{};
+    int rc = persist_buffers(c, G, 2, &a);
+    if (rc) return rc;
+    const size_t lds = (size_t)(c->small_max_lds - 1024);
+    const void* fn = form ? reinterpret_cast<const void*>(&k_probe_exchange<1>) : reinterpret_cast<const void*>(&k_probe_exchange<0>);
+    if (lds > 48 * 1024) FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FEMCY_REQUIRE(coresident(c, fn, PBS, lds, G), "probe_exchange: %d workgroups cannot be co-resident", G);
+    hipEvent_t e0, e1;
+    FEMCY_HIP(hipEventCreate(&e0));
+    FEMCY_HIP(hipEventCreate(&e1));
+    double us[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {                      // rounds and 2 x rounds: the difference is launch-free
+        const int r = rounds * (pass + 1);
+        if ((rc = persist_buffers(c, G, 2, &a))) return rc;
+        FEMCY_HIP(hipEventRecord(e0, c->stream));
+        if (form) hipLaunchKernelGGL(k_probe_exchange<1>, dim3(G), dim3(PBS), lds, c->stream, a, r, c->d_part2);
+        else hipLaunchKernelGGL(k_probe_exchange<0>, dim3(G), dim3(PBS), lds, c->stream, a, r, c->d_part2);
+        FEMCY_HIP(hipEventRecord(e1, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        FEMCY_HIP(hipEventElapsedTime(&ms, e0, e1));
+        us[pass] = (double)ms * 1e3;
+        double res[2];
+        FEMCY_HIP(hipMemcpy(res, c->d_part2, sizeof(res), hipMemcpyDeviceToHost));
+        const double want = (double)r * (G * (G - 1) / 2.0) + (double)G * (r * (r - 1.0) / 2.0);
+        if (res[1] != 0.0 || res[0] != want) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            set_error("probe_exchange: form %d failed (flag %g, sum %.17g, expected %.17g)", form, res[1], res[0], want);
+            return FEMCY_EHIP;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    FEMCY_HIP(hipGetLastError());
+    *us_per_exchange = (us[1] - us[0]) / rounds;
+    return FEMCY_OK;
+}
+
+// bytes of the matrix the persistent kernel streams per iteration on this context (stored - register / LDS rows), 0
+// when the system would not take the persistent path
+int64_t persist_streamed_bytes(Ctx* c) {
+    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;
+    if (G < PNX || !c->have_pattern) return 0;
+    const int nwx = (G / PNX) * 4;
+    int32_t maxrange = 0;
+    for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
+    if (maxrange > 4 * nwx || c->nslices < G) return 0;
+    const int DD = c->dm * c->dm;
+    const int SPW = maxrange > 3 * nwx ? 4 : 3;
+    int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
+    lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
+    const int rj = c->dm == 3 ? (SPW == 3 ? c->opt_persist_rj : (c->opt_persist_rj ? 3 : 0)) : (c->opt_persist_rj ? 5 : 0);
+    const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
+    // every slice keeps min(L, rj) rows in registers, and the LDS rows of a wave are full whenever its slices have
+    // more rows than rj (true for every mesh that takes this path)
+    int64_t reg_rows = 0;
+    for (int32_t s = 0; s < c->nslices; ++s) reg_rows += std::min<int64_t>(c->h_slice_len[s], rj);
+    const int64_t lds_total = std::min<int64_t>((int64_t)G * 4 * lds_rows, c->stored_rows - reg_rows);
+    return (c->stored_rows - reg_rows - lds_total) * row_bytes;
 }
 
 }  // namespace femcy

@@ -116,7 +116,7 @@ enum femcy_option {
     FEMCY_OPT_OVERLAP = 9,      /* multi-rank PCG with the neighbour exchange: 1 (default) = the slices that hold interface
                                    nodes are multiplied first and their exchange runs on a second stream while the
                                    interior slices are multiplied; 0 = everything on one stream */
-    FEMCY_OPT_TANGENT = 7       /* what femcy_assemble_K assembles.  0 (default) = the reference's matrix: B^T C B
+    FEMCY_OPT_TANGENT = 7,      /* what femcy_assemble_K assembles.  0 (default) = the reference's matrix: B^T C B
                                    on the current configuration with the constant C (stiffnessMtrx.py:124-186).
                                    1 = the consistent tangent of femcy_internal_force: spatial elasticity tensor of
                                    the material at F (the updates the reference left commented out,
@@ -124,6 +124,38 @@ enum femcy_option {
                                    An EXTENSION outside the parity runs: Newton iterates differ from the
                                    reference's (they converge quadratically).  Isotropic 3-D, plane-strain and
                                    neo-Hookean materials; not available for plane stress. */
+
+    /* ---- tuning and test knobs.  Not needed by a caller of the path; the tests and the tools under tools/ use them
+     * to force code paths and to measure alternatives.  None of them changes results beyond summation order. */
+    FEMCY_TUNE_TIMING_FENCE = 100,   /* 1 (default): an empty kernel precedes every SpMV dispatch that is timed with
+                                        dispatch-attached events, so that the start stamp is not taken while the
+                                        previous kernel drains                                                     */
+    FEMCY_TUNE_SPMV_WG_PER_XCD = 101,/* SpMV workgroups per XCD (default 256; longer slice ranges are looped inside
+                                        the kernel; 1 forces that loop on small meshes)                            */
+    FEMCY_TUNE_SPMV_NT = 102,        /* SpMV matrix stream non-temporal: -1 auto (stored matrix > 256 MiB), 0, 1    */
+    FEMCY_TUNE_VEC_NT = 103,         /* PCG vector kernels non-temporal: -1 auto (vector > 12 MB), 0, 1             */
+    FEMCY_TUNE_PERSIST_LDS_ROWS = 104,/* persistent PCG: block rows per wave kept in LDS (-1 = as many as fit)      */
+    FEMCY_TUNE_PERSIST_REG_ROWS = 105,/* persistent PCG: block rows per slice kept in registers (0, 4 or 5)         */
+    FEMCY_TUNE_PERSIST_PROBE = 106,  /* persistent PCG: 16 = no prefetch during the barriers.  Bits 0-3 (skip the
+                                        streamed / LDS / register rows, skip the barrier wait: timing experiments
+                                        that produce meaningless numbers) are accepted only by a library built with
+                                        -DFEMCY_PERSIST_PROBE; the shipped library has no work-skipping path       */
+    FEMCY_TUNE_PERSIST_WGS = 107,    /* persistent PCG: workgroups of the launch (0 = one per CU).  More than the
+                                        occupancy query admits is refused before the launch; see femcy_pcg          */
+    FEMCY_TUNE_SMALL_REG_ROWS = 108, /* small-system PCG: block rows per wave kept in registers (-1 = its share)    */
+    FEMCY_TUNE_PERSIST_VARIANT = 109,/* persistent PCG variant bits (-1 = the default chosen by measurement, DESIGN.md
+                                        section 3): 1 = alternate the sweep direction of the streamed block rows on
+                                        odd iterations (tail re-read from L2), 2 = the three grid-wide exchanges as
+                                        tagged granules (one hop) instead of counters + data, 4 = d published in
+                                        storage order (16 + 8 byte gathers instead of 3 x 8).  The shipped library
+                                        holds the default and 0 (round 2); all eight with -DFEMCY_PERSIST_ALL_VARIANTS */
+    FEMCY_TUNE_SPMV_KEEP = 110,      /* NT SpMV: per-mille of every XCD's slice range that keeps the default cache
+                                        policy (-1 auto = 235 MB of the matrix)                                     */
+    FEMCY_TUNE_SKIP_OCCUPANCY_CHECK = 111,/* 1 = launch the persistent kernels without the co-residency check (tests
+                                        of the barrier time-out and its fallback)                                   */
+    FEMCY_TUNE_BARRIER_SPIN_LIMIT = 112 /* polls (each ~0.3-1 us) before a grid barrier of the one-launch solvers gives
+                                        up, poisons the exchange and the solve is redone by the three-kernel loop
+                                        (default 2^20, about half a second; 0 provokes the fallback: tests)         */
 };
 
 typedef struct femcy_pattern_info {
@@ -147,6 +179,8 @@ typedef struct femcy_timing_t {
     double persist_ms;   int64_t persist_launches;   /* one-launch PCG (k_pcg_persist) alone  */
     int64_t persist_iters;                           /* CG iterations inside those launches   */
     int64_t solves_three, solves_small, solves_persist; /* PCG solves by path (always counted) */
+    int64_t barrier_timeouts;                        /* one-launch solves abandoned at a grid barrier and redone by
+                                                        the three-kernel loop (always counted)              */
 } femcy_timing_t;
 
 /* ------------------------------------------------------------------ life cycle / diagnostics */
@@ -255,6 +289,23 @@ int femcy_get_K_bsr(femcy_ctx* ctx, int32_t* rowptr, int32_t* colidx, double* va
 int femcy_get_gp_field(femcy_ctx* ctx, int which, double* out);
 int femcy_timing(femcy_ctx* ctx, femcy_timing_t* out);
 int femcy_timing_reset(femcy_ctx* ctx);
+
+/* ----------------------------------------------------- ceilings of the device (bench.py's roofline) */
+/* What the one-launch PCG runs against, measured with the kernel's own launch shape and exchange code:
+ * femcy_probe_stream: a read-only sweep of `bytes` (>= 1 MiB), `reps` passes inside one launch after a warm-up
+ *   launch, 16-byte loads, XCD-contiguous ranges.  mode 0 = one workgroup of four waves per CU (the persistent
+ *   kernel's shape), 1 = the same with non-temporal loads, 2 = eight workgroups per CU, 3 = mode 2 non-temporal.
+ *   A buffer below ~200 MB is served by the Infinity Cache from the second pass on, a larger one by HBM.
+ *   us_per_pass = microseconds per pass, bytes_per_pass = the bytes one pass reads (whole tiles only).
+ * femcy_probe_exchange: one grid-wide exchange of an 8-byte value per workgroup (publish, synchronise, every
+ *   workgroup sums all of them), averaged over `rounds` inside one launch.  form 0 = per-XCD counters + top counter
+ *   + data (FEMCY_TUNE_PERSIST_VARIANT without bit 1), 1 = tagged 16-byte granules (bit 1).  The sums are checked.
+ * femcy_persist_streamed_bytes: bytes of the matrix the persistent PCG streams per iteration on this context (stored
+ *   block rows less the register- and LDS-resident ones), 0 when the system does not fit that kernel. */
+int femcy_probe_stream(femcy_ctx* ctx, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass,
+                       int64_t* bytes_per_pass /* nullable */);
+int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* us_per_exchange);
+int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes);
 
 /* ------------------------------------------------------------------- multi-GPU (new work) */
 /* 128-byte ncclUniqueId produced on rank 0 and broadcast by the host program */

@@ -57,6 +57,11 @@ class MockContext:
 
     def comm_init(self, rank, nranks, uid, iface_local_dofs, iface_global_slot, niface_global, owner):
         assert uid == b"\x07" * 128 and len(owner) == self.n
+        if os.environ.get("FEMCY_MOCK_FAIL_RANK") == str(rank):     # test hook: one rank dies during set-up
+            raise RuntimeError(f"mock failure on rank {rank}")
+        if os.environ.get("FEMCY_MOCK_HANG_RANK") == str(rank):     # test hook: one rank never returns
+            import time
+            time.sleep(3600)
         from types import SimpleNamespace
         self.part = SimpleNamespace(iface_local_dofs=np.asarray(iface_local_dofs), iface_global_slot=np.asarray(iface_global_slot),
                                     niface_global=niface_global, owner=np.asarray(owner))
@@ -127,7 +132,7 @@ class MockContext:
         return {"geom_ms": 1.0, "geom_launches": 1, "assemble_ms": 1.0, "assemble_launches": 1, "force_ms": 0.0,
                 "force_launches": 0, "spmv_ms": 1.0, "spmv_launches": 1, "pcg_ms": 1.0, "pcg_iters": 1,
                 "persist_ms": 0.0, "persist_launches": 0, "persist_iters": 0, "solves_three": 1, "solves_small": 0,
-                "solves_persist": 0}
+                "solves_persist": 0, "barrier_timeouts": 0}
 
     def sync(self):
         pass
@@ -168,3 +173,44 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     assert d["value"] > 0 and d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2 and d["dtype"] == "f64"
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
     assert int(np.load(tmp_path / "uid0.npy")[0]) == 1 and int(np.load(tmp_path / "uid1.npy")[0]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+def _self_launch(extra_env, timeout=600, extra_args=()):
+    """`python bench.py --gpus 2` exactly as README.md types it -- no launcher, no WORLD_SIZE -- with the CPU test hooks
+    (gloo, the mock Context above) handed down through the environment"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FEMCY_BENCH_DIST_BACKEND="gloo", FEMCY_BENCH_DEVICE="cpu",
+               FEMCY_BENCH_MOCK="test_bench_multirank_cpu:MockContext",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, env.get("PYTHONPATH", "")]))
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                           "--iters", "4", "--cells", "4,2,6", "--no-cpu-baseline", "--prewarm", "0", *extra_args],
+                          capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_bench_self_launches_its_ranks():
+    out = _self_launch({})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["launcher"] == "self-launched torch.distributed.run"
+    assert d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2
+
+
+def test_bench_self_launch_reports_a_failed_rank():
+    out = _self_launch({"FEMCY_MOCK_FAIL_RANK": "1"})
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_bench_self_launch_times_out_on_a_hung_rank():
+    """a rank that never returns from the communicator set-up: the per-phase watchdog ends it (exit code 3), the
+    launcher tears the job down, the command returns non-zero within seconds instead of hanging the driver"""
+    import time
+    t = time.time()
+    out = _self_launch({"FEMCY_MOCK_HANG_RANK": "1"}, extra_args=("--comm-timeout", "8"))
+    assert out.returncode != 0 and time.time() - t < 240
+    assert "did not finish within" in out.stderr

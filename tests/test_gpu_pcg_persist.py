@@ -141,6 +141,13 @@ def test_barrier_timeout_falls_back_to_the_three_kernel_loop(plate):
     (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 12)
     ctx.set_option(be.OPT_PCG_PERSIST, 2)
     ctx.set_option(107, 512)
+    # with the co-residency check (round 3) the over-sized grid is refused BEFORE the launch: three launches, no time-out
+    before = _paths(ctx)
+    (itc, r0c, rmc), xc = _solve(ctx, be, 0.0, 12)
+    after = _paths(ctx)
+    assert (after[0] - before[0], after[2] - before[2]) == (1, 0) and ctx.timing()["barrier_timeouts"] == 0
+    assert (itc, r0c, rmc) == (it0, r00, rm0) and np.array_equal(xc, x0)
+    ctx.set_option(be.TUNE_SKIP_OCCUPANCY_CHECK, 1)                     # ... and without the check it times out
     try:
         before = _paths(ctx)
         (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 12)
@@ -149,7 +156,9 @@ def test_barrier_timeout_falls_back_to_the_three_kernel_loop(plate):
         assert (it1, r01, rm1) == (it0, r00, rm0) and np.array_equal(x1, x0)
         (it2, _, _), x2 = _solve(ctx, be, 0.0, 12)                      # no second attempt (no second time-out)
         assert _paths(ctx)[0] - after[0] == 1 and np.array_equal(x2, x0)
+        assert ctx.timing()["barrier_timeouts"] == 1
     finally:
+        ctx.set_option(be.TUNE_SKIP_OCCUPANCY_CHECK, 0)
         ctx.set_option(107, 0)                                          # also clears the "failed once" mark
     before = _paths(ctx)
     _solve(ctx, be, 0.0, 12)
@@ -211,3 +220,119 @@ def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
     assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= 1e-11 * rm0
     assert np.linalg.norm(x1 - x0) <= 1e-11 * np.linalg.norm(x0)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+@pytest.mark.parametrize("var", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_persistent_pcg_variants_agree(plate, var):
+    """FEMCY_TUNE_PERSIST_VARIANT: sweep direction, exchange form and the order in which d is published change the
+    order of partial sums and nothing else -- iterates agree with the round-2 form to rounding, the converged solution
+    solves the system, a solve is bit-reproducible.  The shipped library holds the default variant and 0; the others
+    run when FEMCY_HIP_LIB points at a -DFEMCY_PERSIST_ALL_VARIANTS build."""
+    be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
+    ctx.set_option(be.TUNE_PERSIST_VARIANT, 0)
+    ref = [_solve(ctx, be, 0.0, k) for k in (1, 8, 25)]
+    ctx.set_option(be.TUNE_PERSIST_VARIANT, var)
+    try:
+        before = _paths(ctx)
+        try:
+            got = [_solve(ctx, be, 0.0, k) for k in (1, 8, 25)]
+        except be.FemcyError as e:
+            if "not in this build" in str(e):
+                pytest.skip(str(e))
+            raise
+        for ((it0, r00, rm0), x0), ((it1, r01, rm1), x1), tol in zip(ref, got, (1e-13, 1e-12, 1e-11)):
+            assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+            assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+        (it, r0, rm), x = _solve(ctx, be, 1e-9, 10 ** 6)
+        assert rm < 1e-9 * r0 and np.abs(K @ x - bb).max() < 2.1e-9 * r0
+        (it2, _, rm2), x2 = _solve(ctx, be, 1e-9, 10 ** 6)
+        assert it2 == it and rm2 == rm and np.array_equal(x2, x)
+        assert _paths(ctx)[2] - before[2] == 5 and ctx.timing()["barrier_timeouts"] == 0
+        # edge cases through this variant's exchanges: b = 0, NaN
+        ctx.vector(be.VEC_RESIDUAL).fill(0.0)
+        it, r0, rm = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        assert it == 0 and r0 == 0.0 and not ctx.download(be.VEC_X).any()
+        bad = bb.copy()
+        bad[7] = np.nan
+        ctx.upload(be.VEC_RESIDUAL, bad)
+        with pytest.raises(be.FemcyError) as ei:
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        assert ei.value.status == be.FEMCY_ENUMERIC
+    finally:
+        ctx.upload(be.VEC_RESIDUAL, bb)
+        ctx.set_option(be.TUNE_PERSIST_VARIANT, -1)
+
+
+@pytest.mark.parametrize("var", [0, 2])
+def test_exchange_timeout_of_every_form_falls_back(plate, var):
+    """a spin limit of 0 makes the first exchange of the launch give up (some workgroup always polls before the last
+    one has arrived): the poison reaches every workgroup through the form's own channel (top counter / granule tags),
+    the solve is redone by the three-kernel loop, the context stops trying"""
+    be, ctx = plate["be"], plate["ctx"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 0)
+    (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 12)
+    ctx.set_option(be.OPT_PCG_PERSIST, 2)
+    ctx.set_option(be.TUNE_PERSIST_VARIANT, var)
+    ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 0)
+    try:
+        t0 = ctx.timing()["barrier_timeouts"]
+        before = _paths(ctx)
+        try:
+            (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 12)
+        except be.FemcyError as e:
+            if "not in this build" in str(e):
+                pytest.skip(str(e))
+            raise
+        after = _paths(ctx)
+        assert (after[0] - before[0], after[2] - before[2]) == (1, 0)
+        assert ctx.timing()["barrier_timeouts"] == t0 + 1
+        assert (it1, r01, rm1) == (it0, r00, rm0) and np.array_equal(x1, x0)
+    finally:
+        ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 1 << 20)             # also clears the "failed once" marks
+        ctx.set_option(be.TUNE_PERSIST_VARIANT, -1)
+    before = _paths(ctx)
+    _solve(ctx, be, 0.0, 12)
+    assert _paths(ctx)[2] - before[2] == 1
+
+
+def test_small_system_pcg_timeout_falls_back(gpu_ctx_factory):
+    """k_pcg_small's grid barrier has the poison-on-time-out protocol of the persistent kernel; a
+    time-out is not an error any more -- the three-kernel loop redoes the solve and the context remembers"""
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    m = meshgen.twist_plate(8, 2, 12)
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_linear_tetrahedral())
+    assert info.nslices <= 128 and ctx.n <= 12288
+    (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 15)
+    assert _paths(ctx)[1] == 1                                          # the one-launch small-system kernel ran
+    ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 0)
+    (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 15)
+    p = _paths(ctx)
+    assert p[0] == 1 and p[1] == 1 and ctx.timing()["barrier_timeouts"] == 1
+    assert it1 == it0 and r01 == r00 and abs(rm1 - rm0) <= 1e-10 * rm0
+    assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+    _solve(ctx, be, 0.0, 15)                                            # remembered: no second attempt
+    assert _paths(ctx)[0] == 2 and ctx.timing()["barrier_timeouts"] == 1
+    ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 1 << 20)                 # clears the mark
+    _solve(ctx, be, 0.0, 15)
+    assert _paths(ctx)[1] == 2
+    ctx.close()
+
+
+def test_ceiling_probes(plate):
+    """femcy_probe_exchange checks its own sums (every workgroup must have seen every other's value in every round);
+    femcy_probe_stream returns a rate; femcy_persist_streamed_bytes is below the stored matrix"""
+    be, ctx = plate["be"], plate["ctx"]
+    for form in (0, 1):
+        us = ctx.probe_exchange(500, form)
+        assert 0.2 < us < 50.0, (form, us)
+        print(f"[probe] exchange form {form}: {us:.2f} us")
+    for mode in (0, 1, 2, 3):
+        gbs, moved = ctx.probe_stream(64 << 20, 10, mode)
+        assert moved > (60 << 20) and 500.0 < gbs < 40000.0, (mode, gbs, moved)
+        print(f"[probe] stream 64 MiB mode {mode}: {gbs:.0f} GB/s")
+    info = ctx.pattern_info()
+    sb = ctx.persist_streamed_bytes()
+    assert 0 <= sb < info.stored_blocks * 76
