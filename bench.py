@@ -733,14 +733,16 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
     co.zero_rows_cols_unit_diag(cons)
     f = co.internal_force(u, 0, *elastic)
     f[cons] = 0.0
+    # ~10 s of CG in solves of 100 iterations from x0 = 0 (a single long solve would run past convergence into
+    # denormal residuals, which cost the host cores up to 100x per operation and are not what the GPU step does either)
     co.cg(f, eps=0.0, maxit=3)
-    t = time.perf_counter()
-    co.cg(f, eps=0.0, maxit=10)
-    per_it = (time.perf_counter() - t) / 10
-    its = int(max(20, min(20000, 10.0 / per_it)))
-    t = time.perf_counter()
-    _, it, _, _ = co.cg(f, eps=0.0, maxit=its)
-    dt = time.perf_counter() - t
+    it, dt, chunk = 0, 0.0, 100
+    t_end = time.perf_counter() + 10.0
+    while time.perf_counter() < t_end:
+        t = time.perf_counter()
+        _, k, _, _ = co.cg(f, eps=0.0, maxit=chunk)
+        dt += time.perf_counter() - t
+        it += k
     # as-written bytes of one CG iteration: the ELL arrays (8 + 4 bytes per slot, padding included: the port reads
     # them) + 17 vector passes of 8 n bytes (SpMV + 136 n)
     bytes_it = co.n * co.W * 12 + 4 * co.n + 16 * co.n + 136 * co.n

@@ -163,6 +163,7 @@ struct Ctx {
     int opt_persist_rj = 4;           // block rows per slice kept in registers (test knob 105)
     int opt_persist_wgs = 0;          // test knob 107: workgroups of the launch (0 = one per CU; more than that cannot
                                       // be co-resident, the barrier times out and the solve falls back)
+    int opt_persist_l2rows = 1;       // FEMCY_TUNE_PERSIST_L2_ROWS: default-policy streamed rows per slice (VAR & 1)
     int opt_persist_variant = -1;     // FEMCY_TUNE_PERSIST_VARIANT bits (-1 = defaults)
     int opt_persist_dbg = 0;          // timing experiments only (test knob 106): skip parts of the iteration
     int opt_persist_lds = -1;         // block rows per wave kept in LDS (-1: as many as fit; test knob 104)

@@ -291,7 +291,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
     CTX_OR_FAIL(ctx);
     switch (option) {
         case FEMCY_OPT_ASSEMBLY:
-            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS2, "bad assembly mode %lld", (long long)value);
+            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS3, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
         case FEMCY_OPT_PCG_POLL:
@@ -354,6 +354,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value >= 0 && value <= (1ll << 30), "spin limit out of range");
             c->barrier_spin_limit = (uint32_t)value;
             c->persist_failed = c->small_failed = false;
+            break;
+        case FEMCY_TUNE_PERSIST_L2_ROWS:
+            FEMCY_REQUIRE(value >= 0 && value <= 64, "rows out of range");
+            c->opt_persist_l2rows = (int)value;
             break;
         case FEMCY_TUNE_PERSIST_VARIANT:
             FEMCY_REQUIRE(value >= -1 && value <= 7, "variant bits: -1 (default) or 0..7");

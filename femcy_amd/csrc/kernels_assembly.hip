@@ -943,6 +943,212 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
 #undef ROW_L
 }
 
+// row-centric assembly, third form (round 3): k_assemble_rows2 with the write-out of EIGHT adjacent rows at a time.
+// rows2 writes a finished row as 16-byte pieces, one per block entry pair, 1 KiB apart (the lane-interleaved SELL
+// layout is made for the product): every 128-byte line of K is touched by eight rows at eight different times, the
+// L2 fetches the line for the first partial write (read-for-fill) and often writes it back more than once --
+// profiles/r02_pmc_rows2_c3d10.txt: FETCH 563 MB + WRITE 515 MB for 357 MB of K + 123 MB of records.  Here wave w
+// of the workgroup takes rows 8 g + 2 w and 8 g + 2 w + 1 of group g (two accumulators per wave), the four waves meet
+// at the end of the group, and all 256 threads write the group: eight lanes x 16 bytes = one whole 128-byte line per
+// (block, entry pair), 64 bytes for the trailing entry plane -- no line is written twice, none is fetched.  Two
+// workgroup barriers per 8 rows (rows2's experiment with 4-row / 64-byte write-outs paid two per row).
+// Everything else (LDS-staged records, the three-deep software pipeline over passes, lanes = (element, column != row)
+// pairs, row-sum diagonal, 30-flop blocks for cubic C, fixed order => bit-reproducible) is rows2's.
+template <int NPE, int NGP, bool CUBIC>
+__global__ void __launch_bounds__(256) k_assemble_rows3(int32_t nslices, int32_t nn, int32_t Lmax,
+                                                        const int32_t* __restrict__ ne_ptr,
+                                                        const int32_t* __restrict__ ne_idx,
+                                                        const uint16_t* __restrict__ slotj,
+                                                        const int32_t* __restrict__ rowlen,
+                                                        const int32_t* __restrict__ node_of,
+                                                        const int64_t* __restrict__ slice_off,
+                                                        const double* __restrict__ dsdx, const double* __restrict__ vol,
+                                                        const double* __restrict__ C, double c11, double c12, double c44,
+                                                        double* __restrict__ Kvals) {
+    constexpr int DM = 3, DD = 9, T = NPE - 1, EPC = 64 / T, RD = NGP * NPE * DM, P16 = RD / 2;
+    constexpr int NIT = (EPC * P16 + 63) / 64;                   // 16-byte pieces per lane and pass (C3D10: 7)
+    constexpr int VOLW = (EPC * NGP + 1) & ~1, CODEW = (EPC + 1) / 2 * 2 / 2 + 1;
+    static_assert(RD % 2 == 0, "records are staged in 16-byte pieces");
+    static_assert(EPC * NGP <= 64, "one vol value per lane and pass");
+    extern __shared__ __attribute__((aligned(16))) double lds_rows3[];
+    __shared__ int32_t gL[8];                                    // row lengths of the group being written
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int accw = (Lmax * DD + 1) & ~1;
+    const int wstride = EPC * RD + VOLW + 2 * accw + 2 * CODEW;  // doubles per wave
+    double* rec = lds_rows3 + (size_t)wave * wstride;
+    double* vl = rec + EPC * RD;
+    double* acc0 = vl + VOLW;                                    // two row accumulators: rows 2 w and 2 w + 1 of a group
+    int32_t* codes = reinterpret_cast<int32_t*>(acc0 + 2 * accw);
+    const int32_t s = blockIdx.x;
+    if (s >= nslices) return;
+    const int64_t off = slice_off[s];
+    const int32_t nvalid = min(SLICE, nn - s * SLICE);           // valid rows are a prefix of the slice
+    const int ngroups = (nvalid + 7) / 8;
+
+    // ---- the wave's rows: its i-th row is slice lane 8 (i / 2) + 2 wave + (i % 2); lane i holds the metadata
+    constexpr int RPW = SLICE / 4;
+    int32_t m_L = 0, m_k0 = 0, m_cnt = 0;
+    bool m_valid = false;
+    if (lane < RPW) {
+        const int32_t a = node_of[(int64_t)s * SLICE + 8 * (lane >> 1) + 2 * wave + (lane & 1)];
+        if (a >= 0) {
+            m_valid = true;
+            m_L = rowlen[a];
+            m_k0 = ne_ptr[a];
+            m_cnt = ne_ptr[a + 1] - m_k0;
+        }
+    }
+    const int nrows = __popcll(__ballot(m_valid));               // valid rows are a prefix in i as well
+#define ROW_CNT(i) __builtin_amdgcn_readlane(m_cnt, (i))
+#define ROW_K0(i) __builtin_amdgcn_readlane(m_k0, (i))
+#define ROW_L(i) __builtin_amdgcn_readlane(m_L, (i))
+    auto advance = [&](int& i, int& c0) {
+        c0 += EPC;
+        if (i < nrows && c0 >= ROW_CNT(i)) {
+            ++i;
+            c0 = 0;
+        }
+    };
+    auto load_codes = [&](int i, int c0) -> int32_t {           // lane q: (element, local row node) code of element q
+        if (i >= nrows) return 0;
+        const int32_t nE = min(EPC, ROW_CNT(i) - c0);
+        return lane < nE ? ne_idx[ROW_K0(i) + c0 + lane] : 0;
+    };
+    double2 R[NIT];
+    double V = 0.0;
+    int32_t JS = 0;
+#define LOAD_RECORDS(code_, i_, c0_)                                                                  \
+    if ((i_) < nrows) {                                                                               \
+        const int32_t nE_ = min(EPC, ROW_CNT(i_) - (c0_));                                            \
+        _Pragma("unroll") for (int u = 0; u < NIT; ++u) {                                             \
+            const int32_t p_ = lane + 64 * u;                                                         \
+            const int32_t q_ = p_ / P16, w_ = p_ - q_ * P16;                                          \
+            const int64_t e_ = __shfl((code_), q_, 64) / NPE;                                         \
+            if (p_ < nE_ * P16) R[u] = reinterpret_cast<const double2*>(dsdx + e_ * RD)[w_];          \
+        }                                                                                             \
+        const int32_t qv_ = lane / NGP, gv_ = lane - qv_ * NGP;                                       \
+        const int64_t ev_ = __shfl((code_), qv_, 64) / NPE;                                           \
+        if (lane < nE_ * NGP) V = vol[ev_ * NGP + gv_];                                               \
+        const int32_t qt_ = lane / T, jb_ = lane - qt_ * T;                                           \
+        const int32_t ct_ = __shfl((code_), qt_, 64);                                                 \
+        const int32_t lat_ = ct_ % NPE;                                                               \
+        if (lane < nE_ * T) JS = slotj[(int64_t)ct_ * NPE + jb_ + (jb_ >= lat_ ? 1 : 0)];             \
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) R[u] = make_double2(0.0, 0.0);
+
+    int i0 = 0, c00 = 0, i1 = 0, c01 = 0, i2 = 0, c02 = 0;
+    advance(i1, c01);
+    i2 = i1;
+    c02 = c01;
+    advance(i2, c02);
+    int32_t code_c = load_codes(i0, c00);
+    int32_t code_n = load_codes(i1, c01);
+    LOAD_RECORDS(code_c, i0, c00)
+
+    for (int g = 0; g < ngroups; ++g) {
+        // both accumulators of the wave start at zero (the previous group has been written: second barrier below)
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * g + h;
+            if (i < nrows) {
+                double* acc = acc0 + h * accw;
+                for (int idx = lane; idx < ROW_L(i) * DD; idx += 64) acc[idx] = 0.0;
+            }
+        }
+        while (i0 < nrows && (i0 >> 1) == g) {
+            double* acc = acc0 + (i0 & 1) * accw;
+            const int32_t cnt = ROW_CNT(i0);
+            const int32_t nE = max(0, min(EPC, cnt - c00));
+            wave_lds_sync();                                        // the previous pass is done with rec / vl / codes
+            if (lane < nE) codes[lane] = code_c;
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int32_t p = lane + 64 * u;
+                const int32_t q = p / P16, w = p - q * P16;
+                if (p < nE * P16) reinterpret_cast<double2*>(rec + q * RD)[w] = R[u];
+            }
+            if (lane < nE * NGP) vl[lane] = V;
+            int32_t j = JS;
+            asm volatile("" : "+v"(j));     // consume JS here (see k_assemble_rows2)
+            LOAD_RECORDS(code_n, i1, c01)
+            const int32_t code_nn = load_codes(i2, c02);
+            wave_lds_sync();
+            if (lane < nE * T) {
+                const int32_t q = lane / T, jb = lane - q * T;
+                const int32_t code = codes[q];
+                const int32_t la = code % NPE;
+                const int32_t lb = jb + (jb >= la ? 1 : 0);         // every column node of the element but the row node
+                double blk[DD];
+#pragma unroll
+                for (int k = 0; k < DD; ++k) blk[k] = 0.0;
+#pragma unroll
+                for (int gp = 0; gp < NGP; ++gp) {
+                    const double* ga = rec + q * RD + (gp * NPE + la) * DM;
+                    const double* gb = rec + q * RD + (gp * NPE + lb) * DM;
+                    if (CUBIC) kblock_cubic3(ga, gb, c11, c12, c44, vl[q * NGP + gp], blk);
+                    else kblock_add<3>(ga, gb, C, vl[q * NGP + gp], blk);
+                }
+#pragma unroll
+                for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
+            }
+            if (c00 + EPC >= cnt) {                                 // last pass of the row: diagonal from the row sum
+                const int32_t L = ROW_L(i0);
+                wave_lds_sync();
+                if (lane < 63) {
+                    const int jj = lane / DD, k = lane - jj * DD;
+                    double t = 0.0;
+                    for (int32_t jx = 1 + jj; jx < L; jx += 7) t += acc[jx * DD + k];
+                    rec[lane] = t;
+                }
+                wave_lds_sync();
+                if (lane < DD) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 7; ++jj) t += rec[jj * DD + lane];
+                    acc[lane] = -t;
+                }
+                if (lane == 0) gL[2 * wave + (i0 & 1)] = L;
+            }
+            i0 = i1; c00 = c01;
+            i1 = i2; c01 = c02;
+            advance(i2, c02);
+            code_c = code_n;
+            code_n = code_nn;
+        }
+        // ---- the group's eight rows are complete: all threads write them, whole lines at a time
+        __syncthreads();
+        {
+            const int r8 = threadIdx.x & 7;                          // row of the group
+            const int rr = 8 * g + r8;                               // slice lane
+            const bool rv = rr < nvalid;
+            const int32_t Lr = rv ? gL[r8] : 0;
+            int32_t Lg = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Lg = max(Lg, (8 * g + q < nvalid) ? gL[q] : 0);
+            const double* accr = lds_rows3 + (size_t)(r8 >> 1) * wstride + (EPC * RD + VOLW) + (r8 & 1) * accw;
+            double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
+            for (int idx = threadIdx.x >> 3; idx < Lg * 5; idx += 32) {
+                const int j = idx / 5, pc = idx - j * 5;
+                double* dst = Krow + (int64_t)j * (DD * SLICE);
+                const bool has = j < Lr;                             // rows shorter than the group's longest: zero blocks
+                if (rv) {
+                    if (pc < 4) {
+                        reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[rr] =
+                            has ? make_double2(accr[j * DD + 2 * pc], accr[j * DD + 2 * pc + 1]) : make_double2(0.0, 0.0);
+                    } else {
+                        dst[4 * (2 * SLICE) + rr] = has ? accr[j * DD + 8] : 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef LOAD_RECORDS
+#undef ROW_CNT
+#undef ROW_K0
+#undef ROW_L
+}
+
 // scatter assembly with hardware f64 atomics: one lane per element-local (a,b) block
 template <int DM>
 __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t npe, int32_t nGP,
@@ -1509,6 +1715,33 @@ int launch_assemble(Ctx* c) {
         FEMCY_HIP(hipGetLastError());
         return FEMCY_OK;
     }
+    if (mode == FEMCY_ASM_ROWS3) {
+        FEMCY_REQUIRE(c->dm == 3 && c->dN_sums_to_zero && ((c->npe == 10 && c->nGP == 4) || (c->npe == 4 && c->nGP == 1)),
+                      "ROWS3 assembly is instantiated for C3D10 / C3D4 tables with sum_a dN_a = 0 (npe %d, nGP %d)", c->npe, c->nGP);
+        const int T = c->npe - 1, EPC = 64 / T, RD = c->nGP * c->npe * 3;
+        const int volw = (EPC * c->nGP + 1) & ~1, codew = (EPC + 1) / 2 * 2 / 2 + 1, accw = (c->max_row_blocks * 9 + 1) & ~1;
+        const size_t lds = (size_t)4 * (EPC * RD + volw + 2 * accw + 2 * codew) * sizeof(double);
+        if (lds + 512 > (size_t)c->small_max_lds) {
+            FEMCY_REQUIRE(c->opt_assembly == FEMCY_ASM_AUTO, "ROWS3 assembly needs %zu B of LDS per workgroup (longest row: %d "
+                          "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
+            mode = FEMCY_ASM_ROWS2;
+        }
+#define FEMCY_ROWS3(NPE_, NGP_, CUB_)                                                                                  \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows3<NPE_, NGP_, CUB_>),          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL((k_assemble_rows3<NPE_, NGP_, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices, \
+                           c->nn, c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,  \
+                           c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
+                           c->d_Kvals);                                                                                \
+    } while (0)
+        if (mode == FEMCY_ASM_ROWS3) {
+            if (c->npe == 10) { if (c->C_is_cubic) FEMCY_ROWS3(10, 4, true); else FEMCY_ROWS3(10, 4, false); }
+            else              { if (c->C_is_cubic) FEMCY_ROWS3(4, 1, true); else FEMCY_ROWS3(4, 1, false); }
+        }
+#undef FEMCY_ROWS3
+    }
     if (mode == FEMCY_ASM_ROWS2) {
         FEMCY_REQUIRE(c->dm == 3 && c->dN_sums_to_zero && ((c->npe == 10 && c->nGP == 4) || (c->npe == 4 && c->nGP == 1)),
                       "ROWS2 assembly is instantiated for C3D10 / C3D4 tables with sum_a dN_a = 0 (npe %d, nGP %d)", c->npe, c->nGP);
@@ -1538,7 +1771,7 @@ int launch_assemble(Ctx* c) {
         }
 #undef FEMCY_ROWS2
     }
-    if (mode == FEMCY_ASM_ROWS2) {
+    if (mode == FEMCY_ASM_ROWS2 || mode == FEMCY_ASM_ROWS3) {
     } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);

@@ -20,13 +20,18 @@
 //       - tagged granules (VAR & 2): every workgroup publishes {value, round} as ONE 16-byte sc1 store and one wave per
 //         workgroup sweeps all G granules until every tag shows the round -- barrier and exchange in one store
 //         latency + one load latency instead of store-ack + two atomics + poll + data load.
-// Round 3 variants (template parameter VAR, bits):
-//   1  the streamed block rows are swept in alternating direction on odd / even iterations: the tail of one sweep is
-//      the head of the next and is re-read from the XCD's 4 MiB L2 instead of the Infinity Cache;
+// Round 3 variants (template parameter VAR, bits; measurements in DESIGN.md section 3):
+//   1  the streamed block rows are loaded non-temporally, except the first `l2_rows` streamed rows of every slice, which
+//      keep the default policy: the stream is latency-bound at one wave per SIMD (femcy_probe_stream: 7.4 TB/s from the
+//      Infinity Cache in this launch shape against 24 TB/s at eight workgroups per CU), nt loads return sooner, and
+//      the default-policy rows are what stays in the XCD's 4 MiB L2 from one product to the next;
 //   2  tagged-granule synchronisation (above);
 //   4  d is published in STORAGE order (position = slice * 64 + lane) so that a lane's dm values are contiguous for
 //      the whole wave: one 16-byte + one 8-byte store / gather per node instead of three 8-byte ones (a third fewer
 //      texture-address cycles on the largest non-matrix item of the iteration).
+// Measured and dropped in round 3: sweeping the streamed rows in alternating direction on odd / even iterations (the
+// tail of one sweep re-read from L2 as the head of the next): +4.7 us per iteration -- two copies of the product loop
+// spill, and the reuse does not materialise.
 // Recurrence, preconditioner and stopping rule are those of pcg_solve / the reference
 // (conjugateGradientSolver.py:103-127); partial sums are combined in a fixed order, so a solve is bit-reproducible.
 // d is double-buffered by iteration parity (a wave may gather d_k while a faster one already publishes d_k+1), as are
@@ -53,7 +58,7 @@ namespace {
 constexpr int PBS = 256;        // 4 waves per workgroup, one workgroup per CU
 constexpr int PNX = 8;
 constexpr int CH = 4;         // block rows per batch of the LDS-resident and the streamed part
-constexpr int V_ALT = 1, V_A2A = 2, V_WIDE = 4;
+constexpr int V_NT = 1, V_A2A = 2, V_WIDE = 4;
 constexpr unsigned long long TAG_POISON = ~0ull;
 
 // Work-skipping switches for timing experiments (tools/persist_breakdown.py) exist only in a probe build
@@ -82,7 +87,7 @@ struct PersistPcg {
     unsigned int* xc;     // [8][32]     per-XCD arrival counters (one cache line apart)
     unsigned int* top;
     PcgState* st;
-    int32_t npad, maxit, lds_rows, dbg;
+    int32_t npad, maxit, lds_rows, dbg, l2_rows;
     uint32_t spin_limit;  // polls before a barrier gives up and poisons the exchange
     double eps;
 };
@@ -196,7 +201,7 @@ __device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, i
 template <int DM, int SPW, int RJ, int VAR>
 __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
-    constexpr bool ALT = (VAR & V_ALT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
+    constexpr bool NT = (VAR & V_NT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
     extern __shared__ __attribute__((aligned(16))) char lds_persist[];
     __shared__ double sm1[PBS / 64], sm2[PBS / 64], bc[2];
     __shared__ int s_fail;
@@ -310,20 +315,34 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     };
     // nb (<= CH) consecutive block rows of a slice: columns and values (rows beyond nb: the column of the last one,
     // so that its gather stays in range; no values)
+    // keep0 = first block row (of the slice) from which the loads are non-temporal (VAR & 1); rows below it keep the
+    // default policy
+    typedef double nt_d2 __attribute__((ext_vector_type(2)));
     auto load_rows = [&](const int32_t* __restrict__ bc_, const double2* __restrict__ vp, const double* __restrict__ vs,
-                         int32_t j, int nb, int32_t (&col)[CH], double (&e)[CH][DD]) {
+                         int32_t j, int nb, int32_t keep0, int32_t (&col)[CH], double (&e)[CH][DD]) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) col[u] = bc_[(int64_t)(j + max(0, min(u, nb - 1))) * 64];
 #pragma unroll
         for (int u = 0; u < CH; ++u)
             if (u < nb) {
+                if (NT && j + u >= keep0) {                                 // wave-uniform
 #pragma unroll
-                for (int kp = 0; kp < NP; ++kp) {
-                    const double2 v2 = vp[(int64_t)(j + u) * (DD * 32) + kp * 64];
-                    e[u][2 * kp] = v2.x;
-                    e[u][2 * kp + 1] = v2.y;
+                    for (int kp = 0; kp < NP; ++kp) {
+                        const nt_d2 v2 = __builtin_nontemporal_load(
+                            reinterpret_cast<const nt_d2*>(&vp[(int64_t)(j + u) * (DD * 32) + kp * 64]));
+                        e[u][2 * kp] = v2.x;
+                        e[u][2 * kp + 1] = v2.y;
+                    }
+                    if (DD & 1) e[u][DD - 1] = __builtin_nontemporal_load(&vs[(int64_t)(j + u) * (DD * 64)]);
+                } else {
+#pragma unroll
+                    for (int kp = 0; kp < NP; ++kp) {
+                        const double2 v2 = vp[(int64_t)(j + u) * (DD * 32) + kp * 64];
+                        e[u][2 * kp] = v2.x;
+                        e[u][2 * kp + 1] = v2.y;
+                    }
+                    if (DD & 1) e[u][DD - 1] = vs[(int64_t)(j + u) * (DD * 64)];
                 }
-                if (DD & 1) e[u][DD - 1] = vs[(int64_t)(j + u) * (DD * 64)];
             } else {
                 // defined on every path: a conditionally rewritten loop-carried buffer would keep its old value alive
                 // through the whole iteration (the prefetch buffer then costs 76 registers at the product's peak)
@@ -342,7 +361,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     int32_t pcol[CH];
     double pe[CH][DD];
     const int32_t jpf = npf > 0 ? je[0] : 0;                               // (npf = 0: row 0's column, unused)
-    load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
+    load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe);
     // ---- x0 = 0, r = b, d = M r
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
@@ -439,57 +458,36 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     int it = 0;
 
     // ---- Ad = K d for the wave's rows (d gathered with sc1 loads: the other XCDs wrote it with sc1 stores); returns
-    // the lane's part of d.Ad.  REV: slices and streamed rows in descending order (VAR & 1, odd iterations)
-    auto product = [&](const int32_t poff, auto rev_tag) -> double {
-        constexpr bool REV = decltype(rev_tag)::value;
+    // the lane's part of d.Ad
+    auto product = [&](const int32_t poff) -> double {
         double acc[SPW][DM];
 #pragma unroll
         for (int t = 0; t < SPW; ++t)
 #pragma unroll
             for (int r = 0; r < DM; ++r) acc[t][r] = 0.0;
-        // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points; it is
-        // multiplied first in either direction, so that its registers are free for the streaming loop
-        if (npf > 0 && !PDBG(a, 1)) {
-            double xg[CH][DM];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (u < npf) {
-#pragma unroll
-                    for (int r = 0; r < DM; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < DM; ++cc) acc[0][r] += pe[u][r * DM + cc] * xg[u][cc];
-                }
-        }
-#pragma unroll
-        for (int tt = 0; tt < SPW; ++tt) {
-            const int t = REV ? SPW - 1 - tt : tt;
+        for (int t = 0; t < SPW; ++t) {
             const int32_t L = Ls[t];
             const int32_t* __restrict__ bcp = a.bcol + offs[t] * 64 + lane;
             const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
             const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
-            const int32_t js = je[t] + ((t == 0) ? npf : 0);                 // first streamed block row of this sweep
-            // one batch of streamed block rows: columns, then the values, then the gathers, then the multiplies
-            auto batch = [&](int32_t j, int nb) {
-                int32_t col[CH];
-                double e[CH][DD], xg[CH][DM];
-                load_rows(bcp, vp, vs, j, nb, col, e);
+            int32_t j = je[t];                                               // first streamed block row
+            // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points
+            if (t == 0 && npf > 0 && !PDBG(a, 1)) {
+                double xg[CH][DM];
 #pragma unroll
-                for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
+                for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
-                    if (u < nb) {
+                    if (u < npf) {
 #pragma unroll
                         for (int r = 0; r < DM; ++r)
 #pragma unroll
-                            for (int cc = 0; cc < DM; ++cc) acc[t][r] += e[u][r * DM + cc] * xg[u][cc];
+                            for (int cc = 0; cc < DM; ++cc) acc[t][r] += pe[u][r * DM + cc] * xg[u][cc];
                     }
-            };
-            if (REV && !PDBG(a, 1))
-                for (int32_t j1 = L; j1 > js; j1 -= CH) batch(max(js, j1 - CH), min(CH, j1 - js));
+                j += npf;
+            }
             // block rows held in registers: their gathers are issued in batches before the first multiply
             if (RJ > 0 && !PDBG(a, 4)) {
                 constexpr int RB = RJ > 4 ? 3 : (RJ > 0 ? RJ : 1);               // rows per batch (register budget)
@@ -529,8 +527,25 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                                 acc[t][r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
                     }
             }
-            if (!REV && !PDBG(a, 1))
-                for (int32_t j = js; j < L; j += CH) batch(j, min(CH, L - j));
+            // streamed block rows, CH at a time: columns, then the values, then the gathers, then the multiplies
+            while (j < L && !PDBG(a, 1)) {
+                const int nb = min(CH, L - j);
+                int32_t col[CH];
+                double e[CH][DD], xg[CH][DM];
+                load_rows(bcp, vp, vs, j, nb, je[t] + a.l2_rows, col, e);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (u < nb) {
+#pragma unroll
+                        for (int r = 0; r < DM; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < DM; ++cc) acc[t][r] += e[u][r * DM + cc] * xg[u][cc];
+                    }
+                j += nb;
+            }
         }
         double dot = 0.0;
 #pragma unroll
@@ -543,12 +558,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         return dot;
     };
 
-    // one iteration; with VAR & 1 the loop below holds two copies of it (even: ascending sweep, odd: descending) --
-    // as two alternatives inside ONE loop body the register allocator spilled 350 bytes per lane
-    auto iteration = [&](auto rev_tag) {
+    auto iteration = [&]() {
         __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
         const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
-        double dot = product(poff, rev_tag);
+        double dot = product(poff);
         // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested inside the first
         // exchange (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
         // synchronisation points (registers and memory system are idle there)
@@ -577,7 +590,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                     for (int k = 0; k < DD; ++k) pe[u][k] = 0.0;
                 }
             } else {
-                load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe);
+                load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe);
             }
             ++round;
             __syncthreads();
@@ -585,7 +598,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             dAd = bc[0];
         } else {
             if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
-            if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, pcol, pe); })) { done = 3; return; }
+            if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe); })) { done = 3; return; }
             double ps = 0.0;
             for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
             ps = wave_sum(ps);
@@ -654,10 +667,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         }
         if (done) rMr = rMr_new;
     };
-    while (!done && it < a.maxit) {
-        iteration(std::false_type{});
-        if (ALT && !done && it < a.maxit) iteration(std::true_type{});
-    }
+    while (!done && it < a.maxit) iteration();
 #pragma unroll
     for (int t = 0; t < SPW; ++t)
         if (node[t] >= 0) {
@@ -685,19 +695,23 @@ __global__ void k_bcol_to_pos(int64_t n, const int32_t* __restrict__ bcol, const
 // buffer of the size of the kernel's streamed matrix part, in the kernel's launch shape (one workgroup of four waves
 // per CU, 16-byte loads, XCD-contiguous ranges), repeated so that it comes from wherever a buffer of that size lives
 // (Infinity Cache below ~200 MB); (2) the price of one grid-wide exchange of the form the solver uses.
+template <int U>   // 16-byte loads in flight per lane
 __global__ void __launch_bounds__(PBS) k_probe_stream(const double2* __restrict__ buf, int64_t n16, int reps, int nt,
                                                       double* __restrict__ sink) {
     const int G = gridDim.x, xk = blockIdx.x % PNX, per = G / PNX;
-    const int64_t chunk = (n16 / G) & ~(int64_t)(PBS * 8 - 1);   // 16-byte elements per workgroup, whole tiles
-    const int64_t wg = (int64_t)xk * per + blockIdx.x / PNX;     // XCD k walks a contiguous range
-    const double2* __restrict__ p = buf + wg * chunk + threadIdx.x;
+    const int64_t chunk = (n16 / G) / (PBS * U) * (PBS * U);     // 16-byte elements per workgroup, whole tiles
     double s0 = 0.0, s1 = 0.0;
     typedef double nt_d2 __attribute__((ext_vector_type(2)));
     for (int r = 0; r < reps; ++r) {
-        for (int64_t i = 0; i < chunk; i += PBS * 8) {
-            double2 v[8];
+        // XCD k walks a contiguous range; the chunk of a workgroup moves on by a third of that range every pass, so that
+        // nothing is re-read before the whole buffer has gone by (a workgroup looping over ONE small chunk would
+        // measure its L2, not the stream: 24 TB/s at 8 workgroups per CU in the first version of this probe)
+        const int64_t wg = (int64_t)xk * per + (blockIdx.x / PNX + (int64_t)r * (per / 3 + 1)) % per;
+        const double2* __restrict__ p = buf + wg * chunk + threadIdx.x;
+        for (int64_t i = 0; i < chunk; i += PBS * U) {
+            double2 v[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (nt) {
                     const nt_d2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p + i + u * PBS));
                     v[u] = make_double2(t.x, t.y);
@@ -705,8 +719,9 @@ __global__ void __launch_bounds__(PBS) k_probe_stream(const double2* __restrict_
                     v[u] = p[i + u * PBS];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 s0 += v[u].x;
                 s1 += v[u].y;
             }
@@ -714,6 +729,35 @@ __global__ void __launch_bounds__(PBS) k_probe_stream(const double2* __restrict_
         __builtin_amdgcn_sched_barrier(0);
     }
     if (s0 + s1 == 1.2345e-300) sink[0] = s0;                    // keeps the loads alive
+}
+
+// the same sweep through the LDS-DMA path (global_load_lds_dwordx4: 1 KiB per wave instruction lands in LDS without
+// passing through VGPRs), U instructions in flight per wave into a wave-private ring of U KiB; one ds_read per lane and
+// tile keeps the data "used"
+template <int U>
+__global__ void __launch_bounds__(PBS) k_probe_stream_lds(const double2* __restrict__ buf, int64_t n16, int reps, int nt,
+                                                          double* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds_probe_ring[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int G = gridDim.x, xk = blockIdx.x % PNX, per = G / PNX;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t chunk = (n16 / G) / (PBS * U) * (PBS * U);
+    char* ring = lds_probe_ring + (size_t)wave * (U * 1024);
+    double s0 = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const int64_t wg = (int64_t)xk * per + (blockIdx.x / PNX + (int64_t)r * (per / 3 + 1)) % per;
+        const double2* __restrict__ p = buf + wg * chunk + (int64_t)wave * (chunk / 4) + lane;
+        for (int64_t i = 0; i < chunk / 4; i += 64 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (nt) __builtin_amdgcn_global_load_lds(p + i + u * 64, (lds_ptr_t)(ring + u * 1024), 16, 0, 2);
+                else __builtin_amdgcn_global_load_lds(p + i + u * 64, (lds_ptr_t)(ring + u * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s0 += reinterpret_cast<const double*>(ring)[lane * 2 + (int)(i & 1)];
+        }
+    }
+    if (s0 == 1.2345e-300) sink[0] = s0;
 }
 
 template <int A2A>
@@ -729,11 +773,13 @@ __global__ void __launch_bounds__(PBS) k_probe_exchange(PersistPcg a, int rounds
         const double mine = (double)(blockIdx.x + r);
         double total;
         if (A2A) {
+            // three granule arrays in turn, as in the solver: a slot is rewritten only after two other exchanges
+            const int base = (r % 3) * G;
             if (wave == 0) {
-                if (lane == 0) granule_store(srsrc, blockIdx.x, mine, (unsigned long long)r + 1);
+                if (lane == 0) granule_store(srsrc, base + blockIdx.x, mine, (unsigned long long)r + 1);
                 double o[1];
                 const int op[1] = {0};
-                const bool okx = granule_sweep<1>(srsrc, 0, G, (unsigned long long)r + 1, a.spin_limit, o, op);
+                const bool okx = granule_sweep<1>(srsrc, base, G, (unsigned long long)r + 1, a.spin_limit, o, op);
                 if (lane == 0) {
                     bc[0] = o[0];
                     if (!okx) s_fail = 1;
@@ -788,7 +834,7 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
 // default variant of the persistent kernel (FEMCY_TUNE_PERSIST_VARIANT = -1), chosen by the round-3 measurements
 // 
 #ifndef FEMCY_PERSIST_DEFAULT_VARIANT
-#define FEMCY_PERSIST_DEFAULT_VARIANT 0
+#define FEMCY_PERSIST_DEFAULT_VARIANT 6
 #endif
 
 // eligibility + launch; *handled = false when the system does not qualify (too small, too large, multi-rank)
@@ -802,7 +848,8 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
     // every wave gets its slices (<= 4), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
     // synchronisation per iteration exceed the (graph-replayed) three-launch iteration (size sweep in DESIGN.md)
-    if (maxrange > 4 * nwx || c->nslices < G || (c->nslices < G + G / 2 && c->opt_persist < 2)) return FEMCY_OK;
+    // (FEMCY_OPT_PCG_PERSIST = 2 takes any system whose slices fit; waves without a slice idle through the exchanges)
+    if (maxrange > 4 * nwx || ((c->nslices < G + G / 2) && c->opt_persist < 2)) return FEMCY_OK;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
     const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
@@ -875,6 +922,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
     a.st = c->d_state;
     a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
+    a.l2_rows = c->opt_persist_l2rows;
     size_t tp = (size_t)-1;
 #define FEMCY_PERSIST(DM_, SPW_, RJ_, VAR_)                                                                       \
     do {                                                                                                          \
@@ -931,15 +979,24 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
 }
 
 // ---- ceiling probes (femcy_probe_stream / femcy_probe_exchange)
-// mode 0: the persistent kernel's launch shape (one workgroup of four waves per CU); mode 1: the same with
-// non-temporal loads; mode 2: 8 workgroups per CU (what the chip streams at full occupancy); mode 3: mode 2 + nt
+// mode 0: the persistent kernel's launch shape (one workgroup of four waves per CU), 8 loads of 16 bytes in flight per
+// lane; mode 1: the same with non-temporal loads; mode 2: 8 workgroups per CU (what the chip streams at full
+// occupancy); mode 3: mode 2 + nt; modes 4 / 5: mode 0 with 16 / 32 loads in flight per lane (how much of the gap
+// between modes 0 and 2 is memory-level parallelism); modes 6 / 7: modes 4 / 5 non-temporal
 int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass, int64_t* bytes_per_pass) {
-    FEMCY_REQUIRE(bytes >= (1 << 20) && reps >= 1 && mode >= 0 && mode <= 3, "probe_stream: bytes >= 1 MiB, reps >= 1, mode 0..3");
-    const int per_cu = mode >= 2 ? 8 : 1;
-    const int G = (c->persist_cus / PNX) * PNX * per_cu;
-    FEMCY_REQUIRE(G >= PNX, "device reports %d compute units", c->persist_cus);
+    FEMCY_REQUIRE(bytes >= (1 << 20) && reps >= 1 && mode >= 0 && mode <= 16, "probe_stream: bytes >= 1 MiB, reps >= 1, mode 0..16");
+    // modes 14 / 15 / 16: 2 / 3 / 4 workgroups per CU (8 / 12 / 16 waves), 8 loads in flight, default policy
+    const int per_cu = (mode == 2 || mode == 3) ? 8 : (mode >= 14 ? mode - 12 : 1);
     const int64_t n16 = bytes / 16;
-    const int64_t chunk = (n16 / G) & ~(int64_t)(PBS * 8 - 1);
+    // modes 8 / 9 / 10: the LDS-DMA path with 8 / 16 / 32 KiB in flight per wave; 11 / 12 / 13: the same non-temporal
+    const bool dma = mode >= 8 && mode <= 13;
+    const int nt = (mode == 1 || mode == 3 || mode == 6 || mode == 7 || mode >= 11) ? 1 : 0;
+    const int unroll = dma ? (8 << ((mode - 8) % 3)) : ((mode == 4 || mode == 6) ? 16 : ((mode == 5 || mode == 7) ? 32 : 8));
+    int G = (c->persist_cus / PNX) * PNX * per_cu;
+    FEMCY_REQUIRE(G >= PNX, "device reports %d compute units", c->persist_cus);
+    const int64_t tile = (int64_t)PBS * unroll;
+    G = (int)std::max<int64_t>(PNX, std::min<int64_t>(G, (n16 / tile) / PNX * PNX));   // >= one tile per workgroup
+    const int64_t chunk = (n16 / G) / tile * tile;
     FEMCY_REQUIRE(chunk > 0, "probe_stream: %lld bytes are less than one tile per workgroup", (long long)bytes);
     if (!c->d_probe || c->probe_cap < bytes) {
         if (c->d_probe) (void)hipFree(c->d_probe);
@@ -948,16 +1005,35 @@ int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_p
         FEMCY_HIP(hipMalloc((void**)&c->d_probe, (size_t)bytes + 64));
         FEMCY_HIP(hipMemsetAsync(c->d_probe, 0, (size_t)bytes, c->stream));
     }
-    const size_t lds = per_cu == 1 ? (size_t)(c->small_max_lds - 1024) : 0;   // one workgroup per CU, as the solver
-    const void* fn = reinterpret_cast<const void*>(&k_probe_stream);
-    if (lds > 48 * 1024) FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // dynamic LDS sets the residency: one workgroup per CU as the solver, or exactly per_cu of them
+    const size_t lds = per_cu == 1 ? (size_t)(c->small_max_lds - 1024)
+                                   : (per_cu < 8 ? (size_t)(c->small_max_lds / per_cu - 2048) : 0);
     hipEvent_t e0, e1;
     FEMCY_HIP(hipEventCreate(&e0));
     FEMCY_HIP(hipEventCreate(&e1));
-    const int nt = mode & 1;
-    hipLaunchKernelGGL(k_probe_stream, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, 2, nt, c->d_part1);
-    FEMCY_HIP(hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(k_probe_stream, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, (int)reps, nt, c->d_part1);
+#define FEMCY_PROBE(U_, REPS_)                                                                                     \
+    do {                                                                                                           \
+        const void* fn = reinterpret_cast<const void*>(&k_probe_stream<U_>);                                       \
+        if (lds > 48 * 1024) FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_probe_stream<U_>, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, \
+                           (int)(REPS_), nt, c->d_part1);                                                          \
+    } while (0)
+#define FEMCY_PROBE_DMA(U_, REPS_)                                                                                 \
+    do {                                                                                                           \
+        const void* fn = reinterpret_cast<const void*>(&k_probe_stream_lds<U_>);                                   \
+        if (lds > 48 * 1024) FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_probe_stream_lds<U_>, dim3(G), dim3(PBS), lds, c->stream, (const double2*)c->d_probe, n16, \
+                           (int)(REPS_), nt, c->d_part1);                                                          \
+    } while (0)
+    for (int pass = 0; pass < 2; ++pass) {                       // warm-up launch (2 passes), then the timed one
+        if (pass) FEMCY_HIP(hipEventRecord(e0, c->stream));
+        const int r = pass ? reps : 2;
+        if (dma) {
+            if (unroll == 8) FEMCY_PROBE_DMA(8, r); else if (unroll == 16) FEMCY_PROBE_DMA(16, r); else FEMCY_PROBE_DMA(32, r);
+        } else if (unroll == 8) FEMCY_PROBE(8, r); else if (unroll == 16) FEMCY_PROBE(16, r); else FEMCY_PROBE(32, r);
+    }
+#undef FEMCY_PROBE_DMA
+#undef FEMCY_PROBE
     FEMCY_HIP(hipEventRecord(e1, c->stream));
     FEMCY_HIP(hipStreamSynchronize(c->stream));
     float ms = 0.f;

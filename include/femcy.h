@@ -85,9 +85,11 @@ enum femcy_assembly {
     FEMCY_ASM_GATHER_SYM = 4, /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
     FEMCY_ASM_GATHER_SYM_ROWSUM = 5, /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
                                 unity, checked on the element tables); AUTO picks it for npe <= 4 */
-    FEMCY_ASM_ROWS2 = 6   /* ROWS with the element records staged in LDS, one workgroup per 64-row slice, row-sum
+    FEMCY_ASM_ROWS2 = 6,  /* ROWS with the element records staged in LDS, one workgroup per 64-row slice, row-sum
                              diagonal, 30-flop blocks for cubic-pattern C: AUTO picks it for C3D10 (3.x faster than ROWS);
                              instantiated for C3D10 and C3D4 tables whose gradients sum to zero */
+    FEMCY_ASM_ROWS3 = 7   /* ROWS2 with eight adjacent rows finished together and written as whole 128-byte lines
+                             (no read-for-fill of K: round 3) */
 };
 
 enum femcy_option {
@@ -144,15 +146,17 @@ enum femcy_option {
                                         occupancy query admits is refused before the launch; see femcy_pcg          */
     FEMCY_TUNE_SMALL_REG_ROWS = 108, /* small-system PCG: block rows per wave kept in registers (-1 = its share)    */
     FEMCY_TUNE_PERSIST_VARIANT = 109,/* persistent PCG variant bits (-1 = the default chosen by measurement, DESIGN.md
-                                        section 3): 1 = alternate the sweep direction of the streamed block rows on
-                                        odd iterations (tail re-read from L2), 2 = the three grid-wide exchanges as
-                                        tagged granules (one hop) instead of counters + data, 4 = d published in
-                                        storage order (16 + 8 byte gathers instead of 3 x 8).  The shipped library
-                                        holds the default and 0 (round 2); all eight with -DFEMCY_PERSIST_ALL_VARIANTS */
+                                        section 3): 1 = non-temporal matrix stream (FEMCY_TUNE_PERSIST_L2_ROWS), 2 = the
+                                        three grid-wide exchanges as tagged granules (one hop) instead of counters +
+                                        data, 4 = d published in storage order (16 + 8 byte gathers instead of 3 x 8).
+                                        The shipped library holds the default and 0 (round 2); all eight with
+                                        -DFEMCY_PERSIST_ALL_VARIANTS */
     FEMCY_TUNE_SPMV_KEEP = 110,      /* NT SpMV: per-mille of every XCD's slice range that keeps the default cache
                                         policy (-1 auto = 235 MB of the matrix)                                     */
     FEMCY_TUNE_SKIP_OCCUPANCY_CHECK = 111,/* 1 = launch the persistent kernels without the co-residency check (tests
                                         of the barrier time-out and its fallback)                                   */
+    FEMCY_TUNE_PERSIST_L2_ROWS = 113,/* persistent PCG with non-temporal matrix stream (variant bit 1): streamed block rows
+                                        per slice that keep the default cache policy (they stay in the XCD's L2)     */
     FEMCY_TUNE_BARRIER_SPIN_LIMIT = 112 /* polls (each ~0.3-1 us) before a grid barrier of the one-launch solvers gives
                                         up, poisons the exchange and the solve is redone by the three-kernel loop
                                         (default 2^20, about half a second; 0 provokes the fallback: tests)         */

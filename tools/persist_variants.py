@@ -1,4 +1,4 @@
-"""round 3: the persistent PCG's variants (FEMCY_TUNE_PERSIST_VARIANT bits: 1 alternating sweep, 2 tagged-granule
+"""round 3: the persistent PCG's variants (FEMCY_TUNE_PERSIST_VARIANT bits: 1 non-temporal matrix stream, 2 tagged-granule
 exchanges, 4 d in storage order with 16 + 8 byte gathers) on the headline mesh, and the ceilings the kernel runs
 against (stream rate by buffer size and launch shape, exchange price by form).
 usage: FEMCY_HIP_LIB=femcy_amd/libfemcy_hip_allvar.so ITERS=500 python tools/persist_variants.py [c3d4|c3d10] [variants...]
@@ -32,16 +32,17 @@ streamed = ctx.persist_streamed_bytes()
 print(f"{wl}: n {ctx.n} nslices {info.nslices} stored blocks {info.stored_blocks} "
       f"({info.stored_blocks * 76 / 1e6:.1f} MB), streamed per iteration {streamed / 1e6:.1f} MB", flush=True)
 
-print("== ceilings: stream (GB/s) by buffer size; mode 0 = 1 WG/CU, 1 = +nt, 2 = 8 WG/CU, 3 = +nt", flush=True)
-for mb in (16, 24, 48, int(streamed / 1e6) or 88, 160, 200, 400, 1024):
+print("== ceilings: stream (GB/s) by buffer size; mode 0 = 1 WG/CU x 8 loads in flight, 1 = +nt, 2 = 8 WG/CU, 3 = +nt, "
+      "4 / 5 = 1 WG/CU x 16 / 32 loads in flight, 6 / 7 = +nt", flush=True)
+for mb in (16, 48, int(streamed / 2 ** 20) or 88, 112, 120, 128, 136, 144, 160, 200, 400, 1024):
     row = []
-    for mode in (0, 1, 2, 3):
+    for mode in range(8):
         best = 0.0
         for _ in range(2):
             g, moved = ctx.probe_stream(mb << 20, 20 if mb < 500 else 8, mode)
             best = max(best, g)
         row.append(best)
-    print(f"  {mb:5d} MiB: " + "  ".join(f"mode{k} {v:8.0f}" for k, v in enumerate(row)), flush=True)
+    print(f"  {mb:5d} MiB: " + "  ".join(f"m{k} {v:6.0f}" for k, v in enumerate(row)), flush=True)
 print("== ceilings: grid-wide exchange (us) form 0 = counters + data, 1 = tagged granules", flush=True)
 for form in (0, 1):
     try:
@@ -52,9 +53,12 @@ for form in (0, 1):
 
 ctx.set_option(be.OPT_PCG_PERSIST, 2 if quad else 1)
 ref = None
-for var in variants:
+runs = [(v, 1) for v in variants]
+runs += [(v, l2) for v in variants if v & 1 for l2 in (0, 2, 3)]
+for var, l2 in runs:
     try:
         ctx.set_option(be.TUNE_PERSIST_VARIANT, var)
+        ctx.set_option(be.TUNE_PERSIST_L2_ROWS, l2)
         times = []
         for rep in range(4):
             t = time.perf_counter()
@@ -67,7 +71,7 @@ for var in variants:
         dx = np.linalg.norm(x - ref[0]) / np.linalg.norm(ref[0])
         it2, _, rmax2 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=nit)
         same = np.array_equal(ctx.download(be.VEC_X), x)
-        print(f"  variant {var} (alt {var & 1} a2a {(var >> 1) & 1} wide {(var >> 2) & 1}): "
+        print(f"  variant {var} (nt {var & 1} a2a {(var >> 1) & 1} wide {(var >> 2) & 1}) l2rows {l2}: "
               + " ".join(f"{t:6.2f}" for t in times) + f" us/it  rmax {rmax:.6e} |x-x0|/|x0| {dx:.1e} "
               f"reproducible {same} paths 3k/small/persist {tm['solves_three']}/{tm['solves_small']}/{tm['solves_persist']}"
               f" timeouts {tm['barrier_timeouts']}", flush=True)
