@@ -422,8 +422,28 @@ def main():
             else:
                 ctx.set_option(be.OPT_EXCHANGE, 1 if args.exchange == "neighbour" else 0)
                 exchange["exchange"] = args.exchange
+        # the one-launch PCG on every rank, the ranks' kernels exchanging through mailboxes in each other's HBM
+        # (femcy.h "Persistent PCG across ranks"): blobs all-gathered here, the path agreed collectively; a rank on
+        # which a step fails still takes part in the agreement (with a "no")
+        pmulti = {"enabled": False}
+        if hasattr(ctx, "comm_mailbox_export") and os.environ.get("FEMCY_BENCH_PERSIST_MULTI", "1") != "0":
+            try:
+                with Watchdog(args.comm_timeout, "mailbox exchange"):
+                    blob = ctx.comm_mailbox_export()
+                    blobs = [None] * N
+                    if use_dist:
+                        dist.all_gather_object(blobs, blob)
+                    else:
+                        blobs = [blob]
+                    ctx.comm_mailbox_import(blobs)
+            except Exception as e:                               # noqa: BLE001
+                log(f"[bench] rank {rank}: mailbox set-up failed ({e}); this rank votes for the RCCL loop")
+                ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            with Watchdog(args.comm_timeout, "femcy_comm_persist_agree"):
+                pmulti["enabled"] = bool(ctx.comm_persist_agree())
     else:
         exchange = None
+        pmulti = None
     n, ne = ctx.n, ctx.ne
     if rank == 0:
         log(f"[bench] {args.workload} cells {nx}x{ny}x{nz}: {ne_global} elements / {n_global} DOF global, {ne} elements "
@@ -473,6 +493,31 @@ def main():
         ctx.set_option(be.OPT_EXCHANGE, 1 if pick == "neighbour" else 0)
         exchange["exchange"] = pick
         exchange["step_ms"] = {k: v * 1e3 for k, v in trial.items()}
+
+    # persistent PCG across ranks, second half: one short solve with it and one with the three-launch + collective loop
+    # must give the same numbers (the scalars are global: every rank sees the same ones); otherwise every rank keeps
+    # the loop.  A solve that times out anywhere falls back everywhere by itself (and stays there).
+    if use_comm and pmulti and pmulti["enabled"]:
+        with Watchdog(2 * args.comm_timeout, "persistent multi-rank PCG cross-check"):
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            ref3 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 1)
+            t_before = ctx.timing()
+            got = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
+            t_after = ctx.timing()
+        took = t_after["solves_persist"] > t_before["solves_persist"]
+        same = got[0] == ref3[0] and abs(got[2] - ref3[2]) <= 1e-8 * abs(ref3[2])
+        verdict = 1 if (took and same) else 0
+        if use_dist:
+            box = torch.tensor([verdict], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(box, op=dist.ReduceOp.MIN)
+            verdict = int(box.item())
+        pmulti.update(took_persistent_path=bool(took), matches_three_launch_loop=bool(same), enabled=bool(verdict))
+        if not verdict:
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            log(f"[bench] rank {rank}: persistent multi-rank PCG not used (took {took}, same {same}): RCCL loop")
 
     # untimed pre-warm on top of the W warmup steps: a fresh box needs ~1 s of load before the GPU sits at its
     # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work), and an
@@ -562,7 +607,7 @@ def main():
                    "parallelism": f"element z-slabs x{N}, slab-local mesh generation" if N > 1 else "single GPU",
                    "launcher": "self-launched torch.distributed.run" if os.environ.get("FEMCY_BENCH_SELF_LAUNCHED") else
                                ("torch.distributed.run" if world_env is not None else "single process"),
-                   "interface_exchange": exchange},
+                   "interface_exchange": exchange, "persistent_pcg_across_ranks": pmulti},
         "cg_iters_per_s": cg_only * scale,
         "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,

@@ -29,6 +29,7 @@ OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT, OPT_EW_GRID, OPT_PCG_G
 OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent tangent (extension)
 OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neighbour send/recv
 OPT_PCG_PERSIST = 11     # 1 (default) = persistent one-launch PCG (single rank, <= ~7e5 DOF, matrix <= Infinity Cache); 2 = any matrix size
+OPT_PCG_PERSIST_MULTI = 12   # 1 (default) = the persistent kernel across ranks once the mailboxes are exchanged and agreed
 OPT_PCG_SMALL = 10       # 1 (default) = one persistent launch per solve for systems that fit LDS
 TUNE_PERSIST_VARIANT = 109   # persistent PCG variant bits (-1 default; femcy.h)
 TUNE_SKIP_OCCUPANCY_CHECK = 111
@@ -49,6 +50,7 @@ EXPORTS = [
     "femcy_timing_reset", "femcy_comm_unique_id", "femcy_comm_local_id", "femcy_comm_init", "femcy_comm_info", "femcy_comm_set_neighbours",
     "femcy_comm_tune", "femcy_iface_sum",
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
+    "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
 ]
 
 
@@ -129,6 +131,8 @@ def load_library(require_gpu_runtime: bool = True):
         "femcy_probe_stream": [p, i64, i32, i32, C.POINTER(f64), C.POINTER(i64)],
         "femcy_probe_exchange": [p, i32, i32, C.POINTER(f64)],
         "femcy_persist_streamed_bytes": [p, C.POINTER(i64)],
+        "femcy_comm_mailbox_export": [p, p], "femcy_comm_mailbox_import": [p, i32, p],
+        "femcy_comm_persist_agree": [p, C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -472,6 +476,25 @@ class Context:
         chosen, us = C.c_int32(), (C.c_double * 2)()
         self._call("femcy_comm_tune", int(iters), C.byref(chosen), C.cast(us, C.c_void_p))
         return {"exchange": "neighbour" if chosen.value == 1 else "allreduce", "allreduce_us": us[0], "neighbour_us": us[1]}
+
+    # persistent PCG across ranks: the peers' kernels write into each other's mailboxes (femcy.h)
+    def comm_mailbox_export(self) -> bytes:
+        buf = C.create_string_buffer(256)
+        self._call("femcy_comm_mailbox_export", buf)
+        return buf.raw
+
+    def comm_mailbox_import(self, blobs) -> None:
+        """blobs: the 256-byte exports of ALL ranks, in rank order"""
+        joined = b"".join(blobs)
+        assert len(joined) == 256 * len(blobs)
+        buf = C.create_string_buffer(joined, len(joined))
+        self._call("femcy_comm_mailbox_import", len(blobs), buf)
+
+    def comm_persist_agree(self) -> bool:
+        """collective: True when every rank can keep the one-launch PCG (femcy_comm_persist_agree)"""
+        out = C.c_int32()
+        self._call("femcy_comm_persist_agree", C.byref(out))
+        return bool(out.value)
 
     def iface_sum(self, vec_id: int):
         self._call("femcy_iface_sum", int(vec_id))

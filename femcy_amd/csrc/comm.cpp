@@ -12,6 +12,7 @@
 // multi-rank device path (sub-assembled K, interface pack / unpack, owner masks, the two collectives per
 // iteration) can be run and checked on a single GPU; ranks sum in rank order, so every rank gets the same bits.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -287,7 +288,177 @@ int comm_neighbour_exchange(Ctx* c, hipStream_t stream) {
     return FEMCY_OK;
 }
 
+// ------------------------------------------------------------------------------- mailboxes of the persistent PCG
+// (protocol: kernels_pcg_persist.hip).  A mailbox is one buffer of 8-byte words in the rank's own HBM:
+//   [2][R] entries d.Ad | [2][R][2] entries (r.M.r, max|r|) | [2][nb_total] entries interface rows of Ad
+// (entry = 2 words).  It is exported as a 256-byte blob (IPC handle, process id, device pointer, the neighbour segment
+// table) that the host program hands to the other ranks (torch.distributed all-gather in bench.py / distributed.py;
+// a plain list for the in-process group).
+namespace {
+struct MboxBlob {
+    char magic[8];
+    int32_t rank, nranks;
+    int64_t pid;
+    uint64_t devptr;
+    int32_t device, nnb, nb_total, has_ipc;
+    hipIpcMemHandle_t handle;          // 64 bytes
+    int32_t nb_rank[8];
+    int32_t nb_ptr[9];
+    char pad[256 - (8 + 8 + 8 + 8 + 16 + 64 + 32 + 36)];
+};
+static_assert(sizeof(MboxBlob) == 256, "mailbox blob is 256 bytes");
+const char MBOX_MAGIC[8] = {'F', 'E', 'M', 'C', 'Y', 'M', 'B', '1'};
+}  // namespace
+
+int comm_mailbox_export(Ctx* c, void* blob256) {
+    FEMCY_REQUIRE(c->comm, "femcy_comm_init must come first");
+    FEMCY_REQUIRE(!c->h_nb_ptr.empty() && c->d_if_ptr, "femcy_comm_set_neighbours must come first");
+    const int R = c->nranks;
+    FEMCY_REQUIRE(R <= 16, "the mailbox path supports up to 16 ranks");
+    const int64_t nb_total = c->h_nb_ptr.back();
+    const int64_t words = 12 * (int64_t)R + 4 * nb_total + 16;
+    if (!c->d_mbox || c->mbox_words < words) {
+        if (c->d_mbox) (void)hipFree(c->d_mbox);
+        c->d_mbox = nullptr;
+        // fine-grained: remote (xGMI) writes must become visible to this device's polls without a kernel boundary
+        c->mbox_finegrained = hipExtMallocWithFlags((void**)&c->d_mbox, sizeof(unsigned long long) * words,
+                                                    hipDeviceMallocFinegrained) == hipSuccess;
+        if (!c->mbox_finegrained) {
+            (void)hipGetLastError();
+            FEMCY_HIP(hipMalloc((void**)&c->d_mbox, sizeof(unsigned long long) * words));
+        }
+        c->mbox_words = words;
+        FEMCY_HIP(hipMemset(c->d_mbox, 0, sizeof(unsigned long long) * words));
+    }
+    MboxBlob b;
+    std::memset(&b, 0, sizeof(b));
+    std::memcpy(b.magic, MBOX_MAGIC, 8);
+    b.rank = c->rank;
+    b.nranks = R;
+    b.pid = (int64_t)getpid();
+    b.devptr = (uint64_t)(uintptr_t)c->d_mbox;
+    b.device = c->device;
+    b.nb_total = (int32_t)nb_total;
+    const int nnb = (int)c->h_nb_rank.size();
+    b.nnb = nnb <= 8 ? nnb : -1;                                  // more neighbours than the blob holds: not eligible
+    for (int k = 0; k < nnb && k < 8; ++k) b.nb_rank[k] = c->h_nb_rank[k];
+    for (int k = 0; k <= nnb && k <= 8; ++k) b.nb_ptr[k] = c->h_nb_ptr[k];
+    b.has_ipc = hipIpcGetMemHandle(&b.handle, c->d_mbox) == hipSuccess ? 1 : 0;
+    if (!b.has_ipc) (void)hipGetLastError();
+    std::memcpy(blob256, &b, sizeof(b));
+    return FEMCY_OK;
+}
+
+int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs) {
+    FEMCY_REQUIRE(c->comm && c->d_mbox, "femcy_comm_mailbox_export must come first");
+    FEMCY_REQUIRE(nblobs == c->nranks && blobs, "one blob per rank is needed (%d given, %d ranks)", nblobs, c->nranks);
+    const MboxBlob* B = reinterpret_cast<const MboxBlob*>(blobs);
+    const int R = c->nranks;
+    c->persist_multi_local = c->persist_multi = false;
+    for (void* q : c->ipc_opened) (void)hipIpcCloseMemHandle(q);
+    c->ipc_opened.clear();
+    c->h_peer_mbox.assign((size_t)R, nullptr);
+    bool ok = true;
+    for (int r = 0; r < R; ++r) {
+        FEMCY_REQUIRE(std::memcmp(B[r].magic, MBOX_MAGIC, 8) == 0 && B[r].rank == r && B[r].nranks == R,
+                      "blob %d is not the mailbox of rank %d of %d", r, r, R);
+        if (r == c->rank) {
+            c->h_peer_mbox[r] = c->d_mbox;
+            continue;
+        }
+        if (B[r].pid == (int64_t)getpid()) {                      // same process (in-process group, tests): the pointer itself
+            if (B[r].device != c->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(B[r].device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                (void)hipGetLastError();
+            }
+            c->h_peer_mbox[r] = reinterpret_cast<unsigned long long*>((uintptr_t)B[r].devptr);
+        } else if (B[r].has_ipc) {
+            void* q = nullptr;
+            if (hipIpcOpenMemHandle(&q, B[r].handle, hipIpcMemLazyEnablePeerAccess) == hipSuccess && q) {
+                c->ipc_opened.push_back(q);
+                c->h_peer_mbox[r] = reinterpret_cast<unsigned long long*>(q);
+            } else {
+                (void)hipGetLastError();
+                ok = false;
+            }
+        } else {
+            ok = false;
+        }
+    }
+    // per-position interface table: {entry in the neighbour's Ad area, entry in mine, neighbour | lower << 8, its nb_total}
+    const int nnb = (int)c->h_nb_rank.size();
+    std::vector<int32_t> tab((size_t)c->nslices * SLICE * 4, -1);
+    if (nnb > 8 || (int64_t)c->h_nb_dofs.size() != (int64_t)c->h_nb_ptr.back()) ok = false;
+    for (int k = 0; k < nnb && ok; ++k) {
+        const int q = c->h_nb_rank[k];
+        const MboxBlob& bq = B[q];
+        int kq = -1;
+        for (int t = 0; t < bq.nnb; ++t)
+            if (bq.nb_rank[t] == c->rank) kq = t;
+        const int32_t cnt = c->h_nb_ptr[k + 1] - c->h_nb_ptr[k];
+        if (kq < 0 || bq.nb_ptr[kq + 1] - bq.nb_ptr[kq] != cnt || cnt % c->dm != 0) {
+            ok = false;
+            break;
+        }
+        for (int32_t j = c->h_nb_ptr[k]; j < c->h_nb_ptr[k + 1]; j += c->dm) {
+            const int32_t d0 = c->h_nb_dofs[j];
+            bool whole = d0 % c->dm == 0;                         // the node's dm DOFs, consecutive entries
+            for (int cc = 1; cc < c->dm && whole; ++cc) whole = c->h_nb_dofs[j + cc] == d0 + cc;
+            if (!whole) {
+                ok = false;
+                break;
+            }
+            const int64_t p = c->h_pos[d0 / c->dm];
+            if (tab[p * 4] >= 0) {                                // a node shared with two neighbours: not this path
+                ok = false;
+                break;
+            }
+            tab[p * 4 + 0] = bq.nb_ptr[kq] + (j - c->h_nb_ptr[k]);
+            tab[p * 4 + 1] = j;
+            tab[p * 4 + 2] = q | (q < c->rank ? 0x100 : 0);
+            tab[p * 4 + 3] = bq.nb_total;
+        }
+    }
+    if (c->d_mr_tab) (void)hipFree(c->d_mr_tab);
+    c->d_mr_tab = nullptr;
+    FEMCY_HIP(hipMalloc((void**)&c->d_mr_tab, tab.size() * sizeof(int32_t)));
+    FEMCY_HIP(hipMemcpy(c->d_mr_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (c->d_peer_tab) (void)hipFree(c->d_peer_tab);
+    c->d_peer_tab = nullptr;
+    FEMCY_HIP(hipMalloc((void**)&c->d_peer_tab, sizeof(unsigned long long*) * 16));
+    FEMCY_HIP(hipMemcpy(c->d_peer_tab, c->h_peer_mbox.data(), sizeof(unsigned long long*) * R, hipMemcpyHostToDevice));
+    c->persist_multi_local = ok;
+    return FEMCY_OK;
+}
+
+// collective: the path is taken only if EVERY rank can take it (mailboxes mapped, one sharer per interface node, the
+// pattern fits the persistent kernel) -- a rank that went the other way would leave the others polling
+int comm_persist_agree(Ctx* c, int32_t* enabled) {
+    FEMCY_REQUIRE(c->comm, "femcy_comm_init must come first");
+    const bool local = c->opt_persist_multi && c->persist_multi_local && c->d_mr_tab && persist_pattern_fits(c);
+    double flag = local ? 0.0 : 1.0;
+    FEMCY_HIP(hipMemcpyAsync(c->d_commbuf, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = comm_allreduce_sum(c, c->d_commbuf, 1);
+    if (rc) return rc;
+    FEMCY_HIP(hipMemcpyAsync(&flag, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    c->persist_multi = flag == 0.0;
+    c->persist_multi_failed = false;
+    if (enabled) *enabled = c->persist_multi ? 1 : 0;
+    return FEMCY_OK;
+}
+
 int comm_destroy(Ctx* c) {
+    for (void* q : c->ipc_opened) (void)hipIpcCloseMemHandle(q);
+    c->ipc_opened.clear();
+    if (c->d_mbox) (void)hipFree(c->d_mbox);
+    if (c->d_mr_tab) (void)hipFree(c->d_mr_tab);
+    if (c->d_peer_tab) (void)hipFree(c->d_peer_tab);
+    c->d_mbox = nullptr;
+    c->d_mr_tab = nullptr;
+    c->d_peer_tab = nullptr;
+    c->persist_multi = c->persist_multi_local = false;
     if (c->comm && c->comm_local) {
         LocalGroup* g = (LocalGroup*)c->comm;
         bool last;

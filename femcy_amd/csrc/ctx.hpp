@@ -232,6 +232,22 @@ struct Ctx {
     double* d_commbuf = nullptr;      // [niface_global + 8]
     double* d_gather = nullptr;       // [nranks*2]
 
+    // ---- persistent PCG across ranks (kernels_pcg_persist.hip "persistent PCG across ranks"): this rank's mailbox,
+    // the peers' mailboxes as mapped on this device, the per-position interface table
+    unsigned long long* d_mbox = nullptr;
+    int64_t mbox_words = 0;
+    bool mbox_finegrained = false;
+    std::vector<unsigned long long*> h_peer_mbox;   // [nranks], own entry = d_mbox
+    std::vector<void*> ipc_opened;                  // mappings to close
+    unsigned long long** d_peer_tab = nullptr;      // device copy of h_peer_mbox
+    int32_t* d_mr_tab = nullptr;                    // [nslices * 64][4]
+    std::vector<int32_t> h_nb_dofs;                 // host copy of the neighbour DOF lists
+    bool persist_multi_local = false;               // this rank could take the path
+    bool persist_multi = false;                     // ... and every rank agreed (femcy_comm_persist_agree)
+    bool persist_multi_failed = false;              // a solve timed out: the RCCL loop from now on
+    int opt_persist_multi = 1;                      // FEMCY_OPT_PCG_PERSIST_MULTI
+    uint32_t solve_serial = 0;
+
     // ---- overlapped iteration (neighbour exchange): interface slices first, their exchange on a second stream
     // while the interior slices are multiplied
     hipStream_t comm_stream = nullptr;
@@ -306,6 +322,10 @@ int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);
 int comm_neighbour_exchange(Ctx* c, hipStream_t stream);   // d_nb_send segments -> neighbours, their segments -> d_nb_recv
 int comm_register_neighbours(Ctx* c);  // in-process transport: publish this rank's segment table
 int comm_destroy(Ctx* c);
+int comm_mailbox_export(Ctx* c, void* blob256);
+int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs);
+int comm_persist_agree(Ctx* c, int32_t* enabled);
+bool persist_pattern_fits(Ctx* c);
 int iface_sum(Ctx* c, double* d_v);
 int scalar_across_ranks(Ctx* c, double* d_val, int mode, double* out);
 void pcg_graph_reset(Ctx* c);

@@ -355,6 +355,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->barrier_spin_limit = (uint32_t)value;
             c->persist_failed = c->small_failed = false;
             break;
+        case FEMCY_OPT_PCG_PERSIST_MULTI:
+            FEMCY_REQUIRE(value == 0 || value == 1, "persistent multi-rank PCG: 0 (off) or 1 (when every rank agreed)");
+            c->opt_persist_multi = (int)value;
+            c->persist_multi_failed = false;
+            break;
         case FEMCY_TUNE_PERSIST_L2_ROWS:
             FEMCY_REQUIRE(value >= 0 && value <= 64, "rows out of range");
             c->opt_persist_l2rows = (int)value;
@@ -1241,10 +1246,28 @@ int femcy_comm_set_neighbours(femcy_ctx* ctx, int32_t nnb, const int32_t* nb_ran
     if (total) FEMCY_HIP(hipMemcpy(c->d_nb_dofs, nb_dofs, sizeof(int32_t) * total, hipMemcpyHostToDevice));
     FEMCY_HIP(hipMemcpy(c->d_if_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
     if (!src.empty()) FEMCY_HIP(hipMemcpy(c->d_if_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice));
+    c->h_nb_dofs.assign(nb_dofs, nb_dofs + total);
+    c->persist_multi = c->persist_multi_local = false;
     c->h_nb_rank.assign(nb_rank, nb_rank + nnb);
     c->h_nb_ptr.assign(nb_ptr, nb_ptr + nnb + (nnb ? 1 : 0));
     if (c->h_nb_ptr.empty()) c->h_nb_ptr.push_back(0);
     return comm_register_neighbours(c);
+}
+
+int femcy_comm_mailbox_export(femcy_ctx* ctx, void* blob256) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(blob256, "null blob");
+    return comm_mailbox_export(c, blob256);
+}
+int femcy_comm_mailbox_import(femcy_ctx* ctx, int32_t nblobs, const void* blobs) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
+    return comm_mailbox_import(c, nblobs, blobs);
+}
+int femcy_comm_persist_agree(femcy_ctx* ctx, int32_t* enabled) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
+    return comm_persist_agree(c, enabled);
 }
 
 int femcy_comm_tune(femcy_ctx* ctx, int32_t iters, int32_t* chosen, double* us) {

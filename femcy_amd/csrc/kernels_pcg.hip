@@ -1144,15 +1144,17 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         if (rc) return rc;
         hipLaunchKernelGGL(k_recip, dim3(ew_grid(c, c->n)), dim3(BS), 0, c->stream, c->n, c->d_M);
     }
-    if (!multi) {
+    // one-launch forms: the small-system kernel (single rank), the persistent kernel (single rank; across ranks once
+    // every rank agreed -- femcy_comm_persist_agree -- with its own agreement on the outcome inside pcg_persist_solve)
+    {
         bool handled = false, persist = false;
-        int rc = pcg_small_solve(c, d_b, d_x, eps, maxit, &handled);
-        if (rc) return rc;
+        int rc = FEMCY_OK;
+        if (!multi && (rc = pcg_small_solve(c, d_b, d_x, eps, maxit, &handled))) return rc;
         if (!handled) {
             if ((rc = pcg_persist_solve(c, d_b, d_x, eps, maxit, &handled))) return rc;
             persist = handled;
         }
-        if (handled) {
+        if (handled && !multi) {
             FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
             FEMCY_HIP(hipStreamSynchronize(c->stream));
             // a grid-barrier time-out (a workgroup was not resident: shared GPU, CU mask, another persistent kernel): every

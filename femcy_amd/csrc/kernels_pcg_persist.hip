@@ -90,6 +90,14 @@ struct PersistPcg {
     int32_t npad, maxit, lds_rows, dbg, l2_rows;
     uint32_t spin_limit;  // polls before a barrier gives up and poisons the exchange
     double eps;
+    // ---- across ranks (template parameter MULTI): mailboxes written by the peers' kernels, see the block comment
+    // "persistent PCG across ranks" below
+    unsigned long long* mbox;                 // this rank's mailbox
+    unsigned long long* const* peer;          // [nranks] every rank's mailbox as mapped on this device
+    const int32_t* mr_tab;                    // [positions][4]: send entry, recv entry, neighbour | lower << 8, its nb_total
+    const uint8_t* owner;                     // [n] 1 = this rank counts the DOF in reductions
+    int32_t rank, nranks, nb_total;
+    uint32_t tagbase;                         // solve serial << 20: tags never repeat from one solve to the next
 };
 
 __device__ __forceinline__ void pst(double* p, double v) {
@@ -198,7 +206,79 @@ __device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, i
     }
 }
 
-template <int DM, int SPW, int RJ, int VAR>
+// ------------------------------------------------------------------------------- persistent PCG across ranks
+// With a communicator attached round 2 fell back to three launches + 2-3 RCCL calls per iteration (51-63 us against
+// 29 us on one GPU, before any real link latency).  Here every rank keeps its ONE launch per solve; what crosses
+// the ranks travels through mailboxes -- one buffer per rank in its own HBM (fine-grained), mapped into the peers
+// (hipIpc / peer access) and WRITTEN BY THE PEERS' KERNELS over xGMI, polled locally:
+//   * entry = two 8-byte words {value lo32 | tag << 32, value hi32 | tag << 32}: every word validates itself (the
+//     LL protocol of RCCL), so no flag, no fence and no ordering between the words is needed; 8-byte system-scope
+//     relaxed atomics both sides;
+//   * interface rows of Ad: the lane that owns a shared row writes its partial sum straight into the sharing rank's
+//     mailbox right after the product and reads the neighbour's partial before the r update; the two are added in
+//     ascending rank order, so the replicas stay bit-identical (z-slabs: one sharer per interface node -- the form
+//     this path takes; other partitions keep the RCCL loop);
+//   * d.Ad and (r.M.r, max|r|): local grid-wide exchange first, then workgroup 0 writes the rank's value into every
+//     rank's mailbox and wave 0 of every workgroup polls the nranks entries of its own rank's mailbox and combines
+//     them in rank order.  d.Ad = sum_r d_r.K_r d_r needs no owner mask; r.M.r counts a shared DOF on its owner;
+//   * entries are double-buffered by iteration parity and tagged (solve serial << 20) + iteration, so nothing is ever
+//     re-armed; a rank cannot run more than one exchange ahead of a peer (it needs the peer's value to pass).
+// Every poll is bounded (spin_limit); a time-out ends the launch with done = 3 and the host -- after agreeing with
+// the other ranks through the communicator -- redoes the solve with the RCCL loop.
+constexpr int MB_SA = 0;                                         // [2][R] entries: d.Ad
+__device__ __forceinline__ int mb_sb(int R) { return 4 * R; }    // [2][R][2] entries: (r.M.r, max|r|)
+__device__ __forceinline__ int mb_ad(int R) { return 12 * R; }   // [2][nb_total] entries: interface rows of Ad
+__device__ __forceinline__ void mb_store(unsigned long long* p, double v, uint32_t tag) {
+    const unsigned long long t = (unsigned long long)tag << 32;
+    __hip_atomic_store(p, t | (uint32_t)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, t | (uint32_t)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool mb_load(const unsigned long long* p, uint32_t tag, double& v) {
+    const unsigned long long w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v = __hiloint2double((int)(uint32_t)w1, (int)(uint32_t)w0);
+    return (uint32_t)(w0 >> 32) == tag && (uint32_t)(w1 >> 32) == tag;
+}
+// wave 0 of a workgroup: NV values of this rank (the same in every lane) -> combined over the ranks in rank order.
+// `base` = word offset of the exchange's area, entries [parity][rank][NV].  Workgroup 0 is the sender.
+template <int NV>
+__device__ __forceinline__ bool xrank_reduce(const PersistPcg& a, int base, int parity, uint32_t tag, double (&val)[NV],
+                                             const int (&op)[NV]) {
+    const int lane = threadIdx.x & 63, R = a.nranks;
+    if (blockIdx.x == 0 && lane < R) {
+        unsigned long long* dst = a.peer[lane] + base + (size_t)((parity * R + a.rank) * NV) * 2;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) mb_store(dst + 2 * v, val[v], tag);
+    }
+    double got[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) got[v] = 0.0;
+    uint32_t spins = 0;
+    for (;;) {
+        bool ok = true;
+        if (lane < R) {
+            const unsigned long long* src = a.mbox + base + (size_t)((parity * R + lane) * NV) * 2;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ok = mb_load(src + 2 * v, tag, got[v]) && ok;
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > a.spin_limit) return false;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double acc = 0.0;
+        for (int r = 0; r < R; ++r) {
+            const double x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(got[v]), r),
+                                              __builtin_amdgcn_readlane(__double2loint(got[v]), r));
+            acc = op[v] ? fmax(acc, x) : acc + x;
+        }
+        val[v] = acc;
+    }
+    return true;
+}
+
+template <int DM, int SPW, int RJ, int VAR, bool MULTI = false>
 __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
     constexpr bool NT = (VAR & V_NT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
@@ -365,6 +445,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     // ---- x0 = 0, r = b, d = M r
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
+    uint32_t ownbits = 0;                                         // bit t * DM + c: this rank counts the DOF (MULTI)
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
 #pragma unroll
@@ -377,12 +458,35 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             mm[t][c] = mi;
             dd[t][c] = mi * bi;
             Ad[t][c] = 0.0;
-            accs += bi * mi * bi;
+            // across ranks a shared DOF is counted by its owner only; max|r| is the same on every replica
+            const bool mine = !MULTI || (in && a.owner[i] != 0);
+            if (mine) ownbits |= 1u << (t * DM + c);
+            if (mine) accs += bi * mi * bi;
             accm = fmax(accm, pabs(bi));
         }
         if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], 0, dd[t]);
     }
     unsigned round = 0;
+    // across ranks: the cross-rank stage of an exchange (wave 0 of every workgroup; the local result is in `val`),
+    // result through LDS to every thread
+    int xr_it = -1;                                               // iteration the running exchanges belong to (-1: set-up)
+    auto xrank_stage = [&](auto nv_tag, int base, double (&val)[decltype(nv_tag)::value],
+                           const int (&op)[decltype(nv_tag)::value]) -> bool {
+        constexpr int NV = decltype(nv_tag)::value;
+        __syncthreads();
+        if (wave == 0) {
+            const bool okx = xrank_reduce<NV>(a, base, (xr_it + 1) & 1, a.tagbase + (uint32_t)(xr_it + 1), val, op);
+            if (lane == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) bc[v] = val[v];
+                if (!okx) s_fail = 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) val[v] = bc[v];
+        return s_fail == 0;
+    };
     // granule arrays: [0, G) d.Ad, [G, 3 G) (r.M.r, max|r|), [3 G, 4 G) "d published"
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.slots, 0, G * 4 * 16, 0x00020000);
     auto poison_granules = [&]() {
@@ -449,10 +553,21 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             return true;
         }
     };
+    auto exchange_pair_all = [&](double s_, double m_, double* part2_base, double& s_out, double& m_out) -> bool {
+        if (!exchange_pair(s_, m_, part2_base, s_out, m_out)) return false;
+        if (MULTI) {
+            double val[2] = {s_out, m_out};
+            const int op[2] = {0, 1};
+            if (!xrank_stage(std::integral_constant<int, 2>{}, mb_sb(a.nranks), val, op)) return false;
+            s_out = val[0];
+            m_out = val[1];
+        }
+        return true;
+    };
     double rMr = 0.0, r0 = 0.0;
     // the initial d is published with the first exchange: its stores are drained before anybody passes it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool ok0 = exchange_pair(accs, accm, a.part2, rMr, r0);
+    const bool ok0 = exchange_pair_all(accs, accm, a.part2, rMr, r0);
     double rmax = r0;
     int done = !ok0 ? 3 : ((r0 == 0.0) ? 1 : ((r0 != r0 || isinf(r0)) ? 2 : 0));
     int it = 0;
@@ -562,6 +677,23 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
         const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
         double dot = product(poff);
+        xr_it = it;
+        if (MULTI) {
+            // interface rows: the partial sums of this rank go straight into the sharing rank's mailbox (system-scope
+            // 8-byte words that validate themselves); they travel while the exchanges below run
+            const uint32_t tag = a.tagbase + (uint32_t)(it + 1);
+#pragma unroll
+            for (int t = 0; t < SPW; ++t)
+                if (sl[t] >= 0) {
+                    const int4 tb = reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane];
+                    if (tb.x >= 0) {
+                        unsigned long long* dst = a.peer[tb.z & 0xff] + mb_ad(a.nranks) +
+                                                  ((size_t)(it & 1) * tb.w + tb.x) * 2;
+#pragma unroll
+                        for (int c = 0; c < DM; ++c) mb_store(dst + 2 * c, Ad[t][c], tag);
+                    }
+                }
+        }
         // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested inside the first
         // exchange (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
         // synchronisation points (registers and memory system are idle there)
@@ -607,6 +739,36 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             __syncthreads();
             dAd = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
         }
+        if (MULTI) {
+            double val[1] = {dAd};
+            const int op[1] = {0};
+            if (!xrank_stage(std::integral_constant<int, 1>{}, MB_SA, val, op)) { done = 3; return; }
+            dAd = val[0];
+            // the neighbour's partial sums of the interface rows, added in ascending rank order on both sides
+            const uint32_t tag = a.tagbase + (uint32_t)(it + 1);
+            bool okr = true;
+#pragma unroll
+            for (int t = 0; t < SPW; ++t)
+                if (sl[t] >= 0) {
+                    const int4 tb = reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane];
+                    if (tb.y >= 0) {
+                        const unsigned long long* src = a.mbox + mb_ad(a.nranks) + ((size_t)(it & 1) * a.nb_total + tb.y) * 2;
+#pragma unroll
+                        for (int c = 0; c < DM; ++c) {
+                            double other = 0.0;
+                            uint32_t spins = 0;
+                            while (!mb_load(src + 2 * c, tag, other)) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > a.spin_limit) { okr = false; break; }
+                            }
+                            Ad[t][c] = (tb.z & 0x100) ? other + Ad[t][c] : Ad[t][c] + other;
+                        }
+                    }
+                }
+            if (__any(!okr)) s_fail = 1;
+            __syncthreads();
+            if (s_fail) { done = 3; return; }
+        }
         // ---- alpha; x, r; partials of (r.M.r, max|r|)
         const double alpha = rMr / dAd;
         accs = 0.0;
@@ -619,13 +781,13 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 const double ri = rr[t][c] - alpha * Ad[t][c];
                 rr[t][c] = ri;
                 if (node[t] >= 0) {
-                    accs += ri * mm[t][c] * ri;
+                    if (!MULTI || ((ownbits >> (t * DM + c)) & 1u)) accs += ri * mm[t][c] * ri;
                     accm = fmax(accm, pabs(ri));
                 }
             }
         __syncthreads();
         double rMr_new = 0.0;
-        if (!exchange_pair(accs, accm, a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax)) { done = 3; return; }
+        if (!exchange_pair_all(accs, accm, a.part2 + (size_t)((it + 1) & 1) * 2 * G, rMr_new, rmax)) { done = 3; return; }
         ++it;
         if (PDBG(a, 15)) rmax = 1.0, rMr_new = 1.0;   // bits 0-3 skip work: keep iterating on whatever numbers result
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
@@ -837,10 +999,30 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
 #define FEMCY_PERSIST_DEFAULT_VARIANT 6
 #endif
 
-// eligibility + launch; *handled = false when the system does not qualify (too small, too large, multi-rank)
+int64_t persist_streamed_bytes(Ctx* c);
+// does the system of this context take the persistent kernel?  (the multi-rank agreement)
+bool persist_pattern_fits(Ctx* c) {
+    if (!c->opt_persist || !c->have_pattern) return false;
+    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;
+    if (G < PNX) return false;
+    const int nwx = (G / PNX) * 4;
+    int32_t maxrange = 0;
+    for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
+    if (maxrange > 4 * nwx || c->dm != 3) return false;          // (the multi-rank kernel is instantiated for 3 x 3 blocks)
+    if (c->opt_persist >= 2) return true;
+    // the single-rank rules of pcg_persist_solve, evaluated here once so that every rank applies the same verdict: the
+    // chip is filled 1.5 times over, and the streamed part of the matrix fits the Infinity Cache
+    if (c->nslices < G + G / 2) return false;
+    return persist_streamed_bytes(c) <= c->persist_max_bytes;
+}
+
+// eligibility + launch; *handled = false when the system does not qualify (too small, too large, ranks not agreed)
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled) {
     *handled = false;
-    if (!c->opt_persist || c->comm || c->persist_failed) return FEMCY_OK;
+    const bool multi = c->comm != nullptr;
+    if (!c->opt_persist || c->persist_failed) return FEMCY_OK;
+    if (multi && (!c->persist_multi || c->persist_multi_failed || !c->opt_persist_multi || maxit >= (1 << 20) - 2))
+        return FEMCY_OK;
     const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;   // one workgroup per CU
     if (G < PNX) return FEMCY_OK;
     const int nwx = (G / PNX) * 4;
@@ -849,7 +1031,8 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     // every wave gets its slices (<= 4), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
     // synchronisation per iteration exceed the (graph-replayed) three-launch iteration (size sweep in DESIGN.md)
     // (FEMCY_OPT_PCG_PERSIST = 2 takes any system whose slices fit; waves without a slice idle through the exchanges)
-    if (maxrange > 4 * nwx || ((c->nslices < G + G / 2) && c->opt_persist < 2)) return FEMCY_OK;
+    // across ranks every rank must take the same path: only the rule the agreement checked applies there
+    if (maxrange > 4 * nwx || ((c->nslices < G + G / 2) && c->opt_persist < 2 && !multi)) return FEMCY_OK;
     const int DD = c->dm * c->dm;
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
     const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
@@ -862,7 +1045,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
     const int64_t kbytes = c->stored_rows * row_bytes;
     const int64_t resident = (int64_t)G * 4 * (SPW * rj + lds_rows) * row_bytes;   // upper bound (short slices hold less)
-    if (kbytes - resident > c->persist_max_bytes && c->opt_persist < 2) return FEMCY_OK;
+    if (kbytes - resident > c->persist_max_bytes && c->opt_persist < 2 && !multi) return FEMCY_OK;
     const size_t lds = (size_t)4 * lds_rows * 64 * (DD * 8 + 4) + 16;
     const int var = c->opt_persist_variant < 0 ? FEMCY_PERSIST_DEFAULT_VARIANT : c->opt_persist_variant;
     const bool wide = (var & V_WIDE) != 0, a2a = (var & V_A2A) != 0;
@@ -923,16 +1106,28 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     a.st = c->d_state;
     a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
     a.l2_rows = c->opt_persist_l2rows;
+    a.mbox = c->d_mbox; a.peer = c->d_peer_tab; a.mr_tab = c->d_mr_tab; a.owner = c->d_owner;
+    a.rank = c->rank; a.nranks = c->nranks; a.nb_total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
+    c->solve_serial = (c->solve_serial % 4095) + 1;               // 1 .. 4095: a tag is never 0 (the zeroed mailbox)
+    a.tagbase = c->solve_serial << 20;
     size_t tp = (size_t)-1;
-#define FEMCY_PERSIST(DM_, SPW_, RJ_, VAR_)                                                                       \
+    bool launched = true;
+#define FEMCY_PERSIST_M(DM_, SPW_, RJ_, VAR_, MULTI_)                                                             \
     do {                                                                                                          \
-        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_, VAR_>);                     \
+        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>);             \
         if (lds > 48 * 1024)                                                                                      \
             FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        if (!coresident(c, fn, PBS, lds, G)) return FEMCY_OK;   /* the grid barrier needs all G workgroups resident */ \
+        /* the grid barrier needs all G workgroups resident; across ranks a refusal here would leave the others */ \
+        /* polling, so it is reported as a failed solve: the agreement after the launch sends everybody to RCCL  */ \
+        if (!coresident(c, fn, PBS, lds, G)) {                                                                    \
+            if (!multi) return FEMCY_OK;                                                                          \
+            launched = false;                                                                                     \
+            break;                                                                                                \
+        }                                                                                                         \
         tp = timing_begin(c, T_PERSIST);                                                                          \
-        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_, VAR_>), dim3(G), dim3(PBS), lds, c->stream, a);         \
+        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>), dim3(G), dim3(PBS), lds, c->stream, a); \
     } while (0)
+#define FEMCY_PERSIST(DM_, SPW_, RJ_, VAR_) FEMCY_PERSIST_M(DM_, SPW_, RJ_, VAR_, false)
 #ifdef FEMCY_PERSIST_ALL_VARIANTS
 #define FEMCY_PERSIST_V(DM_, SPW_, RJ_)                                                                           \
     switch (var & 7) {                                                                                            \
@@ -955,6 +1150,13 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
 #endif
     // register-resident block rows per slice: what 512 VGPRs per lane hold next to the vectors and the streaming
     // buffers (dm 3: 5 rows x 3 slices or 3 rows x 4 slices of 19 registers each)
+    if (multi) {
+        // across ranks: the default variant, 3 x 3 blocks (the agreement checked dm == 3); register rows as in the
+        // single-rank kernel of the same shape
+        FEMCY_REQUIRE((var & 7) == FEMCY_PERSIST_DEFAULT_VARIANT, "the multi-rank persistent PCG exists for the default variant only");
+        if (SPW == 3) { FEMCY_PERSIST_M(3, 3, 4, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+        else { FEMCY_PERSIST_M(3, 4, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+    } else
 #ifdef FEMCY_PERSIST_ONLY_334     // compile-time experiments: one shape only
     if (c->dm == 3 && SPW == 3 && c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) } else return FEMCY_OK;
 #else
@@ -972,8 +1174,27 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
 #endif
 #undef FEMCY_PERSIST_V
 #undef FEMCY_PERSIST
-    timing_end(c, tp);
+#undef FEMCY_PERSIST_M
+    if (launched) timing_end(c, tp);
     FEMCY_HIP(hipGetLastError());
+    if (multi) {
+        // every rank learns whether the solve completed EVERYWHERE (a time-out on one rank leaves the others'
+        // iterates unusable as well); this collective is also what keeps a fast rank's next solve from writing into
+        // mailboxes a slow rank is still reading
+        FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        double bad = (!launched || c->h_state->done == 3) ? 1.0 : 0.0;
+        FEMCY_HIP(hipMemcpyAsync(c->d_commbuf, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int rc = comm_allreduce_sum(c, c->d_commbuf, 1);
+        if (rc) return rc;
+        FEMCY_HIP(hipMemcpyAsync(&bad, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FEMCY_HIP(hipStreamSynchronize(c->stream));
+        if (bad != 0.0) {
+            c->persist_multi_failed = true;
+            c->timing.barrier_timeouts++;
+            return FEMCY_OK;                                      // *handled stays false: the RCCL loop redoes the solve
+        }
+    }
     *handled = true;
     return FEMCY_OK;
 }

@@ -112,6 +112,12 @@ enum femcy_option {
                                    in registers, another part in LDS, grid barriers at the three synchronisation points
                                    of the recurrence; 2 = also when the streamed part is larger than the cache (slower
                                    than three launches; tests); 0 = three launches per iteration */
+    FEMCY_OPT_PCG_PERSIST_MULTI = 12, /* 1 (default): with a communicator attached, femcy_pcg keeps the one-launch
+                                   persistent kernel on every rank and the ranks' kernels exchange the interface rows of
+                                   Ad and the two scalar reductions through mailboxes in each other's HBM (written over
+                                   xGMI by the peers' kernels) -- once the mailboxes are exchanged
+                                   (femcy_comm_mailbox_export / _import) and EVERY rank agreed
+                                   (femcy_comm_persist_agree).  0 = three launches + RCCL calls per iteration */
     FEMCY_OPT_PCG_SMALL = 10,   /* 1 (default): systems whose two work vectors fit the LDS of a workgroup (~1e4 DOF on
                                    MI355X) are solved by ONE persistent launch with one grid barrier per iteration
                                    instead of three launches per iteration; 0 = always the three-kernel loop */
@@ -347,6 +353,21 @@ int femcy_comm_set_neighbours(femcy_ctx* ctx, int32_t nnb, const int32_t* nb_ran
  * a failed cross-check keeps the all-reduce and reports us[1] = -1. */
 int femcy_comm_tune(femcy_ctx* ctx, int32_t iters, int32_t* chosen, double* us /*[2]*/);
 int femcy_iface_sum(femcy_ctx* ctx, int vec);
+/* Persistent PCG across ranks (FEMCY_OPT_PCG_PERSIST_MULTI).  After femcy_comm_set_neighbours:
+ *   femcy_comm_mailbox_export  allocates this rank's mailbox (fine-grained device memory the peers' kernels write
+ *                              into) and describes it in a 256-byte blob: IPC handle, process id, device pointer,
+ *                              neighbour segment table;
+ *   (the host program hands every rank all blobs, in rank order -- torch.distributed all-gather, MPI, a list)
+ *   femcy_comm_mailbox_import  maps the peers' mailboxes (same process: the pointer, with peer access between
+ *                              devices; other processes: hipIpcOpenMemHandle) and builds the interface tables;
+ *   femcy_comm_persist_agree   collective: enabled = 1 only if every rank can take the path (mailboxes mapped, every
+ *                              interface node shared with exactly one other rank as in a slab partition, at most 8
+ *                              neighbours, the pattern fits the persistent kernel).
+ * femcy_pcg then takes the one-launch path on every rank alike; after each such solve the ranks agree through the
+ * communicator whether it completed, and a solve that timed out anywhere is redone everywhere by the RCCL loop. */
+int femcy_comm_mailbox_export(femcy_ctx* ctx, void* blob256);
+int femcy_comm_mailbox_import(femcy_ctx* ctx, int32_t nblobs, const void* blobs /*[nranks][256]*/);
+int femcy_comm_persist_agree(femcy_ctx* ctx, int32_t* enabled);
 
 #ifdef __cplusplus
 }

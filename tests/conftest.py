@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# Several contexts of ONE process on ONE GPU stand in for the ranks of a multi-GPU job (tests/test_gpu_multirank.py); the
+# persistent multi-rank PCG needs their kernels to run AT THE SAME TIME.  HIP maps the streams of a process onto 4
+# hardware queues by default, and two persistent kernels on one queue would wait for each other for ever (they end in
+# the bounded-spin fall-back instead) -- one queue per stream, set before the HIP runtime starts.  One process per GPU
+# (bench.py --gpus N, femcy_amd.main under torch.distributed.run) has one such kernel per process and needs nothing.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -313,3 +313,150 @@ def test_neighbour_exchange_equals_allreduce(name, nranks, axis):
         gd = (p.l2g[:, None] * dm + np.arange(dm)[None, :]).ravel()
         for g, v in zip(gd[p.iface_local_dofs], out[1][0][p.iface_local_dofs]):
             assert y_glob.setdefault(int(g), v) == v
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+@pytest.mark.parametrize("nranks,wgs", [(2, 64), (4, 32), (3, 48)])
+def test_persistent_pcg_across_ranks_on_one_gpu(gpu_ctx_factory, nranks, wgs):
+    """the one-launch PCG on every rank, the ranks' kernels exchanging the interface rows of Ad and the scalar
+    reductions through mailboxes in each other's memory (kernels_pcg_persist.hip "persistent PCG across ranks").
+    Here: N contexts of one process on ONE GPU, `wgs` workgroups each so that all kernels are co-resident, pointers
+    exchanged directly (the same-process branch of femcy_comm_mailbox_import); peers' stores are system-scope, polls
+    are system-scope loads of fine-grained memory -- what runs between GPUs over xGMI, minus the link.  Iterates must
+    equal the single-context solve of the whole mesh and the three-launch + collective path of the same ranks."""
+    from femcy_amd import backend as be, meshgen, partition
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    m = meshgen.twist_plate(24, 6, 96)                                  # 82 944 C3D4, 16 975 nodes
+    nodes, el = m["nodes"], m["elements"]
+    mat = LinearIsotropic(*m["elastic"])
+    n = nodes.size
+    cons_nodes = [(np.asarray(b["node_set"]), b["dof"]) for b in m["dirichlet_bc_info"]]
+    cons_g = np.unique(np.concatenate([ns * 3 + d for ns, d in cons_nodes]))
+    b_g = np.sin(np.arange(n) * 0.11) * 1e3
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(Element_linear_tetrahedral())
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, b_g)
+    ctx.dirichlet_newton(cons_g, be.VEC_RESIDUAL)
+    ref = [(ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=k), ctx.download(be.VEC_X)) for k in (1, 7, 40)]
+    ref_conv = (ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8), ctx.download(be.VEC_X))
+
+    parts = partition.build_all_parts(nodes, el, nranks, axis=2)
+    uid = be.Context.comm_local_id()
+    blobs = [None] * nranks
+    gate = threading.Barrier(nranks)
+
+    def rank_main(r):
+        p = parts[r]
+        c = be.Context(0)
+        try:
+            c.set_option(107, wgs)                                      # FEMCY_TUNE_PERSIST_WGS: all ranks' kernels co-resident
+            c.set_mesh(p.nodes, p.elements)
+            c.set_element(Element_linear_tetrahedral())
+            c.set_material(mat)
+            c.build_pattern()
+            c.comm_init(p.rank, p.nranks, uid, p.iface_local_dofs, p.iface_global_slot, p.niface_global, p.owner)
+            c.comm_set_neighbours(p)
+            blobs[r] = c.comm_mailbox_export()
+            gate.wait(timeout=60)
+            c.comm_mailbox_import(blobs)
+            assert c.comm_persist_agree()
+            c.assemble_K(-1)
+            c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
+            cons = np.unique(np.concatenate([p.localize_nodes(ns) * 3 + d for ns, d in cons_nodes]))
+            c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+            out = {}
+            for multi in (1, 0):
+                c.set_option(be.OPT_PCG_PERSIST_MULTI, multi)
+                t0 = c.timing()
+                out[multi] = [(c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=k), c.download(be.VEC_X)) for k in (1, 7, 40)]
+                out[multi].append((c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8), c.download(be.VEC_X)))
+                t1 = c.timing()
+                out[multi].append((t1["solves_persist"] - t0["solves_persist"], t1["solves_three"] - t0["solves_three"],
+                                   t1["barrier_timeouts"] - t0["barrier_timeouts"]))
+            return out
+        finally:
+            c.close()
+
+    outs = run_ranks(nranks, rank_main)
+    for p, out in zip(parts, outs):
+        assert out[1][-1] == (4, 0, 0), out[1][-1]                     # four solves, all persistent, no time-out
+        assert out[0][-1] == (0, 4, 0), out[0][-1]
+        for form in (1, 0):
+            for ((k, r0k, rmk), xk), ((kr, r0r, rmr), xr) in zip(out[form][:3], ref):
+                assert k == kr and abs(r0k - r0r) <= 1e-12 * r0r and abs(rmk - rmr) <= 1e-9 * rmr
+                assert np.linalg.norm(xk - p.scatter_global(xr)) <= 1e-9 * np.linalg.norm(xr)
+            (itc, r0c, rmc), xc = out[form][3]
+            (itr, _, _), xr = ref_conv
+            assert abs(itc - itr) <= max(2, itr // 50) and rmc < 1e-8 * r0c
+            assert np.linalg.norm(xc - p.scatter_global(xr)) <= 1e-6 * np.linalg.norm(xr)
+    # replicas are bit-identical: every rank reports the same scalars, shared nodes hold the same x
+    assert len({tuple(o[1][k][0] for k in range(4)) for o in outs}) == 1
+    xg = {}
+    for p, o in zip(parts, outs):
+        x = o[1][2][1].reshape(-1, 3)
+        for a, g in enumerate(p.l2g):
+            key = int(g)
+            if key in xg:
+                assert np.array_equal(xg[key], x[a])
+            else:
+                xg[key] = x[a]
+
+
+def test_persistent_pcg_across_ranks_times_out_together(gpu_ctx_factory):
+    """a spin limit of 0 on every rank: the first cross-rank poll gives up, every rank's launch ends with done = 3, the
+    ranks agree through the communicator and redo the solve with the three-launch + collective loop -- same iterates
+    -- and stay on that loop afterwards"""
+    from femcy_amd import backend as be, meshgen, partition
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    m = meshgen.twist_plate(24, 6, 96)
+    nodes, el = m["nodes"], m["elements"]
+    mat = LinearIsotropic(*m["elastic"])
+    cons_nodes = [(np.asarray(b["node_set"]), b["dof"]) for b in m["dirichlet_bc_info"]]
+    b_g = np.sin(np.arange(nodes.size) * 0.11) * 1e3
+    nranks = 2
+    parts = partition.build_all_parts(nodes, el, nranks, axis=2)
+    uid = be.Context.comm_local_id()
+    blobs = [None] * nranks
+    gate = threading.Barrier(nranks)
+
+    def rank_main(r):
+        p = parts[r]
+        c = be.Context(0)
+        try:
+            c.set_option(107, 64)
+            c.set_mesh(p.nodes, p.elements)
+            c.set_element(Element_linear_tetrahedral())
+            c.set_material(mat)
+            c.build_pattern()
+            c.comm_init(p.rank, p.nranks, uid, p.iface_local_dofs, p.iface_global_slot, p.niface_global, p.owner)
+            c.comm_set_neighbours(p)
+            blobs[r] = c.comm_mailbox_export()
+            gate.wait(timeout=60)
+            c.comm_mailbox_import(blobs)
+            assert c.comm_persist_agree()
+            c.assemble_K(-1)
+            c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
+            cons = np.unique(np.concatenate([p.localize_nodes(ns) * 3 + d for ns, d in cons_nodes]))
+            c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+            good = (c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=9), c.download(be.VEC_X))
+            t0 = c.timing()
+            c.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 0)
+            bad = (c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=9), c.download(be.VEC_X))
+            again = (c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=9), c.download(be.VEC_X))
+            t1 = c.timing()
+            return good, bad, again, (t1["solves_persist"] - t0["solves_persist"], t1["solves_three"] - t0["solves_three"],
+                                      t1["barrier_timeouts"] - t0["barrier_timeouts"])
+        finally:
+            c.close()
+
+    for good, bad, again, counts in run_ranks(nranks, rank_main):
+        assert counts == (0, 2, 1), counts
+        for (res, x) in (bad, again):
+            assert res[0] == good[0][0] and abs(res[2] - good[0][2]) <= 1e-9 * good[0][2]
+            assert np.linalg.norm(x - good[1]) <= 1e-9 * np.linalg.norm(good[1])
