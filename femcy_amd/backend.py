@@ -1,10 +1,15 @@
-"""ctypes binding of libfemcy_hip.so (include/femcy.h) -- the only compute backend of femcy_amd.
+"""ctypes binding of the C ABI of include/femcy.h.
 
-There is deliberately no CPU fallback: if the HIP library is missing, or no MI355X is visible,
-construction of a `Context` raises `FemcyError`.  (The CPU restatement of the reference lives in
-`oracle/` and is test infrastructure only.)
+Two libraries implement it:
+  libfemcy_hip.so  the product: hand-written HIP kernels for gfx950 (csrc/).  The default, and the only thing a run on
+                   a GPU box ever uses.
+  libfemcy_cpu.so  the same ABI on the host (csrc_cpu/, C++ / OpenMP; the arithmetic of an element is the code the HIP
+                   kernels run, csrc/element_math.hpp).  Loaded ONLY when FEMCY_BACKEND=cpu is set (or
+                   Context(backend="cpu")): there is no silent fallback -- if the HIP library is missing, or no MI355X
+                   is visible, construction of a `Context` raises `FemcyError`.  (The CPU restatement of the reference
+                   in `oracle/` is something else again: test infrastructure only.)
 
-`import torch` happens before the library is loaded so that libfemcy_hip.so binds to the HIP
+`import torch` happens before the HIP library is loaded so that libfemcy_hip.so binds to the HIP
 runtime (and, for multi-GPU runs, the RCCL) that PyTorch already mapped into the process: the
 wheel bundles its own libamdhip64.so/librccl.so with the same SONAMEs as /opt/rocm's, and two
 HIP runtimes in one process do not mix.
@@ -19,6 +24,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEMCY_HIP_LIB") or os.path.join(_HERE, "libfemcy_hip.so")   # override: kernel A/B runs
+CPU_LIB_PATH = os.environ.get("FEMCY_CPU_LIB") or os.path.join(_HERE, "libfemcy_cpu.so")
+
+
+def default_backend() -> str:
+    """"hip" unless FEMCY_BACKEND=cpu was set explicitly"""
+    kind = os.environ.get("FEMCY_BACKEND", "hip").lower()
+    if kind not in ("hip", "cpu"):
+        raise FemcyError(f"FEMCY_BACKEND={kind!r}: expected 'hip' or 'cpu'")
+    return kind
 
 # enum femcy_vec
 VEC_DOF, VEC_RHS, VEC_RESIDUAL, VEC_FORCE, VEC_DU, VEC_DOF_OLD, VEC_X, VEC_TMP0, VEC_TMP1 = range(9)
@@ -85,20 +99,30 @@ class Timing(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-_lib = None
+_libs = {}
 
 
-def load_library(require_gpu_runtime: bool = True):
-    """dlopen libfemcy_hip.so.  Raises FemcyError when the in-tree library has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(require_gpu_runtime: bool = True, kind: Optional[str] = None):
+    """dlopen the library of the backend (default: FEMCY_BACKEND, i.e. "hip").  Raises FemcyError when the in-tree
+    library has not been built."""
+    kind = kind or default_backend()
+    if kind in _libs:
+        return _libs[kind]
+    if kind == "cpu":
+        if not os.path.exists(CPU_LIB_PATH):
+            raise FemcyError(f"{CPU_LIB_PATH} not found: build it with `bash femcy_amd/csrc_cpu/build.sh`")
+        lib = C.CDLL(CPU_LIB_PATH)
+        return _bind(lib, kind)
     if not os.path.exists(LIB_PATH):
         raise FemcyError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                         "(femcy_amd has no CPU fallback)")
+                         "(there is no silent CPU fallback; FEMCY_BACKEND=cpu selects the host backend explicitly)")
     if require_gpu_runtime:
         import torch  # noqa: F401  (maps PyTorch's HIP runtime first; see module docstring)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    return _bind(lib, kind)
+
+
+def _bind(lib, kind):
     p, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     cint = C.c_int
     sig = {
@@ -140,7 +164,7 @@ def load_library(require_gpu_runtime: bool = True):
         fn.restype = cint
     lib.femcy_last_error.argtypes = []
     lib.femcy_last_error.restype = C.c_char_p
-    _lib = lib
+    _libs[kind] = lib
     return lib
 
 
@@ -200,10 +224,11 @@ class GaussField:
 
 
 class Context:
-    """one HIP device + stream + all device state of one System_of_equations."""
+    """one HIP device + stream + all device state of one System_of_equations (backend "cpu": the host)."""
 
-    def __init__(self, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, backend: Optional[str] = None):
+        self.backend = backend or default_backend()
+        self.lib = load_library(kind=self.backend)
         h = C.c_void_p()
         rc = self.lib.femcy_ctx_create(int(device), C.byref(h))
         if rc != 0:

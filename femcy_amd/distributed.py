@@ -45,9 +45,16 @@ def partitioned_system(inp, material, verbose=True, tangent="reference"):
     axis = int(np.argmax(np.ptp(inp.nodes, axis=0)))
     part = partition.build_part(inp.nodes, el, nranks, rank, axis=axis)
     body = Body(part.nodes, part.elements, inp.ELE)
+    def gather_blobs(blob):
+        import torch.distributed as dist
+        blobs = [None] * nranks
+        dist.all_gather_object(blobs, blob)
+        return blobs
+
     system = System_of_equations(body, material, inp.geometric_nonlinear, device=local, verbose=verbose, part=part,
                                  comm_uid=uid, tangent=tangent,
-                                 exchange=os.environ.get("FEMCY_EXCHANGE", "allreduce"))   # or "neighbour" / "auto"
+                                 exchange=os.environ.get("FEMCY_EXCHANGE", "allreduce"),   # or "neighbour" / "auto"
+                                 gather_blobs=gather_blobs)
     return system, partition.LocalDeck(inp, part, body), part
 
 

@@ -38,7 +38,8 @@ class System_of_equations:
 
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
-                 part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce"):
+                 part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce",
+                 gather_blobs=None):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -78,6 +79,17 @@ class System_of_equations:
             else:
                 self.ctx.set_option(be.OPT_EXCHANGE, 1 if exchange == "neighbour" else 0)
                 self.exchange = {"exchange": exchange}
+            # persistent PCG across ranks (femcy.h): `gather_blobs(blob) -> [blob of rank 0, 1, ...]` is the host
+            # program's all-gather (torch.distributed in distributed.py); the path is used only if every rank agrees
+            # -- systems large enough for the one-launch kernel -- and a rank where the set-up fails votes "no"
+            self.persistent_across_ranks = False
+            if gather_blobs is not None:
+                try:
+                    self.ctx.comm_mailbox_import(gather_blobs(self.ctx.comm_mailbox_export()))
+                except be.FemcyError as e:
+                    self._say(f"mailbox set-up failed ({e}): three launches + collectives per CG iteration")
+                    self.ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+                self.persistent_across_ranks = self.ctx.comm_persist_agree()
         self._say("\033[32;1m pattern: {} DOF, {} blocks of {}x{}, ELL width {} ({:.3f} s) \033[0m".format(
             self.pattern.n, self.pattern.nnzb, self.dm, self.dm, self.pattern.ell_width, time.time() - t0))
 

@@ -30,6 +30,22 @@ def pytest_configure(config):
             print(f"[conftest] could not build {lib}: {e}", file=sys.stderr)
 
 
+# FEMCY_BACKEND=cpu runs the SAME parity tests against libfemcy_cpu.so (tests/test_cpu_backend.py does that in a child
+# process as part of the CPU suite).  Tests of device-only machinery are skipped there.
+DEVICE_ONLY = ("test_gpu_pcg_persist.py", "test_gpu_multirank.py", "test_gpu_fullsize.py", "test_gpu_bench_contract.py",
+               "test_rowsum_diagonal_needs_partition_of_unity", "test_pcg_single_rank_communicator",
+               "test_main_as_one_rank_rccl_job", "test_synthetic_twist_plate_end_to_end")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("FEMCY_BACKEND", "hip").lower() != "cpu":
+        return
+    skip = pytest.mark.skip(reason="device-only machinery (FEMCY_BACKEND=cpu)")
+    for item in items:
+        if any(pat in item.nodeid for pat in DEVICE_ONLY):
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx_factory():
     """creates femcy_amd Contexts; a -m gpu run on a box without a GPU must fail, not skip."""
