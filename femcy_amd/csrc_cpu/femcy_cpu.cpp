@@ -3,7 +3,7 @@
 // small systems on the host (stiffnessMtrx.py:219-251); this backend lets `python -m femcy_amd.main deck.inp` and the
 // whole Python surface run on a box without a GPU.
 //
-// It is NOT the oracle (oracle/ restates the reference as written and is test infrastructure) and it is never chosen
+// It is NOT the oracle (`oracle/` restates the reference as written and is test infrastructure) and it is never chosen
 // silently: femcy_amd.backend loads it only when FEMCY_BACKEND=cpu is set.  The arithmetic of an element, a Gauss
 // point, a facet is the SAME CODE the HIP kernels run (csrc/element_math.hpp); what differs is storage and schedule:
 //   * K is block-CSR (dm x dm blocks, the diagonal block first, then ascending columns -- the slot order of the
