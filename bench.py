@@ -722,6 +722,15 @@ def cpu_baseline_subprocess(nx, ny, nz, etype, both):
     inside the same static parallel loops that later use them (oracle/femcy_oracle.c), so pages sit on the NUMA node of
     their thread.  `both`: also the round-2 configuration (all hardware threads, unbound) for comparison."""
     cores = physical_cores()
+    # a container with a CPU quota (cgroup cpu.max) is throttled as soon as more threads than that run: the 128 pinned
+    # threads of the first version of this leg got 260 CG iterations / s on a 16-CPU quota, 16 threads get 1.3 k
+    nthreads = len(cores)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            nthreads = max(1, min(nthreads, int(float(q[0]) / float(q[1]) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
 
     def run(env_extra, label):
         env = dict(os.environ)
@@ -734,7 +743,7 @@ def cpu_baseline_subprocess(nx, ny, nz, etype, both):
         rec["omp"] = {k: env_extra.get(k) for k in ("OMP_NUM_THREADS", "OMP_PLACES", "OMP_PROC_BIND")}
         return rec
 
-    tuned = run({"OMP_NUM_THREADS": str(len(cores)), "OMP_PLACES": "cores", "OMP_PROC_BIND": "spread"}, "pinned")
+    tuned = run({"OMP_NUM_THREADS": str(nthreads), "OMP_PLACES": "cores", "OMP_PROC_BIND": "spread"}, "pinned")
     tuned["physical_cores"] = len(cores)
     if both:
         try:
@@ -818,16 +827,45 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
     co.zero_rows_cols_unit_diag(cons)
     f = co.internal_force(u, 0, *elastic)
     f[cons] = 0.0
-    # ~10 s of CG in solves of 100 iterations from x0 = 0 (a single long solve would run past convergence into
-    # denormal residuals, which cost the host cores up to 100x per operation and are not what the GPU step does either)
+    # CG in solves of 100 iterations from x0 = 0 (a single long solve would run past convergence into denormal
+    # residuals, which cost the host cores up to 100x per operation and are not what the GPU step does either).
+    # First a short scan over the thread count -- more threads than memory channels / the container's CPU quota can
+    # feed only adds synchronisation -- then ~10 s at the best count.
     co.cg(f, eps=0.0, maxit=3)
-    it, dt, chunk = 0, 0.0, 100
-    t_end = time.perf_counter() + 10.0
-    while time.perf_counter() < t_end:
-        t = time.perf_counter()
-        _, k, _, _ = co.cg(f, eps=0.0, maxit=chunk)
-        dt += time.perf_counter() - t
-        it += k
+    chunk = 100
+
+    def sample(seconds):
+        n_it, t_sum = 0, 0.0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            t = time.perf_counter()
+            _, k, _, _ = co.cg(f, eps=0.0, maxit=chunk)
+            t_sum += time.perf_counter() - t
+            n_it += k
+        return n_it, t_sum
+
+    scan, tmax = {}, co.threads()
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        nt = tmax
+        while nt >= max(1, tmax // 16):
+            gomp.omp_set_num_threads(int(nt))
+            k, tt = sample(1.5)
+            scan[int(nt)] = k / tt
+            nt //= 2
+        best = max(scan, key=scan.get)
+        gomp.omp_set_num_threads(int(best))
+    except Exception as e:                                       # noqa: BLE001
+        scan = {"error": repr(e)}
+        best = tmax
+    it, dt = sample(10.0)
+    quota = None
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        pass
     # as-written bytes of one CG iteration: the ELL arrays (8 + 4 bytes per slot, padding included: the port reads
     # them) + 17 vector passes of 8 n bytes (SpMV + 136 n)
     bytes_it = co.n * co.W * 12 + 4 * co.n + 16 * co.n + 136 * co.n
@@ -847,13 +885,16 @@ def cpu_baseline(nodes, el, elastic, u, cons, etype):
                 break
     except OSError:
         pass
-    return {"value": it / dt, "unit": "CG iters/s", "cores": co.threads(), "kind": "port",
+    numa = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]) \
+        if os.path.isdir("/sys/devices/system/node") else None
+    return {"value": it / dt, "unit": "CG iters/s", "cores": int(best), "kind": "port",
             "gbs": bytes_it * it / dt / 1e9,
+            "threads_scan_iters_per_s": scan, "container_cpu_quota": quota, "numa_nodes": numa,
             "assemblies_per_s": co.ne / t_asm, "assembly_ms": t_asm * 1e3,
             "cpu_model": cpu_model, "host_threads_available": os.cpu_count(),
             "scipy_csr_spmv_per_s_1thread": 1.0 / t_scipy,
             "sample": f"same {co.ne}-element {etype} mesh and state: 1 as-written assembly ({t_asm:.2f} s) + {it} CG "
-                      f"iterations ({dt:.1f} s) of oracle/femcy_oracle.c, OpenMP x{co.threads()} threads; setup "
+                      f"iterations ({dt:.1f} s) of oracle/femcy_oracle.c, OpenMP x{int(best)} threads (best of the scan); setup "
                       f"{setup:.0f} s untimed"}
 
 

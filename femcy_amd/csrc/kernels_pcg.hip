@@ -72,6 +72,23 @@ __device__ __forceinline__ double nan_to_inf_abs(double r) {   // fmax() drops N
     return (a != a) ? INFINITY : a;
 }
 
+// the dm doubles of a column node are contiguous (8-byte aligned): ONE 16-byte load (+ one 8-byte load for dm = 3)
+// instead of dm 8-byte loads -- a third fewer texture-address cycles on the gathers, which is what bounds the product
+// once the matrix streams from HBM (C3D10, 8 M elements: TA_TA_BUSY 74 % in round 2).  Buffer loads: dword alignment
+// suffices, out-of-range lanes (none here) would read 0.
+typedef unsigned int spmv_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int spmv_u32x4 __attribute__((ext_vector_type(4)));
+template <int DM>
+__device__ __forceinline__ void gather_x(const __amdgpu_buffer_rsrc_t rs, int32_t col, double (&xv)[DM]) {
+    const spmv_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, col * (DM * 8), 0, 0);
+    xv[0] = __hiloint2double((int)w.y, (int)w.x);
+    xv[1] = __hiloint2double((int)w.w, (int)w.z);
+    if (DM == 3) {
+        const spmv_u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(rs, col * (DM * 8) + 16, 0, 0);
+        xv[DM - 1] = __hiloint2double((int)w2.y, (int)w2.x);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ SpMV
 // WPS = wavefronts per slice: long rows (C3D10: 27-65 blocks per node) are split into WPS contiguous j-chunks
 // handled by WPS waves of the same workgroup and summed through LDS, so that the chain per wave stays short and
@@ -89,6 +106,7 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)std::min<size_t>((size_t)nn * DM * sizeof(double), 0x7fffffffu), 0x00020000);
     // XCD-aware mapping: physical block b runs on XCD b % 8 (observed dispatch order; speed only).  XCD k
     // walks the contiguous slice range [xr.start[k], xr.start[k+1]), ranges balanced by stored work, so the
     // x-gathers of neighbouring slices share one private L2.  gridDim.x = 8 * blocks-per-XCD; blocks past
@@ -130,10 +148,9 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
                 constexpr bool N = decltype(nt_tag)::value;
 #pragma unroll FEMCY_SPMV_UNROLL
                 for (int32_t j = j0; j < j1; ++j) {
-                    const int64_t col = N ? __builtin_nontemporal_load(&bc[(int64_t)j * SLICE]) : bc[(int64_t)j * SLICE];
+                    const int32_t col = N ? __builtin_nontemporal_load(&bc[(int64_t)j * SLICE]) : bc[(int64_t)j * SLICE];
                     double xv[DM];
-#pragma unroll
-                    for (int cc = 0; cc < DM; ++cc) xv[cc] = x[col * DM + cc];
+                    gather_x<DM>(xrsrc, col, xv);
                     double e[DD];
 #pragma unroll
                     for (int kp = 0; kp < NP; ++kp) {
