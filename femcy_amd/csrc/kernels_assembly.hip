@@ -29,6 +29,18 @@ namespace femcy {
 
 // (det_inv, det3, push_forward3, green_voigt3, cauchy_large: element_math.hpp -- shared with the host backend)
 
+// a gradient row / force row / coordinate triple is dm contiguous doubles at 8-byte alignment: one 16-byte load (+ one
+// 8-byte load for dm = 3) instead of dm 8-byte loads.  The gather kernels are bound by the texture-address path
+// (24-byte gathers: DESIGN.md section 3); a third fewer load instructions is a third fewer address cycles.
+typedef double femcy_d2u __attribute__((ext_vector_type(2), aligned(8)));
+template <int DM>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, double (&v)[DM]) {
+    const femcy_d2u t = *reinterpret_cast<const femcy_d2u*>(p);
+    v[0] = t.x;
+    v[1] = t.y;
+    if (DM == 3) v[DM - 1] = p[2];
+}
+
 // records of W doubles held one per lane -> the workgroup's 256 consecutive records in global memory, written
 // through an LDS transpose so that a wavefront stores 512 consecutive bytes per instruction instead of 64 8-byte
 // pieces 8 W bytes apart (the element pass writes ~100..350 B per element; strided, the stores were its bottleneck)
@@ -79,10 +91,12 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
 #pragma unroll
     for (int a = 0; a < NPE; ++a) {
         const int32_t nd = elems[(int64_t)e * NPE + a];
+        load_row<DM>(nodes + (int64_t)nd * DM, X[a]);
+        if (u) {
+            load_row<DM>(u + (int64_t)nd * DM, U[a]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < DM; ++i) {
-            X[a][i] = nodes[(int64_t)nd * DM + i];
-            U[a][i] = u ? u[(int64_t)nd * DM + i] : 0.0;
+            for (int i = 0; i < DM; ++i) U[a][i] = 0.0;
         }
     }
     for (int g = 0; g < nGP; ++g) {
@@ -320,12 +334,17 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
         for (int k = 0; k < DM * DM; ++k) acc1[k] = 0.0;
         for (int g = 0; g < nGP; ++g) {
             const int64_t b0 = (e0 * nGP + g) * npe, b1 = (e1 * nGP + g) * npe;
+            double ga0[DM], gb0[DM], ga1[DM], gb1[DM];
+            load_row<DM>(dsdx + (b0 + la0) * DM, ga0);
+            load_row<DM>(dsdx + (b0 + lb0) * DM, gb0);
+            load_row<DM>(dsdx + (b1 + la1) * DM, ga1);
+            load_row<DM>(dsdx + (b1 + lb1) * DM, gb1);
             if constexpr (CUBIC && DM == 3) {
-                kblock_cubic3(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, c11, c12, c44, vol[e0 * nGP + g], acc);
-                kblock_cubic3(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, c11, c12, c44, vol[e1 * nGP + g], acc1);
+                kblock_cubic3(ga0, gb0, c11, c12, c44, vol[e0 * nGP + g], acc);
+                kblock_cubic3(ga1, gb1, c11, c12, c44, vol[e1 * nGP + g], acc1);
             } else {
-                kblock_add<DM>(dsdx + (b0 + la0) * DM, dsdx + (b0 + lb0) * DM, C, vol[e0 * nGP + g], acc);
-                kblock_add<DM>(dsdx + (b1 + la1) * DM, dsdx + (b1 + lb1) * DM, C, vol[e1 * nGP + g], acc1);
+                kblock_add<DM>(ga0, gb0, C, vol[e0 * nGP + g], acc);
+                kblock_add<DM>(ga1, gb1, C, vol[e1 * nGP + g], acc1);
             }
         }
 #pragma unroll
@@ -339,10 +358,13 @@ __global__ void __launch_bounds__(256) k_assemble_gather(int64_t npos, int32_t n
         const int64_t e = t / npe;
         for (int g = 0; g < nGP; ++g) {
             const int64_t base = (e * nGP + g) * npe;
+            double ga[DM], gb[DM];
+            load_row<DM>(dsdx + (base + la) * DM, ga);
+            load_row<DM>(dsdx + (base + lb) * DM, gb);
             if constexpr (CUBIC && DM == 3)
-                kblock_cubic3(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, c11, c12, c44, vol[e * nGP + g], acc);
+                kblock_cubic3(ga, gb, c11, c12, c44, vol[e * nGP + g], acc);
             else
-                kblock_add<DM>(dsdx + (base + la) * DM, dsdx + (base + lb) * DM, C, vol[e * nGP + g], acc);
+                kblock_add<DM>(ga, gb, C, vol[e * nGP + g], acc);
         }
     }
     const int64_t row = p >> 6;
@@ -914,8 +936,10 @@ __global__ void __launch_bounds__(256) k_nodal_force(int32_t nn, const int32_t* 
         const int32_t k1 = ne_ptr[a + 1];
         for (int32_t k = ne_ptr[a] + sub; k < k1; k += 32) {
             const double* __restrict__ row = fe + (int64_t)ne_idx[k] * DM;      // ne_idx = e*npe + la: the row of fe
+            double rv[DM];
+            load_row<DM>(row, rv);
 #pragma unroll
-            for (int i = 0; i < DM; ++i) acc[i] += row[i];
+            for (int i = 0; i < DM; ++i) acc[i] += rv[i];
         }
     }
 #pragma unroll

@@ -89,6 +89,7 @@ struct PersistPcg {
     PcgState* st;
     int32_t npad, maxit, lds_rows, dbg, l2_rows;
     uint32_t spin_limit;  // polls before a barrier gives up and poisons the exchange
+    uint32_t xspin_limit; // the same for polls of another rank's words (ranks start their launches milliseconds apart)
     double eps;
     // ---- across ranks (template parameter MULTI): mailboxes written by the peers' kernels, see the block comment
     // "persistent PCG across ranks" below
@@ -263,7 +264,7 @@ __device__ __forceinline__ bool xrank_reduce(const PersistPcg& a, int base, int 
         }
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > a.spin_limit) return false;
+        if (++spins > a.xspin_limit) return false;
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -759,7 +760,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                             uint32_t spins = 0;
                             while (!mb_load(src + 2 * c, tag, other)) {
                                 __builtin_amdgcn_s_sleep(1);
-                                if (++spins > a.spin_limit) { okr = false; break; }
+                                if (++spins > a.xspin_limit) { okr = false; break; }
                             }
                             Ad[t][c] = (tb.z & 0x100) ? other + Ad[t][c] : Ad[t][c] + other;
                         }
@@ -985,6 +986,7 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
     a->xc = reinterpret_cast<unsigned int*>(a->slots + 8 * G);
     a->top = a->xc + 8 * 32;
     a->spin_limit = c->barrier_spin_limit;
+    a->xspin_limit = (uint32_t)std::min<uint64_t>((uint64_t)c->barrier_spin_limit * 16, 1u << 30);   // ~10 s
     a->dbg = c->opt_persist_dbg;
     // granules and counters start at zero (tags / rounds count from 1)
     FEMCY_HIP(hipMemsetAsync(a->slots, 0, sizeof(double) * 8 * G + sizeof(unsigned int) * (8 * 32 + 32), c->stream));
