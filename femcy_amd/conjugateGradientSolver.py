@@ -5,7 +5,8 @@ The reference's `spm`/`sparseIJ` arguments are its ELL value/index fields; here 
 in the femcy context (blocked SELL-64), so `spm` is the owning
 `System_of_equations` (or a `backend.Context`) and `sparseIJ` is ignored.  The recurrence, the
 preconditioner M = 1/diag(A), x0 = 0 and the stopping rule max|r| < eps*max|r0| are the
-reference's; they run as three fused HIP kernels per iteration with no host round trips.
+reference's; they run on the device without host round trips -- as ONE persistent launch per solve where the system
+fits (`k_pcg_persist`, `k_pcg_small`), as three fused kernels per iteration otherwise.
 """
 from . import backend as be
 
