@@ -66,6 +66,24 @@ class MockContext:
         self.part = SimpleNamespace(iface_local_dofs=np.asarray(iface_local_dofs), iface_global_slot=np.asarray(iface_global_slot),
                                     niface_global=niface_global, owner=np.asarray(owner))
 
+    # ---- persistent PCG across ranks: the host side of the mailbox set-up (blobs gathered, imported, agreed).  The
+    # mock has no one-launch kernel, so it agrees and then reports the three-launch path: bench.py's cross-check must
+    # see that the persistent path did not run and switch it off on every rank
+    mailbox_calls = []
+
+    def comm_mailbox_export(self):
+        MockContext.mailbox_calls.append("export")
+        return bytes([self.device]) * 256
+
+    def comm_mailbox_import(self, blobs):
+        assert len(blobs) == int(os.environ["WORLD_SIZE"]) and all(len(b) == 256 for b in blobs)
+        assert [b[0] for b in blobs] == list(range(len(blobs)))           # rank order
+        MockContext.mailbox_calls.append("import")
+
+    def comm_persist_agree(self):
+        MockContext.mailbox_calls.append("agree")
+        return True
+
     # ---- vectors
     class _Vec:
         def __init__(self, ctx, vid):
@@ -173,6 +191,10 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     assert d["value"] > 0 and d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2 and d["dtype"] == "f64"
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
     assert int(np.load(tmp_path / "uid0.npy")[0]) == 1 and int(np.load(tmp_path / "uid1.npy")[0]) == 0
+    # the mailbox set-up ran on the ranks, the agreement said yes, and the cross-check -- the mock's solves are never
+    # the persistent kernel -- switched the path off again, on every rank alike
+    pm = d["config"]["persistent_pcg_across_ranks"]
+    assert pm == {"enabled": False, "took_persistent_path": False, "matches_three_launch_loop": True}, pm
 
 
 # ------------------------------------------------------------------------------------------------ round 3
