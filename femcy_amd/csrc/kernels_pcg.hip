@@ -831,6 +831,8 @@ struct SmallPcg {
     PcgState* st;
     int32_t n, npad, maxit;
     uint32_t spin_limit;   // polls of the grid barrier before a workgroup gives up and poisons the counter
+    int32_t dbg;           // probe build only (FEMCY_PERSIST_PROBE, tools/small_breakdown.py): 32 no Ad loads, 64 no wait,
+                           // 128 no Ad stores, 256 no product, 512 no vector update
     double eps;
 };
 
@@ -847,6 +849,11 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 // share is a quarter of the slice's block rows: the register file holds 8-16 of them next to r and M); the rest is streamed from
 // L2 as before.  Keeping those in LDS as well was measured (same time: the iteration is bound by its synchronisation
 // chain, not by the product) and dropped
+#ifdef FEMCY_PERSIST_PROBE
+#define SDBG(a_, bit_) ((a_).dbg & (bit_))
+#else
+#define SDBG(a_, bit_) false
+#endif
 template <int DM, int K, int RR>
 __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
     extern __shared__ __attribute__((aligned(16))) double lds_small[];
@@ -915,6 +922,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
         for (int r = 0; r < DM; ++r) acc[r] = 0.0;
 #pragma unroll
         for (int jj = 0; jj < RR; ++jj) {
+            if (SDBG(a, 256)) continue;
             double xv[DM];
 #pragma unroll
             for (int cc = 0; cc < DM; ++cc) xv[cc] = d_l[rcl[jj] * DM + cc];
@@ -924,7 +932,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
                 for (int cc = 0; cc < DM; ++cc) acc[r] += rv[jj][r * DM + cc] * xv[cc];
         }
 #pragma unroll 2
-        for (int32_t j = j0 + RR; j < j1; ++j) {
+        for (int32_t j = j0 + RR; j < (SDBG(a, 256) ? 0 : j1); ++j) {
             const int32_t col = bc[(int64_t)j * SLICE];
             double xv[DM], e[DD];
 #pragma unroll
@@ -953,7 +961,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
                 double v = acc[r];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) v += red[(w * DM + r) * 64 + lane];
-                st_sc1(Adw + (int64_t)node * DM + r, v);
+                if (!SDBG(a, 128)) st_sc1(Adw + (int64_t)node * DM + r, v);
                 dold[r] = d_l[node * DM + r];
                 dot += dold[r] * v;
             }
@@ -980,7 +988,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
                     s_fail = 1;
                     break;
                 }
-                if (v >= target) break;
+                if (v >= target || SDBG(a, 64)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > a.spin_limit) {            // a workgroup is missing (not resident / died)
                     __hip_atomic_fetch_or(a.counter, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -998,8 +1006,8 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
         const double ps = tid < G ? ld_sc1(a.part + (size_t)(it & 1) * G + tid) : 0.0;    // G <= 128 < BS
         double av[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) av[k] = ld_sc1(Adw + min(tid + k * BS, n - 1));
-        const double dAd = block_sum(ps, sm1);
+        for (int k = 0; k < K; ++k) av[k] = SDBG(a, 32) ? mm[k] : ld_sc1(Adw + min(tid + k * BS, n - 1));
+        const double dAd = SDBG(a, 64) ? 1.0 : block_sum(ps, sm1);
         const double alpha = rMr / dAd;
         if (wave == 0 && node >= 0) {
 #pragma unroll
@@ -1009,6 +1017,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
         accm = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            if (SDBG(a, 512) && k > 0) continue;
             const bool in = tid + k * BS < n;
             const double ri = in ? rr[k] - alpha * av[k] : 0.0;
             rr[k] = ri;
@@ -1026,7 +1035,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
         const double rMr_new = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
         rmax = fmax(fmax(sm2[0], sm2[1]), fmax(sm2[2], sm2[3]));
         ++it;
-        if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new) {
+        if (!SDBG(a, 0xfe0) && (rmax != rmax || isinf(rmax) || rMr_new != rMr_new)) {
             done = 2;
         } else if (rmax < a.eps * r0) {
             done = 1;
@@ -1034,6 +1043,7 @@ __global__ void __launch_bounds__(BS) k_pcg_small(SmallPcg a) {
             const double beta = rMr_new / rMr;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                if (SDBG(a, 512) && k > 0) continue;
                 const int i = tid + k * BS;
                 if (i < n) d_l[i] = mm[k] * rr[k] + beta * d_l[i];
             }
@@ -1095,6 +1105,7 @@ static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, i
     a.st = c->d_state;
     a.n = (int32_t)c->n; a.npad = (int32_t)npad; a.maxit = maxit; a.eps = eps;
     a.spin_limit = c->barrier_spin_limit;
+    a.dbg = c->opt_persist_dbg;
     FEMCY_HIP(hipMemsetAsync(a.counter, 0, 8, c->stream));
     const int kneed = (int)((c->n + BS - 1) / BS);
     // register buckets: thread t keeps entries t + 256 k, k < K, of r and M

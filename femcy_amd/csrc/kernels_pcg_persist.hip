@@ -43,6 +43,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "wave_reduce.hpp"
+#include "granule.hpp"
 
 // The inter-workgroup protocol below (sc1 write-through stores, sc1 loads, relaxed agent-scope counters, no fences)
 // rests on the cache-policy semantics of the multi-XCD CDNA3 / CDNA4 parts (MI355X_MICROARCH.md "Workgroup dispatch,
@@ -59,7 +60,6 @@ constexpr int PBS = 256;        // 4 waves per workgroup, one workgroup per CU
 constexpr int PNX = 8;
 constexpr int CH = 4;         // block rows per batch of the LDS-resident and the streamed part
 constexpr int V_NT = 1, V_A2A = 2, V_WIDE = 4;
-constexpr unsigned long long TAG_POISON = ~0ull;
 
 // Work-skipping switches for timing experiments (tools/persist_breakdown.py) exist only in a probe build
 // (FEMCY_EXTRA_FLAGS=-DFEMCY_PERSIST_PROBE FEMCY_OUT=../libfemcy_hip_probe.so csrc/build.sh): the shipped library
@@ -112,9 +112,6 @@ __device__ __forceinline__ double pabs(double r) {   // fmax() drops NaN; keep i
     return (a != a) ? INFINITY : a;
 }
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int AUX_SC1 = 16;     // gfx940+ buffer cache-policy bit 4: sc1 = write-through store / L2-served load
 
 // all workgroups of the launch; `round` counts the barriers since the launch (0, 1, 2, ...)
 // `mid` runs in every thread between the arrival and the wait: loads issued there travel while the workgroup waits
@@ -157,55 +154,7 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
     return grid_barrier(a, round, s_fail, [] {});
 }
 
-// ---- tagged-granule exchange (wave 0 of every workgroup).  A granule is one naturally aligned 16-byte {f64 value,
-// u64 tag} written by ONE sc1 store (observed untorn on gfx950, MI355X_MICROARCH.md "Valid forms": R2); tags are
-// the launch-wide round number (1, 2, 3, ...; the arrays are zeroed before the launch), so a slot needs no re-arming
-// and no second buffer: a workgroup can write round k + 1 of an array only after every workgroup has read round k
-// of it (the two other exchanges of the iteration lie in between).
-__device__ __forceinline__ void granule_store(const __amdgpu_buffer_rsrc_t rs, int idx, double v, unsigned long long tag) {
-    u32x4 w;
-    w.x = (unsigned)__double2loint(v);
-    w.y = (unsigned)__double2hiint(v);
-    w.z = (unsigned)tag;
-    w.w = (unsigned)(tag >> 32);
-    __builtin_amdgcn_raw_buffer_store_b128(w, rs, idx * 16, 0, AUX_SC1);
-}
-// NV granules per workgroup, stored [G][NV]; lane sweeps workgroups lane, lane + 64, ...; sums / maxima in a fixed
-// order (the same in every workgroup).  op[v]: 0 = sum, 1 = max.  Returns false on poison or time-out (the caller's
-// workgroup then poisons its own granules, which every other sweep sees).
-template <int NV>
-__device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, int base, int G, unsigned long long tag,
-                                              uint32_t spin_limit, double (&out)[NV], const int (&op)[NV]) {
-    const int lane = threadIdx.x & 63;
-    uint32_t spins = 0;
-    for (;;) {
-        double acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-        bool ok = true, poison = false;
-        for (int k = lane; k < G; k += 64) {
-            u32x4 w[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) w[v] = __builtin_amdgcn_raw_buffer_load_b128(rs, (base + k * NV + v) * 16, 0, AUX_SC1);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const unsigned long long t = ((unsigned long long)w[v].w << 32) | w[v].z;
-                ok = ok && (t == tag);
-                poison = poison || (t == TAG_POISON);
-                const double val = __hiloint2double((int)w[v].y, (int)w[v].x);
-                acc[v] = op[v] ? fmax(acc[v], val) : acc[v] + val;
-            }
-        }
-        if (__any(poison)) return false;
-        if (__all(ok)) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) out[v] = op[v] ? wave_max(acc[v]) : wave_sum(acc[v]);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > spin_limit) return false;
-    }
-}
+// ---- tagged-granule exchange (wave 0 of every workgroup): granule.hpp
 
 // ------------------------------------------------------------------------------- persistent PCG across ranks
 // With a communicator attached round 2 fell back to three launches + 2-3 RCCL calls per iteration (51-63 us against
