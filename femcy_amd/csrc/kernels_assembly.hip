@@ -502,6 +502,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 //     are written 16 bytes at a time; what bounds the kernel besides LDS and VALU is ~0.9 GB of fabric traffic for
 //     a 357 MB matrix, and only writing whole 128-byte lines (eight adjacent rows at once) would remove it.)
 // Deterministic: fixed pass order, ds_add_f64 of one instruction applied in lane order, fixed-order diagonal sum.
+// Where its time goes (profiles/r03_rows2_probe.txt; build with -DFEMCY_ROWS2_PROBE=<bits>, results meaningless): bit 1
+// plain LDS stores instead of atomics, 2 no LDS reads / arithmetic, 4 no LDS block writes, 8 no record loads, 16 no
+// global stores, 32 no row end, 64 no staging writes.
+#ifdef FEMCY_ROWS2_PROBE
+#define ROWS2_PROBE_BIT(b_) ((FEMCY_ROWS2_PROBE & (b_)) != 0)
+#else
+#define ROWS2_PROBE_BIT(b_) 0
+#endif
 template <int NPE, int NGP, bool CUBIC>
 __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t Lmax,
                                                         const int32_t* __restrict__ ne_ptr,
@@ -572,7 +580,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
             const int32_t p_ = lane + 64 * u;                                                         \
             const int32_t q_ = p_ / P16, w_ = p_ - q_ * P16;                                          \
             const int64_t e_ = __shfl((code_), q_, 64) / NPE;                                         \
-            if (p_ < nE_ * P16) R[u] = reinterpret_cast<const double2*>(dsdx + e_ * RD)[w_];          \
+            if (p_ < nE_ * P16 && !ROWS2_PROBE_BIT(8)) R[u] = reinterpret_cast<const double2*>(dsdx + e_ * RD)[w_];   \
         }                                                                                             \
         const int32_t qv_ = lane / NGP, gv_ = lane - qv_ * NGP;                                       \
         const int64_t ev_ = __shfl((code_), qv_, 64) / NPE;                                           \
@@ -604,7 +612,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
         for (int u = 0; u < NIT; ++u) {
             const int32_t p = lane + 64 * u;
             const int32_t q = p / P16, w = p - q * P16;
-            if (p < nE * P16) reinterpret_cast<double2*>(rec + q * RD)[w] = R[u];
+            if (p < nE * P16 && !ROWS2_PROBE_BIT(64)) reinterpret_cast<double2*>(rec + q * RD)[w] = R[u];
         }
         if (lane < nE * NGP) vl[lane] = V;
         int32_t j = JS;
@@ -626,13 +634,24 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
             for (int g = 0; g < NGP; ++g) {
                 const double* ga = rec + q * RD + (g * NPE + la) * DM;
                 const double* gb = rec + q * RD + (g * NPE + lb) * DM;
-                if (CUBIC) kblock_cubic3(ga, gb, c11, c12, c44, vl[q * NGP + g], blk);
+#if ROWS2_PROBE_BIT(2)
+                blk[g] += (double)(q + lb);                           // probe: no LDS reads, no arithmetic
+#else
+                if (CUBIC) outer3_add(ga, gb, vl[q * NGP + g], blk);   // the geometric sum; constants at the end of the row
                 else kblock_add<3>(ga, gb, C, vl[q * NGP + g], blk);
+#endif
             }
+#if ROWS2_PROBE_BIT(1)
+#pragma unroll
+            for (int k = 0; k < DD; ++k) acc[j * DD + k] = blk[k];   // probe: plain LDS stores instead of atomics
+#elif ROWS2_PROBE_BIT(4)
+            if (blk[0] == 1.2345) acc[j] = blk[1] + blk[2] + blk[3] + blk[4] + blk[5] + blk[6] + blk[7] + blk[8];   // probe: no LDS writes
+#else
 #pragma unroll
             for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
+#endif
         }
-        if (c00 + EPC >= cnt) {                                 // last pass of the row: diagonal, write-out
+        if (c00 + EPC >= cnt && !ROWS2_PROBE_BIT(32)) {         // last pass of the row: diagonal, constants, write-out
             const int32_t L = ROW_L(i0);
             const int r = wave + 4 * i0;
             wave_lds_sync();
@@ -652,17 +671,32 @@ __global__ void __launch_bounds__(256) k_assemble_rows2(int32_t nslices, int32_t
                 acc[lane] = -t;
             }
             wave_lds_sync();
+            if (CUBIC) {                                        // S -> K, one stored block per lane, in place
+                for (int32_t jb = lane; jb < L; jb += 64) {
+                    double S[DD], Kb[DD];
+#pragma unroll
+                    for (int k = 0; k < DD; ++k) S[k] = acc[jb * DD + k];
+                    cubic_from_outer3(S, c11, c12, c44, Kb);
+#pragma unroll
+                    for (int k = 0; k < DD; ++k) acc[jb * DD + k] = Kb[k];
+                }
+                wave_lds_sync();
+            }
             // the row: per block four 16-byte pairs + the trailing 8-byte entry (kv_index layout), lane r of the slice
             double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
             for (int idx = lane; idx < L * 5; idx += 64) {
                 const int j = idx / 5, pc = idx - j * 5;
                 double* dst = Krow + (int64_t)j * (DD * SLICE);
+#if ROWS2_PROBE_BIT(16)
+                if (pc < 4) acc[j * DD + 2 * pc] += (double)(r + (dst - Krow));     // probe: no store instructions
+#else
                 if (pc < 4) {
                     reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] =
                         make_double2(acc[j * DD + 2 * pc], acc[j * DD + 2 * pc + 1]);
                 } else {
                     dst[4 * (2 * SLICE) + r] = acc[j * DD + 8];
                 }
+#endif
             }
             wave_lds_sync();
             if (i0 + 1 < nrows)
