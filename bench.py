@@ -206,6 +206,20 @@ def algorithmic_bytes(info, nn, n):
     return spmv, spmv + 88 * n
 
 
+def read_stream_probe(ctx, be, footprint):
+    """GB/s of a read-only sweep of `footprint` bytes (capped at 1 GiB) with eight workgroups per CU and 16-byte loads,
+    best of the default / non-temporal policy (femcy_probe_stream modes 2, 3): what a read-mostly kernel such as the
+    SpMV can reach on THIS GPU from HBM -- the demonstrated ceiling next to the 8 TB/s of the spec"""
+    if not hasattr(ctx, "probe_stream"):
+        return None
+    try:
+        nbytes = int(max(1 << 20, min(int(footprint), 1 << 30)))
+        return max(ctx.probe_stream(nbytes, 8, mode)[0] for mode in (2, 3) for _ in range(2))
+    except be.FemcyError as e:
+        log(f"[bench] read-stream probe failed: {e}")
+        return None
+
+
 def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iters=100, spmv_reps=40):
     """one HBM-bound configuration on this GPU: SpMV (dispatch-attached HIP events on every launch) and the PCG
     iteration (whole solves of `iters` iterations, every 16th SpMV sampled) with their algorithmic-byte rates"""
@@ -247,12 +261,14 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         path = ("persistent" if tm["solves_persist"] else "three-kernel")
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
         iter_gbs = iter_b / (iter_us * 1e-6) / 1e9
+        rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
         rec = {"workload": name, "elements": int(ctx.ne), "dof": int(ctx.n), "stored_matrix_mb": info.stored_blocks * 76 / 1e6,
                "pcg_path": path,
                "spmv": {"kernel": f"k_spmv<{ctx.dm}>", "bound": "hbm", "avg_launch_us": spmv_us,
                         "launches_timed": int(spmv_reps), "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                        "frac_of_copy_probe": (spmv_gbs / probe) if probe else None},
+                        "frac_of_copy_probe": (spmv_gbs / probe) if probe else None,
+                        "read_stream_probe_gbs": rprobe, "frac_of_read_stream_probe": (spmv_gbs / rprobe) if rprobe else None},
                "pcg_iteration": {"us": iter_us, "iterations_timed": int(its), "bytes": int(iter_b), "achieved": iter_gbs,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": iter_gbs / HBM_PEAK_GBS,
                                  "frac_of_copy_probe": (iter_gbs / probe) if probe else None},
@@ -575,6 +591,10 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "peak_source": "spec (MI355X_MICROARCH.md)",
                 "frac_of_copy_probe": (achieved / probe) if probe else None,
                 "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us, "launches_timed": int(tm["spmv_launches"])}
+    if not persist and on_gpu and rank == 0:
+        rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
+        roof["read_stream_probe_gbs"] = rprobe
+        roof["frac_of_read_stream_probe"] = (roof["achieved"] / rprobe) if rprobe else None
     traffic, traffic_src = pmc_traffic(args.workload, kernel) if not args.cells else (None, "non-standard --cells")
     roof["traffic"], roof["traffic_source"] = traffic, traffic_src
     roof["copy_probe_gbs"] = probe
