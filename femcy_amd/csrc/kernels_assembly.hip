@@ -1303,7 +1303,11 @@ int launch_assemble(Ctx* c) {
                       "ROWS2 assembly is instantiated for C3D10 / C3D4 tables with sum_a dN_a = 0 (npe %d, nGP %d)", c->npe, c->nGP);
         const int T = c->npe - 1, EPC = 64 / T, RD = c->nGP * c->npe * 3;
         const int volw = (EPC * c->nGP + 1) & ~1, codew = (EPC + 1) / 2 * 2 / 2 + 1, accw = (c->max_row_blocks * 9 + 1) & ~1;
+#ifdef FEMCY_ROWS2_LDS_PAD      /* occupancy experiments: fewer workgroups per CU (profiles/r03_rows2_probe.txt) */
+        const size_t lds = (size_t)4 * (EPC * RD + volw + accw + 2 * codew) * sizeof(double) + FEMCY_ROWS2_LDS_PAD;
+#else
         const size_t lds = (size_t)4 * (EPC * RD + volw + accw + 2 * codew) * sizeof(double);
+#endif
         // the accumulator of a row grows with the longest row of the mesh (288 B per block): an unstructured mesh with
         // high-valence nodes can exceed what a workgroup may allocate -- AUTO then takes ROWS (its LDS is 4 rows only)
         if (lds + 512 > (size_t)c->small_max_lds) {
