@@ -443,14 +443,20 @@ def main():
         # which a step fails still takes part in the agreement (with a "no")
         pmulti = {"enabled": False}
         if hasattr(ctx, "comm_mailbox_export") and os.environ.get("FEMCY_BENCH_PERSIST_MULTI", "1") != "0":
+            try:                                                 # export may fail on ONE rank: it still joins the
+                blob = ctx.comm_mailbox_export()                 # all-gather below (with None), or the others hang in it
+            except Exception as e:                               # noqa: BLE001
+                log(f"[bench] rank {rank}: mailbox export failed ({e})")
+                blob = None
             try:
                 with Watchdog(args.comm_timeout, "mailbox exchange"):
-                    blob = ctx.comm_mailbox_export()
                     blobs = [None] * N
                     if use_dist:
                         dist.all_gather_object(blobs, blob)
                     else:
                         blobs = [blob]
+                    if any(b is None for b in blobs):
+                        raise RuntimeError(f"no mailbox on rank(s) {[i for i, b in enumerate(blobs) if b is None]}")
                     ctx.comm_mailbox_import(blobs)
             except Exception as e:                               # noqa: BLE001
                 log(f"[bench] rank {rank}: mailbox set-up failed ({e}); this rank votes for the RCCL loop")

@@ -84,8 +84,16 @@ class System_of_equations:
             # -- systems large enough for the one-launch kernel -- and a rank where the set-up fails votes "no"
             self.persistent_across_ranks = False
             if gather_blobs is not None:
+                try:                                 # a rank whose export fails still joins the all-gather (with None)
+                    blob = self.ctx.comm_mailbox_export()
+                except be.FemcyError as e:
+                    self._say(f"mailbox export failed ({e})")
+                    blob = None
                 try:
-                    self.ctx.comm_mailbox_import(gather_blobs(self.ctx.comm_mailbox_export()))
+                    blobs = gather_blobs(blob)
+                    if any(b is None for b in blobs):
+                        raise be.FemcyError("a rank has no mailbox")
+                    self.ctx.comm_mailbox_import(blobs)
                 except be.FemcyError as e:
                     self._say(f"mailbox set-up failed ({e}): three launches + collectives per CG iteration")
                     self.ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)

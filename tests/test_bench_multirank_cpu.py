@@ -73,6 +73,8 @@ class MockContext:
 
     def comm_mailbox_export(self):
         MockContext.mailbox_calls.append("export")
+        if os.environ.get("FEMCY_MOCK_FAIL_EXPORT_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("mock: no mailbox on this rank")
         return bytes([self.device]) * 256
 
     def comm_mailbox_import(self, blobs):
@@ -236,3 +238,13 @@ def test_bench_self_launch_times_out_on_a_hung_rank():
     out = _self_launch({"FEMCY_MOCK_HANG_RANK": "1"}, extra_args=("--comm-timeout", "8"))
     assert out.returncode != 0 and time.time() - t < 240
     assert "did not finish within" in out.stderr
+
+
+def test_bench_survives_a_rank_without_mailbox():
+    """the mailbox export fails on ONE rank: that rank still joins the all-gather (with None), every rank votes for the
+    RCCL loop, the run completes -- the other ranks do not hang in the collective"""
+    out = _self_launch({"FEMCY_MOCK_FAIL_EXPORT_RANK": "1"}, extra_args=("--comm-timeout", "60"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["config"]["persistent_pcg_across_ranks"]["took_persistent_path"] is False
+    assert "mailbox export failed" in out.stderr and "no mailbox on rank(s) [1]" in out.stderr
