@@ -63,8 +63,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, HBM section); the D2D probe below reports what
                                 # a plain device copy reaches on the box the bench runs on
 ELEMS_PER_GPU = {"c3d4": 995328, "c3d10": 124416}
-TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/kernels_pcg_persist.hip", "femcy_amd/csrc/ctx.hpp",
-                   "femcy_amd/csrc/pattern.cpp")
+TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/kernels_pcg_persist.hip", "femcy_amd/csrc/granule.hpp",
+                   "femcy_amd/csrc/wave_reduce.hpp", "femcy_amd/csrc/ctx.hpp", "femcy_amd/csrc/pattern.cpp")
 
 
 def log(*a):
