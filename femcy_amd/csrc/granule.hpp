@@ -8,6 +8,10 @@
 #include <hip/hip_runtime.h>
 #include "wave_reduce.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the sc1-only hand-off protocols of the one-launch PCG kernels are validated for gfx942 / gfx950 only"
+#endif
+
 namespace femcy {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
