@@ -50,7 +50,7 @@ TUNE_SKIP_OCCUPANCY_CHECK = 111
 TUNE_BARRIER_SPIN_LIMIT = 112
 TUNE_PERSIST_L2_ROWS = 113
 OPT_OVERLAP = 9          # multi-rank, neighbour exchange: 1 (default) = exchange overlapped with the interior product
-ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2, ASM_ROWS3 = 0, 1, 2, 3, 4, 5, 6, 7
+ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2, ASM_ROWS3, ASM_ROWS4 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = [
     "femcy_ctx_create", "femcy_ctx_destroy", "femcy_last_error", "femcy_version", "femcy_set_option", "femcy_sync",

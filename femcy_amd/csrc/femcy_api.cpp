@@ -291,7 +291,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
     CTX_OR_FAIL(ctx);
     switch (option) {
         case FEMCY_OPT_ASSEMBLY:
-            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS3, "bad assembly mode %lld", (long long)value);
+            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS4, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
         case FEMCY_OPT_PCG_POLL:

@@ -950,6 +950,241 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
     for (int k = 0; k < DM * DM; ++k) unsafeAtomicAdd(&Kvals[kv_index<DM>(row, k, lane)], acc[k]);
 }
 
+// row-centric assembly, fourth form (round 3): TWO rows per wavefront at a time, half a wave (32 lanes) each.
+// profiles/r03_rows2_probe.txt: rows2 spends ~1 000 instructions per matrix row -- a wave runs the whole pass
+// machinery (element lists, record staging, row end) for ONE row whose typical pass fills 45 of its 64 lanes and most
+// of whose control is scalar -- and it is bound by the number of instructions the CU can issue, not by arithmetic,
+// bandwidth or latency.  Here every instruction of the machinery serves two rows:
+//   * lanes 0..31 own row i, lanes 32..63 row i + 1 of the wave's share of the slice (rows sorted by length: the two
+//     have the same number of incident elements or nearly); a step takes up to three incident elements per row: lane
+//     (q, t) = (gl / 10, gl % 10) computes the block of column node t of element q -- the diagonal block included
+//     (t = the row node), so there is no row-sum pass and the element tables need not sum to zero;
+//   * within a row the ten lanes of an element hit ten different slots, the three elements rarely the same one:
+//     ds_add_f64 without the 7-way conflicts the diagonal had in a 64-lane pass;
+//   * the records of a step (6 x 16 bytes per lane) are prefetched during the step before, as in rows2;
+//   * at the end of a pair of rows each lane takes one stored block (32 per trip: one trip for most rows) out of LDS,
+//     leaves zeros, applies the material constants and stores its five pieces.
+// Deterministic for the same reason as rows2 (fixed step order, ds_add_f64 of one instruction applied in lane order).
+template <int NPE, int NGP, bool CUBIC>
+__global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax,
+                                                        const int32_t* __restrict__ ne_ptr,
+                                                        const int32_t* __restrict__ ne_idx,
+                                                        const uint16_t* __restrict__ slotj,
+                                                        const int32_t* __restrict__ rowlen,
+                                                        const int32_t* __restrict__ node_of,
+                                                        const int64_t* __restrict__ slice_off,
+                                                        const double* __restrict__ dsdx, const double* __restrict__ vol,
+                                                        const double* __restrict__ C, double c11, double c12, double c44,
+                                                        double* __restrict__ Kvals) {
+    constexpr int DM = 3, DD = 9, G = 32, EPG = G / NPE, RD = NGP * NPE * DM, P16 = RD / 2;
+    constexpr int NIT = P16 / NPE;                               // 16-byte pieces per lane and step (C3D10: 6): lane (q, t)
+                                                                 // fetches and stages pieces t, t + 10, ... of ITS element
+                                                                 // q -- one address per lane and step, the rest immediates
+    constexpr int VOLW = (EPG * NGP + 1) & ~1;
+    static_assert(RD % 2 == 0 && EPG == 3 && P16 % NPE == 0 && NGP <= NPE, "half-wave layout: three elements per row and step");
+    extern __shared__ __attribute__((aligned(16))) double lds_rows4[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 5, gl = lane & 31, gbase = grp * G;
+    const int q = gl / NPE, t = gl - q * NPE;                    // element of the step, column node
+    const int accw = (Lmax * DD + 1) & ~1;
+    double* wbase = lds_rows4 + (size_t)wave * 2 * (EPG * RD + VOLW + accw + 2);
+    double* rec = wbase + (size_t)grp * (EPG * RD + VOLW + accw + 2);      // this half's records
+    double* vl = rec + EPG * RD;
+    double* acc = vl + VOLW;
+    int32_t* codes = reinterpret_cast<int32_t*>(acc + accw);               // [4]
+    const int32_t s = blockIdx.x;
+    if (s >= nslices) return;
+    const int64_t off_v = slice_off[s];
+    const int64_t off = ((int64_t)__builtin_amdgcn_readfirstlane((int32_t)(off_v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)off_v);
+
+    // ---- the wave's rows (slice lanes wave, wave + 4, ...): lane i holds the metadata of its i-th row
+    constexpr int RPW = SLICE / 4;
+    int32_t m_L = 0, m_k0 = 0, m_cnt = 0;
+    bool m_valid = false;
+    if (lane < RPW) {
+        const int32_t a = node_of[(int64_t)s * SLICE + wave + 4 * lane];
+        if (a >= 0) {
+            m_valid = true;
+            m_L = rowlen[a];
+            m_k0 = ne_ptr[a];
+            m_cnt = ne_ptr[a + 1] - m_k0;
+        }
+    }
+    const int nrows = __popcll(__ballot(m_valid));               // valid rows are a prefix
+    if (nrows == 0) return;
+    const int npairs = (nrows + 1) / 2;
+#define R4_CNT(i) __builtin_amdgcn_readlane(m_cnt, (i))
+    // steps of pair b: enough for the longer of its two element lists, at least one (a row without elements is still
+    // written)
+    auto steps_of = [&](int b) -> int {
+        const int32_t c = max(R4_CNT(2 * b), R4_CNT(2 * b + 1));           // rows >= nrows: cnt = 0
+        return max(1, (c + EPG - 1) / EPG);
+    };
+    auto advance = [&](int& b, int& c) {
+        ++c;
+        if (b < npairs && c >= steps_of(b)) {
+            ++b;
+            c = 0;
+        }
+    };
+    // per-lane view of step (b, c): elements of MY row in this step
+    // a value of row 2 b (lower half) / 2 b + 1 (upper half) of the metadata lanes: two scalar reads and a select.
+    // NO cross-lane traffic through the LDS in the loop: a step of the first version made twelve ds_bpermute round
+    // trips one after the other (each waits for the one before: ~1 400 cycles per step, 118 of the kernel's 334 us with
+    // everything else compiled out, profiles/r03_rows4_probe.txt)
+#define R4_ROWVAL(m_, b_) (grp ? __builtin_amdgcn_readlane((m_), min(2 * (b_) + 1, 63)) : __builtin_amdgcn_readlane((m_), min(2 * (b_), 63)))
+    auto my_nE = [&](int b, int c) -> int32_t {                  // pairs beyond the last: rows with cnt = 0
+        const int32_t cnt = R4_ROWVAL(m_cnt, b);
+        return max(0, min(EPG, cnt - EPG * c));
+    };
+    // Every global load of the loop is UNCONDITIONAL (lanes without work read entry 0 and the value is dropped) and
+    // no loaded value is touched before the step that needs it: only then are the compiler's waits counted
+    // (s_waitcnt vmcnt(N), N = the loads of the step in between) instead of vmcnt(0), and a step waits for the loads
+    // issued TWO steps earlier while the batch issued one step earlier stays in flight.  With ~300 instructions per
+    // step the loop is latency-bound (profiles/r03_rows4_probe.txt): the second batch in flight is what pays here
+    // (it did not in rows2, which is bound by its instruction count).
+    auto load_codes = [&](int b, int c) -> int32_t {             // lane gl < nE of each half: (element, local row node) code
+        const int32_t nE = my_nE(b, c);
+        const int32_t k0 = R4_ROWVAL(m_k0, b);
+        return ne_idx[gl < nE ? k0 + EPG * c + gl : 0];          // other lanes: any valid code, never used
+    };
+    double2 RA[NIT], RB[NIT];
+    double VA = 0.0, VB = 0.0;
+    int32_t JA = 0, JB = 0;
+    // the three element codes of MY row in a step: lanes 0..2 / 32..34 of the list register, read as scalars
+#define R4_CODES(code_, k0_, k1_, k2_)                                                                \
+    const int32_t k0_ = grp ? __builtin_amdgcn_readlane((code_), 32) : __builtin_amdgcn_readlane((code_), 0);   \
+    const int32_t k1_ = grp ? __builtin_amdgcn_readlane((code_), 33) : __builtin_amdgcn_readlane((code_), 1);   \
+    const int32_t k2_ = grp ? __builtin_amdgcn_readlane((code_), 34) : __builtin_amdgcn_readlane((code_), 2);
+#define R4_PICK(q_, a0_, a1_, a2_) ((q_) == 0 ? (a0_) : ((q_) == 1 ? (a1_) : (a2_)))
+#define R4_LOAD_RECORDS(R_, V_, J_, code_, b_, c_)                                                    \
+    {                                                                                                 \
+        const int32_t nE_ = my_nE((b_), (c_));                                                        \
+        R4_CODES(code_, kk0_, kk1_, kk2_)                                                             \
+        const bool ok_ = q < nE_;                                                                     \
+        const int32_t kq_ = ok_ ? R4_PICK(q, kk0_, kk1_, kk2_) : 0;      /* my element's code; 0 = any valid one */ \
+        const int64_t eq_ = kq_ / NPE;                                                                \
+        const double2* rb_ = reinterpret_cast<const double2*>(dsdx + eq_ * RD) + t;                   \
+        _Pragma("unroll") for (int u = 0; u < NIT; ++u)                                               \
+            if (!ROWS2_PROBE_BIT(8)) R_[u] = rb_[NPE * u];                                            \
+        V_ = vol[eq_ * NGP + (t < NGP ? t : 0)];                                                      \
+        J_ = slotj[(int64_t)kq_ * NPE + t];                                                           \
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) RA[u] = RB[u] = make_double2(0.0, 0.0);
+
+    // steps p .. p + 4: (pair of rows, step inside the pair)
+    int b0 = 0, c00 = 0, b1 = 0, c01 = 0, b2, c02, b3, c03, b4, c04;
+    advance(b1, c01);
+    b2 = b1; c02 = c01; advance(b2, c02);
+    b3 = b2; c03 = c02; advance(b3, c03);
+    b4 = b3; c04 = c03; advance(b4, c04);
+    int32_t code0 = load_codes(b0, c00), code1 = load_codes(b1, c01), cnewA = load_codes(b2, c02),
+            cnewB = load_codes(b3, c03);
+    R4_LOAD_RECORDS(RA, VA, JA, code0, b0, c00)
+    R4_LOAD_RECORDS(RB, VB, JB, code1, b1, c01)
+    for (int idx = gl; idx < accw; idx += G) acc[idx] = 0.0;     // every row leaves the slots it used zeroed
+
+    auto compute = [&](int32_t nE, int32_t j, int32_t la) {
+        if (gl < nE * NPE) {
+            double blk[DD];
+#pragma unroll
+            for (int k = 0; k < DD; ++k) blk[k] = 0.0;
+#pragma unroll
+            for (int g = 0; g < NGP; ++g) {
+                const double* ga = rec + q * RD + (g * NPE + la) * DM;
+                const double* gb = rec + q * RD + (g * NPE + t) * DM;
+#if ROWS2_PROBE_BIT(2)
+                blk[g] += (double)(q + t + la);                        // probe: no LDS reads, no arithmetic
+#else
+                if (CUBIC) outer3_add(ga, gb, vl[q * NGP + g], blk);   // geometric sum; constants at the end of the row
+                else kblock_add<3>(ga, gb, C, vl[q * NGP + g], blk);
+#endif
+            }
+#if ROWS2_PROBE_BIT(1)
+#pragma unroll
+            for (int k = 0; k < DD; ++k) acc[j * DD + k] = blk[k];   // probe: plain LDS stores instead of atomics
+#elif ROWS2_PROBE_BIT(4)
+            if (blk[0] == 1.2345) acc[j] = blk[1] + blk[2] + blk[3] + blk[4] + blk[5] + blk[6] + blk[7] + blk[8];   // probe: no LDS writes
+#else
+#pragma unroll
+            for (int k = 0; k < DD; ++k) atomicAdd(&acc[j * DD + k], blk[k]);
+#endif
+        }
+    };
+    auto pair_end = [&](int b) {                                // the pair is complete: constants, write-out, zeros
+        const int32_t i = 2 * b + grp;
+        const int32_t L = R4_ROWVAL(m_L, b);                    // rows >= nrows: 0
+        const int r = wave + 4 * i;
+        double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
+        int32_t ln = gl;
+        asm volatile("" : "+v"(ln));    // addresses built on the lane are computed HERE, not hoisted into VGPRs for the
+                                        // whole kernel
+        wave_lds_sync();                                        // the atomics of the last step have landed
+        for (int32_t jb = ln; jb < L; jb += G) {
+            double S[DD], Kb[DD];
+#pragma unroll
+            for (int k = 0; k < DD; ++k) S[k] = acc[jb * DD + k];
+#pragma unroll
+            for (int k = 0; k < DD; ++k) acc[jb * DD + k] = 0.0;
+            if (CUBIC) cubic_from_outer3(S, c11, c12, c44, Kb);
+            else {
+#pragma unroll
+                for (int k = 0; k < DD; ++k) Kb[k] = S[k];
+            }
+#if ROWS2_PROBE_BIT(16)
+            if (Kb[0] + Kb[1] + Kb[2] + Kb[3] + Kb[4] + Kb[5] + Kb[6] + Kb[7] + Kb[8] == 1.2345) acc[jb * DD] = (double)r;   // probe: no stores
+#else
+            double* dst = Krow + (int64_t)jb * (DD * SLICE);
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc)
+                reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
+            dst[4 * (2 * SLICE) + r] = Kb[8];
+#endif
+        }
+    };
+    // one step: stage set X (records of step p) into LDS, refill X with the records of step p + 2 (their element list
+    // arrived two steps ago), fetch the list of step p + 4, compute step p
+#define R4_STEP(R_, V_, J_, CN_)                                                                      \
+    {                                                                                                 \
+        int32_t code2 = CN_;                                    /* list of step p + 2, fetched in step p - 2 */ \
+        asm volatile("" : "+v"(code2));                         /* its own register: the refill of CN_ is not copied at the latch */ \
+        const int32_t nE = my_nE(b0, c00);                                                            \
+        R4_CODES(code0, kc0, kc1, kc2)                                                                \
+        const int32_t la = R4_PICK(q, kc0, kc1, kc2) % NPE;     /* the row node inside my element of this step */ \
+        wave_lds_sync();                                        /* the previous step is done with rec / vl */ \
+        if (q < nE && !ROWS2_PROBE_BIT(64)) {                                                         \
+            double2* sb_ = reinterpret_cast<double2*>(rec + q * RD) + t;                              \
+            _Pragma("unroll") for (int u = 0; u < NIT; ++u) sb_[NPE * u] = R_[u];                     \
+            if (t < NGP) vl[q * NGP + t] = V_;                                                        \
+        }                                                                                             \
+        int32_t j = J_;                                                                               \
+        asm volatile("" : "+v"(j));     /* take the copy HERE, before the refill overwrites the register */ \
+        CN_ = load_codes(b4, c04);                                                                    \
+        R4_LOAD_RECORDS(R_, V_, J_, code2, b2, c02)                                                   \
+        wave_lds_sync();                                                                              \
+        compute(nE, j, la);                                                                           \
+        if (b0 < npairs && c00 + 1 >= steps_of(b0) && !ROWS2_PROBE_BIT(32)) pair_end(b0);             \
+        b0 = b1; c00 = c01; b1 = b2; c01 = c02; b2 = b3; c02 = c03; b3 = b4; c03 = c04;               \
+        advance(b4, c04);                                                                             \
+        code0 = code1; code1 = code2;                                                                 \
+    }
+    // ONE exit, at the latch (a break between the halves becomes an edge from the first half to the loop header in
+    // the structured control flow, and the path-insensitive wait-count analysis then drains everything there); a step
+    // beyond the last pair -- the second half, at most once per wave -- is empty
+    while (b0 < npairs) {
+        R4_STEP(RA, VA, JA, cnewA)
+        R4_STEP(RB, VB, JB, cnewB)
+    }
+#undef R4_STEP
+#undef R4_PICK
+#undef R4_CODES
+#undef R4_ROWVAL
+#undef R4_LOAD_RECORDS
+#undef R4_CNT
+}
+
 // ----------------------------------------------------------------------------- nodal force gather
 // assemble_nodal_force_GN_kernel (stiffnessMtrx.py:620-644) is node-parallel with a serial loop over the padded
 // nodeEles row that reads a gradient row, a stress tensor and a weight per (element, Gauss point).  Here the element
@@ -1331,7 +1566,27 @@ int launch_assemble(Ctx* c) {
         }
 #undef FEMCY_ROWS2
     }
-    if (mode == FEMCY_ASM_ROWS2 || mode == FEMCY_ASM_ROWS3) {
+    if (mode == FEMCY_ASM_ROWS4) {
+        FEMCY_REQUIRE(c->dm == 3 && c->npe == 10 && c->nGP == 4, "ROWS4 assembly is instantiated for C3D10 (npe %d, nGP %d)",
+                      c->npe, c->nGP);
+        const int EPG = 32 / c->npe, RD = c->nGP * c->npe * 3;
+        const int volw = (EPG * c->nGP + 1) & ~1, accw = (c->max_row_blocks * 9 + 1) & ~1;
+        const size_t lds = (size_t)4 * 2 * (EPG * RD + volw + accw + 2) * sizeof(double);
+        FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS4 assembly needs %zu B of LDS per workgroup (longest row: %d "
+                      "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
+#define FEMCY_ROWS4(CUB_)                                                                                              \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,    \
+                           c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,         \
+                           c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
+                           c->d_Kvals);                                                                                \
+    } while (0)
+        if (c->C_is_cubic) FEMCY_ROWS4(true); else FEMCY_ROWS4(false);
+#undef FEMCY_ROWS4
+    } else if (mode == FEMCY_ASM_ROWS2 || mode == FEMCY_ASM_ROWS3) {
     } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);

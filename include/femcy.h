@@ -88,8 +88,10 @@ enum femcy_assembly {
     FEMCY_ASM_ROWS2 = 6,  /* ROWS with the element records staged in LDS, one workgroup per 64-row slice, row-sum
                              diagonal, 30-flop blocks for cubic-pattern C: AUTO picks it for C3D10 (3.x faster than ROWS);
                              instantiated for C3D10 and C3D4 tables whose gradients sum to zero */
-    FEMCY_ASM_ROWS3 = 7   /* ROWS2 with eight adjacent rows finished together and written as whole 128-byte lines
+    FEMCY_ASM_ROWS3 = 7,  /* ROWS2 with eight adjacent rows finished together and written as whole 128-byte lines
                              (no read-for-fill of K: round 3) */
+    FEMCY_ASM_ROWS4 = 8   /* two rows per wavefront at a time (half a wave each, three incident elements per step, the
+                             diagonal block computed like the others): round 3, C3D10 */
 };
 
 enum femcy_option {

@@ -374,7 +374,7 @@ def test_c3d10_bench_size_against_c_oracle(quad):
         assert rel(ys[wps], yo) < 1e-12
     ctx.set_option(be.OPT_SPMV_VARIANT, 0)
     scale = np.abs(yo).max()
-    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_AUTO):
+    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_ROWS4, be.ASM_AUTO):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(be.VEC_DOF)
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)

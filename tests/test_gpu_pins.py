@@ -43,6 +43,8 @@ def test_one_element_Ke_equals_exact_integration(gpu_ctx_factory, etype):
     mat = SimpleNamespace(kind=be_kind("lin3d"), C=C, params=np.array([1.0, 0.25]))
     ctx = _ctx(gpu_ctx_factory, X, el, _ele(etype), mat)
     modes = [be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_ATOMIC, be.ASM_AUTO]
+    if etype == "C3D10":
+        modes.append(be.ASM_ROWS4)
     for mode in modes:
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(-1)                                    # undeformed configuration
