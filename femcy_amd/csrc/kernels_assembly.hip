@@ -998,12 +998,15 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     const int64_t off = ((int64_t)__builtin_amdgcn_readfirstlane((int32_t)(off_v >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)off_v);
 
-    // ---- the wave's rows (slice lanes wave, wave + 4, ...): lane i holds the metadata of its i-th row
+    // ---- the wave's rows: pair b = slice lanes 8 b + 2 wave and + 1 -- ADJACENT rows, so that the two halves of a
+    // store instruction write neighbouring 16-byte pieces of the same line (one request instead of two), and the eight
+    // rows the four waves finish at about the same time fill whole 128-byte lines; lane i holds the metadata of the
+    // wave's i-th row (pair i / 2, half i % 2)
     constexpr int RPW = SLICE / 4;
     int32_t m_L = 0, m_k0 = 0, m_cnt = 0;
     bool m_valid = false;
     if (lane < RPW) {
-        const int32_t a = node_of[(int64_t)s * SLICE + wave + 4 * lane];
+        const int32_t a = node_of[(int64_t)s * SLICE + 8 * (lane >> 1) + 2 * wave + (lane & 1)];
         if (a >= 0) {
             m_valid = true;
             m_L = rowlen[a];
@@ -1011,7 +1014,8 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
             m_cnt = ne_ptr[a + 1] - m_k0;
         }
     }
-    const int nrows = __popcll(__ballot(m_valid));               // valid rows are a prefix
+    // valid rows are a prefix of the slice: of this wave's rows too (its row index grows with i)
+    const int nrows = __popcll(__ballot(m_valid));
     if (nrows == 0) return;
     const int npairs = (nrows + 1) / 2;
 #define R4_CNT(i) __builtin_amdgcn_readlane(m_cnt, (i))
@@ -1033,7 +1037,12 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     // NO cross-lane traffic through the LDS in the loop: a step of the first version made twelve ds_bpermute round
     // trips one after the other (each waits for the one before: ~1 400 cycles per step, 118 of the kernel's 334 us with
     // everything else compiled out, profiles/r03_rows4_probe.txt)
-#define R4_ROWVAL(m_, b_) (grp ? __builtin_amdgcn_readlane((m_), min(2 * (b_) + 1, 63)) : __builtin_amdgcn_readlane((m_), min(2 * (b_), 63)))
+    // (both scalar reads first, then the select: a readlane inside an arm of ?: is compiled as a divergent branch)
+    auto rowval = [&](int32_t m, int b) -> int32_t {             // b <= npairs + 4 <= 12: lane index < 64
+        const int32_t lo = __builtin_amdgcn_readlane(m, 2 * b), hi = __builtin_amdgcn_readlane(m, 2 * b + 1);
+        return grp ? hi : lo;
+    };
+#define R4_ROWVAL(m_, b_) rowval((m_), (b_))
     auto my_nE = [&](int b, int c) -> int32_t {                  // pairs beyond the last: rows with cnt = 0
         const int32_t cnt = R4_ROWVAL(m_cnt, b);
         return max(0, min(EPG, cnt - EPG * c));
@@ -1052,18 +1061,14 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     double2 RA[NIT], RB[NIT];
     double VA = 0.0, VB = 0.0;
     int32_t JA = 0, JB = 0;
-    // the three element codes of MY row in a step: lanes 0..2 / 32..34 of the list register, read as scalars
-#define R4_CODES(code_, k0_, k1_, k2_)                                                                \
-    const int32_t k0_ = grp ? __builtin_amdgcn_readlane((code_), 32) : __builtin_amdgcn_readlane((code_), 0);   \
-    const int32_t k1_ = grp ? __builtin_amdgcn_readlane((code_), 33) : __builtin_amdgcn_readlane((code_), 1);   \
-    const int32_t k2_ = grp ? __builtin_amdgcn_readlane((code_), 34) : __builtin_amdgcn_readlane((code_), 2);
-#define R4_PICK(q_, a0_, a1_, a2_) ((q_) == 0 ? (a0_) : ((q_) == 1 ? (a1_) : (a2_)))
+    // the code of MY element (q) of a step: lane gbase + q of the list register -- ONE ds_bpermute per use (twelve
+    // dependent ones per step were the first version's problem, six scalar reads + selects cost 20 VALU slots)
+#define R4_MYCODE(code_) __shfl((code_), gbase + q, 64)
 #define R4_LOAD_RECORDS(R_, V_, J_, code_, b_, c_)                                                    \
     {                                                                                                 \
         const int32_t nE_ = my_nE((b_), (c_));                                                        \
-        R4_CODES(code_, kk0_, kk1_, kk2_)                                                             \
         const bool ok_ = q < nE_;                                                                     \
-        const int32_t kq_ = ok_ ? R4_PICK(q, kk0_, kk1_, kk2_) : 0;      /* my element's code; 0 = any valid one */ \
+        const int32_t kq_ = ok_ ? R4_MYCODE(code_) : 0;                  /* my element's code; 0 = any valid one */ \
         const int64_t eq_ = kq_ / NPE;                                                                \
         const double2* rb_ = reinterpret_cast<const double2*>(dsdx + eq_ * RD) + t;                   \
         _Pragma("unroll") for (int u = 0; u < NIT; ++u)                                               \
@@ -1116,7 +1121,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     auto pair_end = [&](int b) {                                // the pair is complete: constants, write-out, zeros
         const int32_t i = 2 * b + grp;
         const int32_t L = R4_ROWVAL(m_L, b);                    // rows >= nrows: 0
-        const int r = wave + 4 * i;
+        const int r = 8 * b + 2 * wave + grp;
         double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
         int32_t ln = gl;
         asm volatile("" : "+v"(ln));    // addresses built on the lane are computed HERE, not hoisted into VGPRs for the
@@ -1151,8 +1156,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
         int32_t code2 = CN_;                                    /* list of step p + 2, fetched in step p - 2 */ \
         asm volatile("" : "+v"(code2));                         /* its own register: the refill of CN_ is not copied at the latch */ \
         const int32_t nE = my_nE(b0, c00);                                                            \
-        R4_CODES(code0, kc0, kc1, kc2)                                                                \
-        const int32_t la = R4_PICK(q, kc0, kc1, kc2) % NPE;     /* the row node inside my element of this step */ \
+        const int32_t la = R4_MYCODE(code0) % NPE;              /* the row node inside my element of this step */ \
         wave_lds_sync();                                        /* the previous step is done with rec / vl */ \
         if (q < nE && !ROWS2_PROBE_BIT(64)) {                                                         \
             double2* sb_ = reinterpret_cast<double2*>(rec + q * RD) + t;                              \
@@ -1178,8 +1182,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
         R4_STEP(RB, VB, JB, cnewB)
     }
 #undef R4_STEP
-#undef R4_PICK
-#undef R4_CODES
+#undef R4_MYCODE
 #undef R4_ROWVAL
 #undef R4_LOAD_RECORDS
 #undef R4_CNT
@@ -1473,9 +1476,16 @@ int launch_assemble(Ctx* c) {
     const int bs = 256;
     size_t th = timing_begin(c, T_ASM);
     int mode = c->opt_assembly;
-    if (mode == FEMCY_ASM_AUTO)
+    if (mode == FEMCY_ASM_AUTO) {
         mode = (c->npe > 4) ? ((c->dm == 3 && c->npe == 10 && c->nGP == 4 && c->dN_sums_to_zero) ? FEMCY_ASM_ROWS2 : FEMCY_ASM_ROWS)
                             : (c->dN_sums_to_zero ? FEMCY_ASM_GATHER_SYM_ROWSUM : FEMCY_ASM_GATHER_SYM);
+        // C3D10: two rows per wave (round 3: 386 -> 307 us on the bench mesh) when its accumulators fit the LDS; it computes
+        // the diagonal block like the others, so it does not need element tables whose gradients sum to zero
+        if (c->dm == 3 && c->npe == 10 && c->nGP == 4) {
+            const size_t lds4 = (size_t)4 * 2 * (3 * 120 + 12 + ((c->max_row_blocks * 9 + 1) & ~1) + 2) * sizeof(double);
+            if (lds4 + 512 <= (size_t)c->small_max_lds) mode = FEMCY_ASM_ROWS4;
+        }
+    }
     if (c->opt_tangent == 1) {
         FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
         const bool neo = c->mat_kind == FEMCY_MAT_NEOHOOKE;
@@ -1570,7 +1580,12 @@ int launch_assemble(Ctx* c) {
         FEMCY_REQUIRE(c->dm == 3 && c->npe == 10 && c->nGP == 4, "ROWS4 assembly is instantiated for C3D10 (npe %d, nGP %d)",
                       c->npe, c->nGP);
         const int EPG = 32 / c->npe, RD = c->nGP * c->npe * 3;
-        const int volw = (EPG * c->nGP + 1) & ~1, accw = (c->max_row_blocks * 9 + 1) & ~1;
+#ifdef FEMCY_ROWS4_FAKE_LMAX    /* occupancy experiment only: WRONG results for longer rows */
+        const int R4_LMAX = FEMCY_ROWS4_FAKE_LMAX;
+#else
+        const int R4_LMAX = c->max_row_blocks;
+#endif
+        const int volw = (EPG * c->nGP + 1) & ~1, accw = (R4_LMAX * 9 + 1) & ~1;
         const size_t lds = (size_t)4 * 2 * (EPG * RD + volw + accw + 2) * sizeof(double);
         FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS4 assembly needs %zu B of LDS per workgroup (longest row: %d "
                       "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
@@ -1580,7 +1595,7 @@ int launch_assemble(Ctx* c) {
             FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_>),               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
         hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,    \
-                           c->max_row_blocks, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,         \
+                           R4_LMAX, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,         \
                            c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
                            c->d_Kvals);                                                                                \
     } while (0)

@@ -81,17 +81,18 @@ enum femcy_assembly {
     FEMCY_ASM_GATHER = 0, /* owner-computes: one lane per stored block, deterministic            */
     FEMCY_ASM_ATOMIC = 1, /* element scatter with f64 HW atomics (comparison / race check)        */
     FEMCY_ASM_ROWS = 2,   /* one wavefront per matrix row, LDS reduction, deterministic           */
-    FEMCY_ASM_AUTO = 3,   /* default: ROWS2 for C3D10, ROWS for the other npe > 4, GATHER_SYM(_ROWSUM) otherwise */
+    FEMCY_ASM_AUTO = 3,   /* default: ROWS4 for C3D10 (ROWS2 / ROWS if its LDS does not fit), ROWS for the other npe > 4,
+                             GATHER_SYM(_ROWSUM) otherwise */
     FEMCY_ASM_GATHER_SYM = 4, /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
     FEMCY_ASM_GATHER_SYM_ROWSUM = 5, /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
                                 unity, checked on the element tables); AUTO picks it for npe <= 4 */
     FEMCY_ASM_ROWS2 = 6,  /* ROWS with the element records staged in LDS, one workgroup per 64-row slice, row-sum
-                             diagonal, 30-flop blocks for cubic-pattern C: AUTO picks it for C3D10 (3.x faster than ROWS);
+                             diagonal, geometric-sum blocks for cubic-pattern C: AUTO's choice for C3D10 until round 3;
                              instantiated for C3D10 and C3D4 tables whose gradients sum to zero */
     FEMCY_ASM_ROWS3 = 7,  /* ROWS2 with eight adjacent rows finished together and written as whole 128-byte lines
                              (no read-for-fill of K: round 3) */
     FEMCY_ASM_ROWS4 = 8   /* two rows per wavefront at a time (half a wave each, three incident elements per step, the
-                             diagonal block computed like the others): round 3, C3D10 */
+                             diagonal block computed like the others): round 3, C3D10; AUTO picks it there */
 };
 
 enum femcy_option {

@@ -358,7 +358,7 @@ def quad():
 def test_c3d10_bench_size_against_c_oracle(quad):
     be, ctx, u, cons, co, m = quad["be"], quad["ctx"], quad["u"], quad["cons"], quad["co"], quad["m"]
     ctx.upload(be.VEC_DOF, u)
-    ctx.assemble_K(be.VEC_DOF)                                   # AUTO: the LDS-staged row kernel (ROWS2) for C3D10
+    ctx.assemble_K(be.VEC_DOF)                                   # AUTO: the two-rows-per-wave kernel (ROWS4) for C3D10
     co.get_dsdx_and_vol(u)
     co.assemble()
     assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
