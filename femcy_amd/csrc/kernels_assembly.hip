@@ -1142,10 +1142,20 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
             if (Kb[0] + Kb[1] + Kb[2] + Kb[3] + Kb[4] + Kb[5] + Kb[6] + Kb[7] + Kb[8] == 1.2345) acc[jb * DD] = (double)r;   // probe: no stores
 #else
             double* dst = Krow + (int64_t)jb * (DD * SLICE);
+#ifdef FEMCY_ROWS4_NT_STORES    /* experiment: K written past the L2 (profiles/r03_rows4_probe.txt) */
+            typedef double d2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                d2v v2 = {Kb[2 * pc], Kb[2 * pc + 1]};
+                __builtin_nontemporal_store(v2, reinterpret_cast<d2v*>(dst + pc * (2 * SLICE)) + r);
+            }
+            __builtin_nontemporal_store(Kb[8], dst + 4 * (2 * SLICE) + r);
+#else
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc)
                 reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
             dst[4 * (2 * SLICE) + r] = Kb[8];
+#endif
 #endif
         }
     };
