@@ -991,7 +991,6 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     double* rec = wbase + (size_t)grp * (EPG * RD + VOLW + accw + 2);      // this half's records
     double* vl = rec + EPG * RD;
     double* acc = vl + VOLW;
-    int32_t* codes = reinterpret_cast<int32_t*>(acc + accw);               // [4]
     const int32_t s = blockIdx.x;
     if (s >= nslices) return;
     const int64_t off_v = slice_off[s];
@@ -1119,7 +1118,6 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
         }
     };
     auto pair_end = [&](int b) {                                // the pair is complete: constants, write-out, zeros
-        const int32_t i = 2 * b + grp;
         const int32_t L = R4_ROWVAL(m_L, b);                    // rows >= nrows: 0
         const int r = 8 * b + 2 * wave + grp;
         double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
