@@ -52,6 +52,61 @@ def test_one_element_Ke_equals_exact_integration(gpu_ctx_factory, etype):
         assert np.abs(K - Ke).max() < 1e-13 * np.abs(Ke).max(), mode
 
 
+@pytest.mark.parametrize("etype", ["C3D4", "C3D10"])
+def test_unreferenced_nodes_and_two_elements_sharing_a_face(gpu_ctx_factory, etype):
+    """edge cases of the row-centric assemblies: nodes no element refers to (rows without incident elements: the
+    stored row is its zero diagonal block), a last slice with an odd number of rows, rows with one and with two
+    incident elements -- two elements sharing a face, every assembly variant against the sum of the two exactly
+    integrated element matrices"""
+    from types import SimpleNamespace
+    from femcy_amd import backend as be
+    import sympy_pins as spn
+    Ke, X, C = spn.exact_Ke(etype)
+    npe = X.shape[0]
+    # mirror image of the element through its face opposite to corner 0 (the plane of corners 1, 2, 3): the face's
+    # nodes are shared, the others are new; corner / mid-side numbering of the mirrored element follows the original's
+    p1, p2, p3 = X[1], X[2], X[3]
+    nrm = np.cross(p2 - p1, p3 - p1)
+    nrm /= np.linalg.norm(nrm)
+    mirror = lambda P: P - 2.0 * np.outer((P - p1) @ nrm, nrm)
+    on_face = np.abs((X - p1) @ nrm) < 1e-12
+    Xm = mirror(X)
+    new_ids = {}
+    nodes = [*X]
+    el2 = []
+    for a in range(npe):
+        if on_face[a]:
+            el2.append(a)
+        else:
+            new_ids[a] = len(nodes)
+            nodes.append(Xm[a])
+            el2.append(new_ids[a])
+    # a reflection flips the orientation: swap two corners (and the mid-side nodes that go with them) to keep det J > 0
+    if etype == "C3D4":
+        el2[1], el2[2] = el2[2], el2[1]
+    else:
+        el2[1], el2[2] = el2[2], el2[1]
+        el2[4], el2[6] = el2[6], el2[4]        # mid-sides (0,1) <-> (0,2)
+        el2[8], el2[9] = el2[9], el2[8]        # mid-sides (1,3) <-> (2,3)
+    nodes += [np.array([9.0, 9.0, 9.0]), np.array([8.0, 9.0, 7.0]), np.array([7.0, 7.0, 9.0])]     # never referenced
+    nodes = np.array(nodes)
+    el = np.array([list(range(npe)), el2], dtype=np.int32)
+    topo = orc.Topology(nodes, el, elem_def(etype))
+    Ko = orc.assemble_K(topo, np.zeros(nodes.size), C)
+    assert np.abs(Ko.toarray()[:3 * npe, :3 * npe] - Ke).max() < 2.0 * np.abs(Ke).max()      # sanity: same scale
+    mat = SimpleNamespace(kind=be_kind("lin3d"), C=C, params=np.array([1.0, 0.25]))
+    ctx = _ctx(gpu_ctx_factory, nodes, el, _ele(etype), mat)
+    modes = [be.ASM_GATHER, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_ATOMIC, be.ASM_AUTO]
+    if etype == "C3D10":
+        modes.append(be.ASM_ROWS4)
+    for mode in modes:
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(-1)
+        K = ctx.get_K_bsr().toarray()
+        assert np.abs(K - Ko.toarray()).max() < 1e-12 * np.abs(Ke).max(), mode
+        assert np.abs(K[-9:, :]).max() == 0.0 and np.abs(K[:, -9:]).max() == 0.0, mode
+
+
 def be_kind(name):
     return {"lin3d": 0, "pstrain": 1, "pstress": 2, "neohooke": 3}[name]
 
