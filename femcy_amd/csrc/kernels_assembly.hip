@@ -58,6 +58,25 @@ __device__ __forceinline__ void block_store(double* __restrict__ dst, const doub
     __syncthreads();
 }
 
+// the same for records that are not contiguous from one element to the next (several Gauss points per element) or wider
+// than the staging area: W doubles of thread t go to dst[t * stride .. + W); a wavefront stores runs of W consecutive
+// doubles (C3D10: 15 = 120 B) instead of 64 pieces `stride` doubles apart
+template <int W>
+__device__ __forceinline__ void block_store_strided(double* __restrict__ dst, const double* __restrict__ v, int nvalid,
+                                                    double* lds, int64_t stride) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < W; ++i) lds[i * 257 + t] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int q = k * 256 + t;
+        const int el = q / W, i = q - el * W;
+        if (q < nvalid * W) dst[(int64_t)el * stride + i] = lds[i * 257 + el];
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------ geometry
 // one thread per element, Gauss points looped inside (dN[g] is then wave-uniform -> scalar loads)
 template <int NPE, int DM, bool STRESS>
@@ -72,7 +91,11 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
     // one Gauss point (C3D4, CPS3) for dsdx / F / sigma, always for the per-element nodal forces
     constexpr int WG = NPE * DM, WT = DM * DM;
     constexpr bool STAGE = WG <= 16;
-    __shared__ double stage_lds[STAGE ? 257 * WG : 1];
+    // round 3: wider records (C3D10: 30 doubles per Gauss point, four Gauss points) go through the same staging area in
+    // chunks of 15 with an element stride -- 49 -> ~30 us of the C3D10 element pass were its 960-byte-strided stores
+    constexpr bool WIDE = !STAGE && WG % 15 == 0;
+    constexpr int CHK = 15;
+    __shared__ double stage_lds[STAGE ? 257 * WG : (WIDE ? 257 * CHK : 1)];
     const int32_t e0 = blockIdx.x * blockDim.x;
     const int nvalid = min(256, ne - e0);
     const bool valid = (int)threadIdx.x < nvalid;
@@ -125,6 +148,11 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                 }
             if (staged) {
                 if constexpr (STAGE) block_store<WG>(dsdx + (int64_t)e0 * WG, G, nvalid, stage_lds);
+            } else if constexpr (WIDE) {
+#pragma unroll
+                for (int c = 0; c < WG / CHK; ++c)
+                    block_store_strided<CHK>(dsdx + ((int64_t)e0 * nGP + g) * WG + c * CHK, G + c * CHK, nvalid, stage_lds,
+                                             (int64_t)nGP * WG);
             } else if (valid) {
                 double* out = dsdx + ((int64_t)e * nGP + g) * WG;
 #pragma unroll
@@ -174,6 +202,8 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                     for (int j = 0; j < DM; ++j) Fl[i * DM + j] = F[i][j];
                 if (staged) {
                     if constexpr (STAGE) block_store<WT>(Fout + (int64_t)e0 * WT, Fl, nvalid, stage_lds);
+                } else if constexpr (WIDE) {
+                    block_store_strided<WT>(Fout + ((int64_t)e0 * nGP + g) * WT, Fl, nvalid, stage_lds, (int64_t)nGP * WT);
                 } else if (valid) {
                     double* fo = Fout + ((int64_t)e * nGP + g) * WT;
 #pragma unroll
@@ -190,6 +220,8 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
                         for (int j = 0; j < DM; ++j) Sl[i * DM + j] = sig[i][j];
                     if (staged) {
                         if constexpr (STAGE) block_store<WT>(Sout + (int64_t)e0 * WT, Sl, nvalid, stage_lds);
+                    } else if constexpr (WIDE) {
+                        block_store_strided<WT>(Sout + ((int64_t)e0 * nGP + g) * WT, Sl, nvalid, stage_lds, (int64_t)nGP * WT);
                     } else if (valid) {
                         double* so = Sout + ((int64_t)e * nGP + g) * WT;
 #pragma unroll
@@ -228,6 +260,10 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
             for (int i = 0; i < DM; ++i) Fe[a * DM + i] = facc[STRESS ? a : 0][i];
         if constexpr (STAGE) {
             block_store<WG>(fe + (int64_t)e0 * WG, Fe, nvalid, stage_lds);
+        } else if constexpr (WIDE) {
+#pragma unroll
+            for (int c = 0; c < WG / CHK; ++c)
+                block_store_strided<CHK>(fe + (int64_t)e0 * WG + c * CHK, Fe + c * CHK, nvalid, stage_lds, (int64_t)WG);
         } else if (valid) {
             double* out = fe + (int64_t)e * WG;
 #pragma unroll
