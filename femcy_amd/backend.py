@@ -42,6 +42,8 @@ GP_DSDX, GP_VOL, GP_F, GP_SIGMA, GP_STRAIN, GP_MISES, GP_ENERGY = range(7)
 OPT_ASSEMBLY, OPT_PCG_POLL, OPT_TIMING, OPT_SPMV_VARIANT, OPT_EW_GRID, OPT_PCG_GRAPH, OPT_SELL_SIGMA = range(7)
 OPT_TANGENT = 7          # 0 = the reference's matrix (default), 1 = consistent tangent (extension)
 OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neighbour send/recv
+OPT_PCG_STORAGE_ORDER = 13   # 1 (default) = the single-rank three-launch PCG keeps its vectors in storage order
+OPT_NODE_ORDER = 14      # 0 = caller's numbering, 1 = measured choice among coordinate orders, 2 + k = forced (before build_pattern)
 OPT_PCG_PERSIST = 11     # 1 (default) = persistent one-launch PCG (single rank, <= ~7e5 DOF, matrix <= Infinity Cache); 2 = any matrix size
 OPT_PCG_PERSIST_MULTI = 12   # 1 (default) = the persistent kernel across ranks once the mailboxes are exchanged and agreed
 OPT_PCG_SMALL = 10       # 1 (default) = one persistent launch per solve for systems that fit LDS
@@ -65,6 +67,7 @@ EXPORTS = [
     "femcy_comm_tune", "femcy_iface_sum",
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
     "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
+    "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order",
 ]
 
 
@@ -156,6 +159,8 @@ def _bind(lib, kind):
         "femcy_probe_exchange": [p, i32, i32, C.POINTER(f64)],
         "femcy_persist_streamed_bytes": [p, C.POINTER(i64)],
         "femcy_comm_mailbox_export": [p, p], "femcy_comm_mailbox_import": [p, i32, p],
+        "femcy_comm_shm_id": [p, i64], "femcy_comm_allgather_host": [p, p, i32, p],
+        "femcy_get_node_order": [p, C.POINTER(i32), p],
         "femcy_comm_persist_agree": [p, C.POINTER(i32)],
     }
     for name, args in sig.items():
@@ -284,6 +289,13 @@ class Context:
     def build_pattern(self) -> PatternInfo:
         self._call("femcy_build_pattern")
         return self.pattern_info()
+
+    def node_order(self):
+        """(order taken by build_pattern: 0 = the caller's numbering, 1 + k = coordinate order k; mean cache lines per
+        wavefront gather of every evaluated candidate, the caller's numbering first)"""
+        used, lines = C.c_int32(), (C.c_double * 7)()
+        self._call("femcy_get_node_order", C.byref(used), C.cast(lines, C.c_void_p))
+        return int(used.value), [float(v) for v in lines]
 
     def pattern_info(self) -> PatternInfo:
         info = PatternInfo()
@@ -477,6 +489,34 @@ class Context:
         if rc != 0:
             raise FemcyError(f"femcy_comm_local_id -> {rc}: {lib.femcy_last_error().decode()}")
         return buf.raw
+
+    @staticmethod
+    def comm_shm_id(max_values: int = 1 << 20) -> bytes:
+        """id of a shared-memory group: the ranks are processes of one host (any devices, also all on one GPU);
+        max_values = the longest vector of one collective, in doubles."""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.femcy_comm_shm_id(buf, int(max_values))
+        if rc != 0:
+            raise FemcyError(f"femcy_comm_shm_id -> {rc}: {lib.femcy_last_error().decode()}")
+        return buf.raw
+
+    def comm_allgather_host(self, payload: bytes) -> list:
+        """collective: every rank's `payload` (same length on all ranks) in rank order, through the context's own
+        transport"""
+        n = len(payload)
+        nranks = C.c_int32()
+        self._call("femcy_comm_info", None, C.byref(nranks), None)
+        send = C.create_string_buffer(payload, n)
+        recv = C.create_string_buffer(n * nranks.value)
+        self._call("femcy_comm_allgather_host", send, n, recv)
+        return [recv.raw[i * n:(i + 1) * n] for i in range(nranks.value)]
+
+    def comm_mailbox_connect(self) -> bool:
+        """export -> all-gather over the context's transport -> import -> agree: True when every rank keeps the
+        one-launch PCG"""
+        self.comm_mailbox_import(self.comm_allgather_host(self.comm_mailbox_export()))
+        return self.comm_persist_agree()
 
     def comm_init(self, rank: int, nranks: int, uid: bytes, iface_local_dofs, iface_global_slot, niface_global: int,
                   owner):

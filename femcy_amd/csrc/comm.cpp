@@ -11,6 +11,12 @@
 // devices) through host staging buffers and a condition-variable rendezvous.  It exists so that the whole
 // multi-rank device path (sub-assembled K, interface pack / unpack, owner masks, the two collectives per
 // iteration) can be run and checked on a single GPU; ranks sum in rank order, so every rank gets the same bits.
+//
+// A third transport, the shared-memory group (round 4), does the same between PROCESSES of one host through a POSIX
+// shared-memory segment (staging areas + a generation barrier on lock-free atomics).  It needs no RCCL, so N processes
+// can share ONE GPU -- which RCCL refuses -- and that is what lets the cross-process branches of the mailbox path
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle of a fine-grained allocation, kernels of different processes polling each
+// other's words) run on a one-GPU box before they meet a real multi-GPU node.
 #include <dlfcn.h>
 #include <unistd.h>
 #include <chrono>
@@ -20,6 +26,7 @@
 #include <memory>
 #include <mutex>
 #include "ctx.hpp"
+#include "shm_group.hpp"
 
 namespace femcy {
 
@@ -160,6 +167,7 @@ static int local_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
         ++g->joined;
     }
     c->comm = g.get();
+    c->comm_kind = COMM_LOCAL;
     c->comm_local = true;
     c->comm_token = token;
     c->rank = rank;
@@ -193,6 +201,44 @@ static int local_exchange(Ctx* c, const double* d_send, int64_t count, double* d
     return FEMCY_OK;
 }
 
+// ------------------------------------------------------------------------------ shared-memory group (processes)
+// shm_group.hpp: rendezvous, staging areas, sums in rank order; here only the device copies around it
+int comm_shm_id(void* id128, int64_t cap_doubles) {
+    shm_make_id(id128, cap_doubles);
+    return FEMCY_OK;
+}
+
+static int shm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
+    FEMCY_REQUIRE(nranks <= SHM_MAXR, "the shared-memory group supports up to %d ranks", SHM_MAXR);
+    auto g = std::make_unique<ShmGroup>();
+    if (!g->open(rank, nranks, id128)) {
+        set_error("%s", g->err.c_str());
+        return FEMCY_ECOMM;
+    }
+    c->comm = g.release();
+    c->comm_kind = COMM_SHM;
+    c->comm_local = false;
+    c->rank = rank;
+    c->nranks = nranks;
+    return FEMCY_OK;
+}
+
+static int shm_exchange(Ctx* c, const double* d_send, int64_t count, double* d_recv, bool gather) {
+    ShmGroup* g = (ShmGroup*)c->comm;
+    FEMCY_REQUIRE((uint64_t)count <= g->h->cap, "shared-memory group: %lld values exceed the staging area of %llu (femcy_comm_shm_id)",
+                  (long long)count, (unsigned long long)g->h->cap);
+    FEMCY_HIP(hipMemcpyAsync(g->area(c->rank), d_send, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> out((size_t)(gather ? count * c->nranks : count));
+    if (!g->exchange(c->rank, g->area(c->rank), count, out.data(), gather)) {
+        set_error("%s", g->err.c_str());
+        return FEMCY_ECOMM;
+    }
+    FEMCY_HIP(hipMemcpyAsync(d_recv, out.data(), sizeof(double) * out.size(), hipMemcpyHostToDevice, c->stream));
+    FEMCY_HIP(hipStreamSynchronize(c->stream));
+    return FEMCY_OK;
+}
+
 int comm_unique_id(void* id128) {
     int rc = load_rccl();
     if (rc) return rc;
@@ -204,12 +250,14 @@ int comm_unique_id(void* id128) {
 
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
     if (std::memcmp(id128, LOCAL_MAGIC, 8) == 0) return local_init(c, rank, nranks, id128);
+    if (std::memcmp(id128, SHM_MAGIC, 8) == 0) return shm_init(c, rank, nranks, id128);
     int rc = load_rccl();
     if (rc) return rc;
     nccl_uid id;
     std::memcpy(&id, id128, sizeof(id));
     FEMCY_HIP(hipSetDevice(c->device));
     FEMCY_NCCL(R.init_rank(&c->comm, nranks, id, rank));
+    c->comm_kind = COMM_RCCL;
     c->rank = rank;
     c->nranks = nranks;
     return FEMCY_OK;
@@ -218,6 +266,7 @@ int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128) {
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count) {
     if (!c->comm || count <= 0) return FEMCY_OK;
     if (c->comm_local) return local_exchange(c, d_buf, count, d_buf, false);
+    if (c->comm_kind == COMM_SHM) return shm_exchange(c, d_buf, count, d_buf, false);
     FEMCY_NCCL(R.allreduce(d_buf, d_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
     return FEMCY_OK;
 }
@@ -228,11 +277,22 @@ int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count) 
         return FEMCY_OK;
     }
     if (c->comm_local) return local_exchange(c, d_send, count, d_recv, true);
+    if (c->comm_kind == COMM_SHM) return shm_exchange(c, d_send, count, d_recv, true);
     FEMCY_NCCL(R.allgather(d_send, d_recv, (size_t)count, /*ncclFloat64*/ 8, c->comm, c->stream));
     return FEMCY_OK;
 }
 
 int comm_register_neighbours(Ctx* c) {
+    if (c->comm && c->comm_kind == COMM_SHM) {
+        ShmGroup* g = (ShmGroup*)c->comm;
+        const int nnb = (int)c->h_nb_rank.size();
+        FEMCY_REQUIRE(nnb <= SHM_MAXR, "the shared-memory group holds up to %d neighbours per rank", SHM_MAXR);
+        ShmHeader::Rank& me = g->h->rk[c->rank];
+        me.nnb = nnb;
+        for (int k = 0; k < nnb; ++k) me.nb_rank[k] = c->h_nb_rank[k];
+        for (int k = 0; k <= nnb; ++k) me.nb_ptr[k] = c->h_nb_ptr[k];
+        return FEMCY_OK;                                 // read by the peers after the first barrier of an exchange
+    }
     if (!c->comm || !c->comm_local) return FEMCY_OK;
     LocalGroup* g = (LocalGroup*)c->comm;
     std::lock_guard<std::mutex> lk(g->m);
@@ -274,6 +334,39 @@ int comm_neighbour_exchange(Ctx* c, hipStream_t stream) {
         FEMCY_HIP(hipStreamSynchronize(stream));
         return FEMCY_OK;
     }
+    if (c->comm_kind == COMM_SHM) {
+        ShmGroup* g = (ShmGroup*)c->comm;
+        ShmHeader* h = g->h;
+        const int64_t total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
+        FEMCY_REQUIRE((uint64_t)total <= h->cap, "shared-memory group: %lld interface values exceed the staging area", (long long)total);
+        if (total) FEMCY_HIP(hipMemcpyAsync(g->area(c->rank), c->d_nb_send, sizeof(double) * total, hipMemcpyDeviceToHost, stream));
+        FEMCY_HIP(hipStreamSynchronize(stream));
+        if (!g->barrier()) {
+            set_error("%s", g->err.c_str());
+            return FEMCY_ECOMM;
+        }
+        std::vector<double> in((size_t)total);
+        for (int k = 0; k < nnb; ++k) {
+            const int q = c->h_nb_rank[k];
+            const int32_t cnt = c->h_nb_ptr[k + 1] - c->h_nb_ptr[k];
+            const ShmHeader::Rank& rq = h->rk[q];
+            int kq = -1;
+            for (int t = 0; t < rq.nnb; ++t)
+                if (rq.nb_rank[t] == c->rank) kq = t;
+            if (kq < 0 || rq.nb_ptr[kq + 1] - rq.nb_ptr[kq] != cnt) {
+                set_error("shared-memory group: ranks %d and %d disagree on their shared DOFs", c->rank, q);
+                return FEMCY_ECOMM;
+            }
+            std::memcpy(in.data() + c->h_nb_ptr[k], g->area(q) + rq.nb_ptr[kq], sizeof(double) * cnt);
+        }
+        if (!g->barrier()) {
+            set_error("%s", g->err.c_str());
+            return FEMCY_ECOMM;
+        }
+        if (total) FEMCY_HIP(hipMemcpyAsync(c->d_nb_recv, in.data(), sizeof(double) * total, hipMemcpyHostToDevice, stream));
+        FEMCY_HIP(hipStreamSynchronize(stream));
+        return FEMCY_OK;
+    }
     if (!R.send || !R.recv || !R.group_start || !R.group_end) {
         set_error("librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
         return FEMCY_ECOMM;
@@ -285,6 +378,38 @@ int comm_neighbour_exchange(Ctx* c, hipStream_t stream) {
         FEMCY_NCCL(R.recv(c->d_nb_recv + c->h_nb_ptr[k], cnt, /*ncclFloat64*/ 8, c->h_nb_rank[k], c->comm, stream));
     }
     FEMCY_NCCL(R.group_end());
+    return FEMCY_OK;
+}
+
+// `bytes` host bytes per rank -> recv[nranks][bytes] on every rank, through whatever transport the context has: the
+// mailbox blobs travel this way, so a host program needs no second communication library for them
+int comm_allgather_host(Ctx* c, const void* send, int32_t bytes, void* recv) {
+    FEMCY_REQUIRE(send && recv && bytes > 0 && bytes <= (1 << 20), "allgather_host: 1 .. 2^20 bytes per rank");
+    if (!c->comm) {
+        std::memcpy(recv, send, (size_t)bytes);
+        return FEMCY_OK;
+    }
+    const int R_ = c->nranks;
+    const int64_t nd = (bytes + 7) / 8;                  // carried as doubles (bit patterns are only copied)
+    double *d_s = nullptr, *d_r = nullptr;
+    FEMCY_HIP(hipMalloc((void**)&d_s, sizeof(double) * nd));
+    if (hipMalloc((void**)&d_r, sizeof(double) * nd * R_) != hipSuccess) {
+        (void)hipFree(d_s);
+        set_error("allgather_host: hipMalloc failed");
+        return FEMCY_ENOMEM;
+    }
+    std::vector<double> hs((size_t)nd, 0.0), hr((size_t)nd * R_);
+    std::memcpy(hs.data(), send, (size_t)bytes);
+    int rc = FEMCY_OK;
+    if (hipMemcpy(d_s, hs.data(), sizeof(double) * nd, hipMemcpyHostToDevice) != hipSuccess) rc = FEMCY_EHIP;
+    if (!rc) rc = comm_allgather(c, d_s, d_r, nd);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = FEMCY_EHIP;
+    if (!rc && hipMemcpy(hr.data(), d_r, sizeof(double) * nd * R_, hipMemcpyDeviceToHost) != hipSuccess) rc = FEMCY_EHIP;
+    (void)hipFree(d_s);
+    (void)hipFree(d_r);
+    if (rc == FEMCY_EHIP) set_error("allgather_host: a HIP copy failed");
+    if (rc) return rc;
+    for (int r = 0; r < R_; ++r) std::memcpy((char*)recv + (size_t)r * bytes, hr.data() + (size_t)r * nd, (size_t)bytes);
     return FEMCY_OK;
 }
 
@@ -304,7 +429,9 @@ struct MboxBlob {
     hipIpcMemHandle_t handle;          // 64 bytes
     int32_t nb_rank[8];
     int32_t nb_ptr[9];
-    char pad[256 - (8 + 8 + 8 + 8 + 16 + 64 + 32 + 36)];
+    int32_t finegrained;
+    uint64_t nonce;                    // of the exporting process: equal pids in different pid namespaces are not one process
+    char pad[256 - (8 + 8 + 8 + 8 + 16 + 64 + 32 + 36 + 4 + 8)];
 };
 static_assert(sizeof(MboxBlob) == 256, "mailbox blob is 256 bytes");
 const char MBOX_MAGIC[8] = {'F', 'E', 'M', 'C', 'Y', 'M', 'B', '1'};
@@ -336,6 +463,8 @@ int comm_mailbox_export(Ctx* c, void* blob256) {
     b.rank = c->rank;
     b.nranks = R;
     b.pid = (int64_t)getpid();
+    b.nonce = process_nonce();
+    b.finegrained = c->mbox_finegrained ? 1 : 0;
     b.devptr = (uint64_t)(uintptr_t)c->d_mbox;
     b.device = c->device;
     b.nb_total = (int32_t)nb_total;
@@ -358,7 +487,11 @@ int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs) {
     for (void* q : c->ipc_opened) (void)hipIpcCloseMemHandle(q);
     c->ipc_opened.clear();
     c->h_peer_mbox.assign((size_t)R, nullptr);
-    bool ok = true;
+    // remote writes into a coarse-grained allocation are not guaranteed to become visible to a running kernel's polls:
+    // without a fine-grained mailbox (here or on a peer) this rank votes for the RCCL loop instead of stalling in the
+    // bounded spin of its first solve
+    bool ok = c->mbox_finegrained;
+    for (int r = 0; r < R; ++r) ok = ok && (R == 1 || B[r].finegrained != 0);
     for (int r = 0; r < R; ++r) {
         FEMCY_REQUIRE(std::memcmp(B[r].magic, MBOX_MAGIC, 8) == 0 && B[r].rank == r && B[r].nranks == R,
                       "blob %d is not the mailbox of rank %d of %d", r, r, R);
@@ -366,7 +499,7 @@ int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs) {
             c->h_peer_mbox[r] = c->d_mbox;
             continue;
         }
-        if (B[r].pid == (int64_t)getpid()) {                      // same process (in-process group, tests): the pointer itself
+        if (B[r].pid == (int64_t)getpid() && B[r].nonce == process_nonce()) {   // same process (in-process group): the pointer itself
             if (B[r].device != c->device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(B[r].device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
@@ -472,10 +605,20 @@ int comm_destroy(Ctx* c) {
         }
         c->comm = nullptr;
         c->comm_local = false;
+        c->comm_kind = COMM_NONE;
+        return FEMCY_OK;
+    }
+    if (c->comm && c->comm_kind == COMM_SHM) {
+        ShmGroup* g = (ShmGroup*)c->comm;
+        g->leave();
+        delete g;
+        c->comm = nullptr;
+        c->comm_kind = COMM_NONE;
         return FEMCY_OK;
     }
     if (c->comm && R.destroy) R.destroy(c->comm);
     c->comm = nullptr;
+    c->comm_kind = COMM_NONE;
     return FEMCY_OK;
 }
 

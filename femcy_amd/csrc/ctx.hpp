@@ -177,8 +177,19 @@ struct Ctx {
     int64_t pattern_serial = 0;       // bumped by femcy_build_pattern
     double* d_persist = nullptr;      // d double buffer, partials, granules, barrier counters
     int64_t persist_cap = 0;
-    int32_t* d_bcolp = nullptr;       // block columns as storage positions (persistent PCG with d in storage order)
+    int32_t* d_bcolp = nullptr;       // block columns as storage positions (PCG with its vectors in storage order)
     int64_t bcolp_serial = -1;
+    int opt_pos_space = 1;            // FEMCY_OPT_PCG_STORAGE_ORDER: the three-kernel PCG of a single rank keeps r, d, M, Ad, x
+                                      // in storage order (gathers of neighbouring lanes then hit neighbouring addresses)
+    double* d_posb = nullptr;         // right-hand side / solution in storage order
+    double* d_posx = nullptr;
+    int64_t pos_cap = 0;
+    int opt_node_order = 0;           // FEMCY_OPT_NODE_ORDER: 0 = rows sorted inside windows of the caller's numbering,
+                                      // 1 = inside windows of the best of a few coordinate orders (measured on the pattern),
+                                      // 2 + k = forced: coordinate order k
+    int node_order_used = 0;          // 0 natural, 1 + k = coordinate order k (femcy_pattern_info)
+    double node_order_cost[8] = {0};  // mean 128-byte lines per wave gather, natural first (diagnostics)
+    std::vector<double> h_nodes;      // host copy of the coordinates (femcy_set_mesh) for the ordering
     char* d_probe = nullptr;          // femcy_probe_stream's buffer
     int64_t probe_cap = 0;
     // ---- one-launch PCG for small systems (k_pcg_small)
@@ -221,7 +232,8 @@ struct Ctx {
     // ---- multi-rank
     int32_t rank = 0, nranks = 1;
     int64_t n_global = 0;             // DOFs of the un-partitioned system (sum of owned DOFs over the ranks)
-    void* comm = nullptr;             // ncclComm_t, or the in-process group when comm_local
+    void* comm = nullptr;             // ncclComm_t, the in-process group (comm_local) or the shared-memory group
+    int comm_kind = 0;                // COMM_*
     bool comm_local = false;
     uint64_t comm_token = 0;
     int32_t niface_local = 0, niface_global = 0;
@@ -244,7 +256,8 @@ struct Ctx {
     std::vector<int32_t> h_nb_dofs;                 // host copy of the neighbour DOF lists
     bool persist_multi_local = false;               // this rank could take the path
     bool persist_multi = false;                     // ... and every rank agreed (femcy_comm_persist_agree)
-    bool persist_multi_failed = false;              // a solve timed out: the RCCL loop from now on
+    bool persist_multi_failed = false;              // a solve timed out: the RCCL loop for the next solves
+    int persist_multi_fallbacks = 0;                // ... counted here; the one-launch path is retried after PERSIST_MULTI_RETRY
     int opt_persist_multi = 1;                      // FEMCY_OPT_PCG_PERSIST_MULTI
     uint32_t solve_serial = 0;
 
@@ -268,6 +281,7 @@ struct Ctx {
     int32_t* d_if_src = nullptr;      //   contributions in ascending rank order; src = recv index, -1 = own value
 };
 
+enum { COMM_NONE = 0, COMM_RCCL = 1, COMM_LOCAL = 2, COMM_SHM = 3 };
 // timing classes
 enum { T_GEOM = 0, T_ASM = 1, T_FORCE = 2, T_SPMV = 3, T_PCG = 4, T_PERSIST = 5 };
 size_t timing_begin(Ctx* c, int cls);
@@ -291,7 +305,9 @@ int launch_energy_sum(Ctx* c, double* total);
 int launch_assemble(Ctx* c);
 int launch_nodal_force(Ctx* c, double* d_f);
 int launch_neumann(Ctx* c, const Ctx::LoadSet& ls, double traction, bool along_normal, double* d_rhs);
-int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out);
+// pos_space: x and y are in STORAGE order (entry p * dm + c belongs to the node at storage position p = slice * 64 + lane;
+// the padding lanes of the last slice hold zeros) -- the form the three-kernel PCG runs in since round 4
+int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out, bool pos_space = false);
 // part 1 / 2 of the split product: the slices holding interface nodes / all others (partials go to
 // d_partials[part_off ...]); split_prepare builds the slice list once per pattern + communicator
 int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d_partials, int part_off, int* nblocks_out);
@@ -300,6 +316,7 @@ bool coresident(Ctx* c, const void* fn, int block, size_t lds, int grid);
 int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass, int64_t* bytes_per_pass);
 int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange);
 int64_t persist_streamed_bytes(Ctx* c);
+int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
@@ -316,6 +333,8 @@ int ensure_scratch(Ctx* c, int64_t k);
 // comm.cpp
 int comm_unique_id(void* id128);
 int comm_local_id(void* id128);
+int comm_shm_id(void* id128, int64_t cap_doubles);
+int comm_allgather_host(Ctx* c, const void* send, int32_t bytes, void* recv);
 int comm_init(Ctx* c, int32_t rank, int32_t nranks, const void* id128);
 int comm_allreduce_sum(Ctx* c, double* d_buf, int64_t count);
 int comm_allgather(Ctx* c, const double* d_send, double* d_recv, int64_t count);

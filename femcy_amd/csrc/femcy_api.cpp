@@ -258,6 +258,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_persist);
     dev_free(&c->d_persist_assign);
     dev_free(&c->d_bcolp);
+    dev_free(&c->d_posb); dev_free(&c->d_posx);
     dev_free(&c->d_probe);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
@@ -365,7 +366,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->opt_persist_l2rows = (int)value;
             break;
         case FEMCY_TUNE_PERSIST_VARIANT:
-            FEMCY_REQUIRE(value >= -1 && value <= 7, "variant bits: -1 (default) or 0..7");
+            FEMCY_REQUIRE(value >= -1 && value <= 15 && (value < 8 || value == 14), "variant bits: -1 (default), 0..7 or 14");
             c->opt_persist_variant = (int)value;
             break;
         case FEMCY_TUNE_PERSIST_PROBE:   /* timing experiments: bit 0 no streamed rows, 1 no LDS rows, 2 no register rows, 3 no barrier wait */
@@ -419,6 +420,16 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(!c->have_pattern, "set the sorting window before femcy_build_pattern");
             c->sell_sigma = (int32_t)value;
             break;
+        case FEMCY_OPT_PCG_STORAGE_ORDER:
+            FEMCY_REQUIRE(value == 0 || value == 1, "storage-order PCG: 0 (node order) or 1");
+            pcg_graph_reset(c);
+            c->opt_pos_space = (int)value;
+            break;
+        case FEMCY_OPT_NODE_ORDER:
+            FEMCY_REQUIRE(value >= 0 && value <= 7, "node order: 0 (caller's numbering), 1 (measured choice), 2..7 (coordinate order k - 2)");
+            FEMCY_REQUIRE(!c->have_pattern, "set the node order before femcy_build_pattern");
+            c->opt_node_order = (int)value;
+            break;
         case FEMCY_OPT_PCG_GRAPH:
             FEMCY_REQUIRE(value >= 0 && value <= 2, "graph mode must be 0 (off), 1 (auto) or 2 (always)");
             c->opt_graph = (int)value;
@@ -471,6 +482,7 @@ int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, 
     c->nn = nn; c->dm = dm; c->ne = ne; c->npe = npe;
     c->n = (int64_t)nn * dm;
     c->h_elems.assign(elems, elems + (int64_t)ne * npe);
+    c->h_nodes.assign(nodes, nodes + (int64_t)nn * dm);
     int rc;
     if ((rc = dev_alloc(&c->d_nodes, (size_t)nn * dm, false))) return rc;
     if ((rc = dev_alloc(&c->d_elems, (size_t)ne * npe, false))) return rc;
@@ -480,8 +492,10 @@ int femcy_set_mesh(femcy_ctx* ctx, int32_t nn, int32_t dm, const double* nodes, 
     const size_t nalloc = (size_t)((c->n + 63) / 64 * 64 + 64);
     for (auto& v : c->d_vec)
         if ((rc = dev_alloc(&v, nalloc))) return rc;
-    if ((rc = dev_alloc(&c->d_r, nalloc)) || (rc = dev_alloc(&c->d_d, nalloc)) || (rc = dev_alloc(&c->d_M, nalloc)) ||
-        (rc = dev_alloc(&c->d_Ad, nalloc)) || (rc = dev_alloc(&c->d_u_lazy, nalloc)))
+    // the PCG work vectors also hold the storage-order form (whole slices of 64 nodes)
+    const size_t palloc = std::max(nalloc, (size_t)((int64_t)(nn + SLICE - 1) / SLICE * SLICE * dm + 64));
+    if ((rc = dev_alloc(&c->d_r, palloc)) || (rc = dev_alloc(&c->d_d, palloc)) || (rc = dev_alloc(&c->d_M, palloc)) ||
+        (rc = dev_alloc(&c->d_Ad, palloc)) || (rc = dev_alloc(&c->d_u_lazy, nalloc)))
         return rc;
     c->gp_lazy = false;
     pcg_graph_reset(c);
@@ -594,6 +608,15 @@ int femcy_get_pattern_info(femcy_ctx* ctx, femcy_pattern_info* out) {
     out->stored_blocks = c->stored_rows * SLICE;
     out->nslices = c->nslices;
     out->max_node_elems = c->max_node_elems;
+    return FEMCY_OK;
+}
+
+int femcy_get_node_order(femcy_ctx* ctx, int32_t* used, double* lines) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "pattern not built");
+    if (used) *used = c->node_order_used;
+    if (lines)
+        for (int k = 0; k < 7; ++k) lines[k] = c->node_order_cost[k];
     return FEMCY_OK;
 }
 
@@ -1147,6 +1170,19 @@ int femcy_comm_local_id(void* id128) {
         return FEMCY_EINVAL;
     }
     return comm_local_id(id128);
+}
+
+int femcy_comm_shm_id(void* id128, int64_t max_values) {
+    if (!id128 || max_values < 0) {
+        set_error("null id buffer / negative capacity");
+        return FEMCY_EINVAL;
+    }
+    return comm_shm_id(id128, max_values);
+}
+
+int femcy_comm_allgather_host(femcy_ctx* ctx, const void* send, int32_t bytes, void* recv) {
+    CTX_OR_FAIL(ctx);
+    return comm_allgather_host(c, send, bytes, recv);
 }
 
 int femcy_comm_init(femcy_ctx* ctx, int32_t rank, int32_t nranks, const void* id128, int32_t niface_local,

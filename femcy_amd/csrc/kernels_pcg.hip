@@ -95,6 +95,9 @@ __device__ __forceinline__ void gather_x(const __amdgpu_buffer_rsrc_t rs, int32_
 // the few thousand slices still fill 1024 SIMDs evenly.
 // slice_list != nullptr: the XCD ranges count positions of that list instead of slices (multi-rank split product:
 // interface slices and interior slices are two launches over the two halves of one list)
+// node_of == nullptr: x and y are in storage order and bcol holds storage positions (nn = nslices * 64): lanes of a wave
+// are rows of one length class in ascending order, their j-th neighbours then sit at (nearly) consecutive positions and
+// a wave's gather touches ~14 cache lines instead of 27-45 on the C3D10 plate (tools/gather_lines.py)
 template <int DM, int WPS, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
@@ -102,7 +105,8 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
                                              const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done,
-                                             const int32_t* __restrict__ slice_list, int32_t keep_permille) {
+                                             const int32_t* __restrict__ slice_list, int32_t keep_permille,
+                                             int32_t nreal) {
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
@@ -185,12 +189,15 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
             }
         }
         if (active && part == 0) {
-            const int64_t a = node_of[(int64_t)s * SLICE + lane];   // row permutation (SELL-C-sigma); -1 = padding lane
+            // node order: row permutation (SELL-C-sigma), -1 = padding lane.  Storage order (node_of == nullptr): the
+            // lane's own position; padding lanes multiply zero blocks and write the zeros they are meant to hold
+            const int64_t a = node_of ? (int64_t)node_of[(int64_t)s * SLICE + lane] : (int64_t)s * SLICE + lane;
             if (a >= 0) {
+                const bool real = a < nreal;         // storage order: positions >= the node count are padding lanes -> 0
 #pragma unroll
                 for (int r = 0; r < DM; ++r) {
-                    y[a * DM + r] = acc[r];
-                    dot += x[a * DM + r] * acc[r];
+                    y[a * DM + r] = real ? acc[r] : 0.0;
+                    if (real) dot += x[a * DM + r] * acc[r];
                 }
             }
         }
@@ -216,6 +223,39 @@ __global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int32_t* __rest
         const double dg = vals[kv_index<DM>(row, r * DM + r, lane)];
         M[a * DM + r] = invert ? 1.0 / dg : dg;
     }
+}
+// the same in storage order: entry p belongs to position p (coalesced); padding lanes get M = 0, so r = d = 0 there
+template <int DM>
+__global__ void __launch_bounds__(BS) k_jacobi_pos(int32_t npos, const int32_t* __restrict__ node_of,
+                                                   const int64_t* __restrict__ slice_off,
+                                                   const double* __restrict__ vals, double* __restrict__ M) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const bool real = node_of[p] >= 0;
+    const int64_t row = slice_off[p >> 6];
+    const int lane = (int)(p & 63);
+#pragma unroll
+    for (int r = 0; r < DM; ++r) M[p * DM + r] = real ? 1.0 / vals[kv_index<DM>(row, r * DM + r, lane)] : 0.0;
+}
+// node order <-> storage order of a vector (once per solve each way)
+template <int DM>
+__global__ void __launch_bounds__(BS) k_to_pos(int32_t npos, const int32_t* __restrict__ node_of,
+                                               const double* __restrict__ v, double* __restrict__ vp) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const int64_t a = node_of[p];
+#pragma unroll
+    for (int r = 0; r < DM; ++r) vp[p * DM + r] = a >= 0 ? v[a * DM + r] : 0.0;
+}
+template <int DM>
+__global__ void __launch_bounds__(BS) k_from_pos(int32_t npos, const int32_t* __restrict__ node_of,
+                                                 const double* __restrict__ vp, double* __restrict__ v) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const int64_t a = node_of[p];
+    if (a < 0) return;
+#pragma unroll
+    for (int r = 0; r < DM; ++r) v[a * DM + r] = vp[p * DM + r];
 }
 __global__ void __launch_bounds__(BS) k_recip(int64_t n, double* __restrict__ v) {
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BS) v[i] = 1.0 / v[i];
@@ -677,7 +717,8 @@ int vec_absmax(Ctx* c, const double* d, double* out) { return vec_reduce(c, d, 1
 __global__ void k_fence_noop() {}
 
 static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out,
-                            const XcdRanges& xr, int grid, const int32_t* slice_list, int part_off = 0) {
+                            const XcdRanges& xr, int grid, const int32_t* slice_list, int part_off = 0,
+                            bool pos_space = false) {
     // the partials of a launch go to d_partials[part_off .. part_off + grid): the two halves of a split product share
     // one array of MAX_PARTIALS entries
     if (part_off + grid > MAX_PARTIALS) {
@@ -697,9 +738,9 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
     // picked up, i.e. possibly while the previous PCG kernel is still draining; the empty kernel absorbs that wait
     if (ev && c->opt_timing_fence) hipLaunchKernelGGL(k_fence_noop, dim3(1), dim3(64), 0, c->stream);
 #define SPMV_ARGS                                                                                              \
-    c->nn, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const int32_t*)c->d_bcol,      \
-        (const int32_t*)c->d_node_of, (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list,              \
-        (int32_t)c->spmv_keep_permille
+    (pos_space ? c->nslices * SLICE : c->nn), xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,  \
+        (const int32_t*)(pos_space ? c->d_bcolp : c->d_bcol), (const int32_t*)(pos_space ? nullptr : c->d_node_of),  \
+        (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list, (int32_t)c->spmv_keep_permille, c->nn
 #define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \
@@ -730,8 +771,8 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
     return FEMCY_OK;
 }
 
-int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out) {
-    return launch_spmv_impl(c, d_x, d_y, d_partials, nblocks_out, c->xcd, c->spmv_grid, nullptr);
+int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int* nblocks_out, bool pos_space) {
+    return launch_spmv_impl(c, d_x, d_y, d_partials, nblocks_out, c->xcd, c->spmv_grid, nullptr, 0, pos_space);
 }
 
 // the slices that hold at least one interface node, then all others (ascending inside each half, so the interior
@@ -1144,18 +1185,6 @@ void pcg_graph_reset(Ctx* c) {
 // ----------------------------------------------------------------------------------------- PCG
 int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, int32_t* iters, double* r0,
               double* rmax) {
-    const int64_t n2 = (c->n + 1) / 2;
-    // element ranges of the vector kernels = the node ranges whose matrix rows each XCD multiplies (c->xcd, in slices
-    // of 64 nodes; the rows of a slice are its sigma-window's nodes, so the match is exact up to one window per
-    // boundary), in double2 units; grid = 8 x workgroups per XCD
-    XcdRanges er;
-    for (int k = 0; k <= NXCD; ++k)
-        er.start[k] = (int32_t)std::min<int64_t>(n2, ((int64_t)c->xcd.start[k] * SLICE * c->dm + 1) / 2);
-    er.start[0] = 0;
-    er.start[NXCD] = (int32_t)n2;
-    int64_t emax = 1;
-    for (int k = 0; k < NXCD; ++k) emax = std::max<int64_t>(emax, er.start[k + 1] - er.start[k]);
-    const int g = NXCD * (int)std::max<int64_t>(1, std::min<int64_t>((emax + BS - 1) / BS, std::max(1, c->ew_cap / NXCD)));
     const bool multi = c->comm != nullptr;   // a 1-rank communicator still runs the exchange path (testable on one GPU)
     size_t th = timing_begin(c, T_PCG);
 
@@ -1213,8 +1242,55 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
             return FEMCY_OK;
         }
     }
-    hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)d_b, (const double2*)c->d_M,
-                       (double2*)d_x, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),
+    // ---- three launches per iteration.  Single rank: the loop runs in STORAGE order (opt_pos_space) -- b is permuted
+    // once, M is taken straight from the diagonal blocks in storage order, x is permuted back at the end; every kernel
+    // in between is element-wise or the product, whose gathers then follow bcolp.  Multi-rank keeps node order (its
+    // interface lists and owner mask are DOF-indexed).
+    const bool pos = !multi && c->opt_pos_space != 0;
+    const int32_t npos = c->nslices * SLICE;
+    const double* vb = d_b;
+    double* vx = d_x;
+    if (pos) {
+        int rc = ensure_bcolp(c);
+        if (rc) return rc;
+        const int64_t need = (int64_t)npos * c->dm + 64;
+        if (c->pos_cap < need) {
+            if (c->d_posb) (void)hipFree(c->d_posb);
+            if (c->d_posx) (void)hipFree(c->d_posx);
+            c->d_posb = c->d_posx = nullptr;
+            c->pos_cap = 0;
+            FEMCY_HIP(hipMalloc((void**)&c->d_posb, sizeof(double) * need));
+            FEMCY_HIP(hipMalloc((void**)&c->d_posx, sizeof(double) * need));
+            FEMCY_HIP(hipMemsetAsync(c->d_posb, 0, sizeof(double) * need, c->stream));
+            FEMCY_HIP(hipMemsetAsync(c->d_posx, 0, sizeof(double) * need, c->stream));
+            c->pos_cap = need;
+            pcg_graph_reset(c);
+        }
+        const int pg = (npos + BS - 1) / BS;
+        if (c->dm == 3) {
+            hipLaunchKernelGGL((k_jacobi_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, c->d_slice_off, c->d_Kvals, c->d_M);
+            hipLaunchKernelGGL((k_to_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_b, c->d_posb);
+        } else {
+            hipLaunchKernelGGL((k_jacobi_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, c->d_slice_off, c->d_Kvals, c->d_M);
+            hipLaunchKernelGGL((k_to_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_b, c->d_posb);
+        }
+        vb = c->d_posb;
+        vx = c->d_posx;
+    }
+    const int64_t n2 = pos ? (int64_t)npos * c->dm / 2 : (c->n + 1) / 2;
+    // element ranges of the vector kernels = the ranges whose matrix rows each XCD multiplies (c->xcd, in slices of 64
+    // rows), in double2 units; exact in storage order, up to one sigma-window per boundary in node order; grid = 8 x
+    // workgroups per XCD
+    XcdRanges er;
+    for (int k = 0; k <= NXCD; ++k)
+        er.start[k] = (int32_t)std::min<int64_t>(n2, ((int64_t)c->xcd.start[k] * SLICE * c->dm + 1) / 2);
+    er.start[0] = 0;
+    er.start[NXCD] = (int32_t)n2;
+    int64_t emax = 1;
+    for (int k = 0; k < NXCD; ++k) emax = std::max<int64_t>(emax, er.start[k + 1] - er.start[k]);
+    const int g = NXCD * (int)std::max<int64_t>(1, std::min<int64_t>((emax + BS - 1) / BS, std::max(1, c->ew_cap / NXCD)));
+    hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)vb, (const double2*)c->d_M,
+                       (double2*)vx, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),
                        c->d_part2);
     if (multi) {
         hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, c->d_commbuf);
@@ -1252,7 +1328,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
             if ((rc = comm_allreduce_sum(c, slot, 1))) return rc;
             FEMCY_HIP(hipStreamWaitEvent(c->stream, c->ev_xchg, 0));
             dAd_red = slot;
-        } else if ((rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1))) {
+        } else if ((rc = launch_spmv(c, c->d_d, c->d_Ad, c->d_part1, &np1, pos))) {
             return rc;
         } else if (multi && c->exchange == 1) {
             // neighbour send/recv of the interface entries of Ad, then the scalar d.Ad by an 8-byte all-reduce
@@ -1287,7 +1363,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
 #define FEMCY_UD(NT_)                                                                              \
     hipLaunchKernelGGL(k_update_d<NT_>, dim3(g), dim3(BS), 0, c->stream, er, g, c->d_part2,         \
                        (const double*)(multi ? c->d_gather : nullptr), (int)c->nranks, c->d_state, \
-                       (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d, (double2*)d_x)
+                       (const double2*)c->d_r, (const double2*)c->d_M, (double2*)c->d_d, (double2*)vx)
         if (c->vec_nt) FEMCY_UD(true); else FEMCY_UD(false);
 #undef FEMCY_UD
         return FEMCY_OK;
@@ -1299,7 +1375,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     // iteration SLOWER at 548 535 DOF (GPU-bound), so "auto" (1) only uses it below 2e5 DOF; 2 forces it on
     const bool want_graph = c->opt_graph == 2 || (c->opt_graph == 1 && c->n < 200000);
     const bool use_graph = want_graph && !multi && !c->opt_timing && maxit >= P;
-    if (use_graph && (!c->pcg_graph || c->pcg_graph_x != d_x || c->pcg_graph_iters != P || c->pcg_graph_g != g ||
+    if (use_graph && (!c->pcg_graph || c->pcg_graph_x != vx || c->pcg_graph_iters != P || c->pcg_graph_g != g ||
                       c->pcg_graph_np1 != c->spmv_grid)) {
         pcg_graph_reset(c);
         hipGraph_t graph = nullptr;
@@ -1314,7 +1390,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         FEMCY_HIP(ce);
         FEMCY_HIP(hipGraphInstantiate(&c->pcg_graph, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
-        c->pcg_graph_x = d_x;
+        c->pcg_graph_x = vx;
         c->pcg_graph_iters = P;
         c->pcg_graph_g = g;
         c->pcg_graph_np1 = c->spmv_grid;
@@ -1337,6 +1413,12 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
         FEMCY_HIP(hipStreamSynchronize(c->stream));
         if (c->h_state->done || it >= maxit) finished = true;
+    }
+    if (pos) {
+        const int pg = (npos + BS - 1) / BS;
+        if (c->dm == 3) hipLaunchKernelGGL((k_from_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_x);
+        else hipLaunchKernelGGL((k_from_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_x);
+        FEMCY_HIP(hipGetLastError());
     }
     timing_end(c, th);
     if (iters) *iters = c->h_state->iters;

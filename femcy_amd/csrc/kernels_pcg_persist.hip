@@ -26,6 +26,8 @@
 //      Infinity Cache in this launch shape against 24 TB/s at eight workgroups per CU), nt loads return sooner, and
 //      the default-policy rows are what stays in the XCD's 4 MiB L2 from one product to the next;
 //   2  tagged-granule synchronisation (above);
+//   8  (round 4) in-band validity of the published d: sentinel words + triple buffer instead of the third exchange
+//      (V_INBAND below); needs bit 4
 //   4  d is published in STORAGE order (position = slice * 64 + lane) so that a lane's dm values are contiguous for
 //      the whole wave: one 16-byte + one 8-byte store / gather per node instead of three 8-byte ones (a third fewer
 //      texture-address cycles on the largest non-matrix item of the iteration).
@@ -59,7 +61,17 @@ namespace {
 constexpr int PBS = 256;        // 4 waves per workgroup, one workgroup per CU
 constexpr int PNX = 8;
 constexpr int CH = 4;         // block rows per batch of the LDS-resident and the streamed part
-constexpr int V_NT = 1, V_A2A = 2, V_WIDE = 4;
+constexpr int V_NT = 1, V_A2A = 2, V_WIDE = 4, V_INBAND = 8;
+// V_INBAND: the published d validates itself.  A word of d that has not been written yet holds a sentinel (a NaN with a
+// payload no arithmetic produces), the consumers' gathers ARE the poll, and the third grid-wide exchange of the
+// iteration ("d published") is gone.  d is triple-buffered by iteration: at the end of iteration k a lane publishes
+// d_(k+1) into buffer (k+1) % 3 and re-arms buffer (k+2) % 3 = (k-1) % 3 with the sentinel -- that buffer was last
+// read by product k-1, which every wave had finished before anybody passed the first exchange of iteration k-1, and the
+// re-arm has been acknowledged (in-order VMEM returns: it sits in front of product k+1's first load) before its owner
+// arrives at the first exchange of iteration k+1, behind which the next publish into it lies.  A gather therefore
+// sees either the sentinel or the value it wants, never an older one.  Each 8-byte word is written by one store
+// instruction and lies inside one cache line (8-byte aligned), so it is never seen half-written.
+constexpr unsigned SENT_HI = 0xFFFBADD0u, SENT_LO = 0x5E471E70u;
 
 // Work-skipping switches for timing experiments (tools/persist_breakdown.py) exist only in a probe build
 // (FEMCY_EXTRA_FLAGS=-DFEMCY_PERSIST_PROBE FEMCY_OUT=../libfemcy_hip_probe.so csrc/build.sh): the shipped library
@@ -171,13 +183,19 @@ __device__ __forceinline__ bool grid_barrier(const PersistPcg& a, unsigned round
 //   * d.Ad and (r.M.r, max|r|): local grid-wide exchange first, then workgroup 0 writes the rank's value into every
 //     rank's mailbox and wave 0 of every workgroup polls the nranks entries of its own rank's mailbox and combines
 //     them in rank order.  d.Ad = sum_r d_r.K_r d_r needs no owner mask; r.M.r counts a shared DOF on its owner;
-//   * entries are double-buffered by iteration parity and tagged (solve serial << 20) + iteration, so nothing is ever
-//     re-armed; a rank cannot run more than one exchange ahead of a peer (it needs the peer's value to pass).
+//   * entries are double-buffered by iteration parity and tagged (solve serial << 20) | (iteration mod 2^20), so nothing
+//     is ever re-armed; a rank cannot run more than one exchange ahead of a peer (it needs the peer's value to pass).
 // Every poll is bounded (spin_limit); a time-out ends the launch with done = 3 and the host -- after agreeing with
 // the other ranks through the communicator -- redoes the solve with the RCCL loop.
 constexpr int MB_SA = 0;                                         // [2][R] entries: d.Ad
 __device__ __forceinline__ int mb_sb(int R) { return 4 * R; }    // [2][R][2] entries: (r.M.r, max|r|)
 __device__ __forceinline__ int mb_ad(int R) { return 12 * R; }   // [2][nb_total] entries: interface rows of Ad
+// tag of the exchanges of iteration `it` (-1 = the set-up exchange): solve serial in the upper 12 bits, the iteration
+// count wraps inside the lower 20 -- an entry is rewritten every second iteration (parity double buffer), so a wrapped
+// tag can only meet the entry of two iterations earlier, never an equal one; never 0 (the zeroed mailbox)
+__device__ __forceinline__ uint32_t mb_tag(uint32_t tagbase, int it) {
+    return tagbase | ((uint32_t)(it + 1) & 0xFFFFFu);
+}
 __device__ __forceinline__ void mb_store(unsigned long long* p, double v, uint32_t tag) {
     const unsigned long long t = (unsigned long long)tag << 32;
     __hip_atomic_store(p, t | (uint32_t)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -228,10 +246,33 @@ __device__ __forceinline__ bool xrank_reduce(const PersistPcg& a, int base, int 
     return true;
 }
 
+// V_INBAND: after a batch of gathers, repeat it until no lane holds a sentinel word (the producer has not published
+// yet); wave-uniform loop, bounded; the "memory" clobber keeps the compiler from re-using the first loads
+#define FEMCY_SETTLE(NB_, REGATHER_)                                                     \
+    if (INB) {                                                                           \
+        uint32_t spins_ = 0;                                                             \
+        for (;;) {                                                                       \
+            bool st_ = false;                                                            \
+            _Pragma("unroll") for (int u_ = 0; u_ < (NB_); ++u_) st_ = st_ || stale_d(xg[u_]); \
+            if (!__any(st_)) break;                                                      \
+            if (++spins_ > a.spin_limit) {                                               \
+                pfail = true;                                                            \
+                break;                                                                   \
+            }                                                                            \
+            __builtin_amdgcn_s_sleep(1);                                                 \
+            asm volatile("" ::: "memory");                                               \
+            REGATHER_;                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                           \
+        }                                                                                \
+    }
+
 template <int DM, int SPW, int RJ, int VAR, bool MULTI = false>
 __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
     constexpr bool NT = (VAR & V_NT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
+    constexpr bool INB = (VAR & V_INBAND) != 0;
+    static_assert(!INB || (WIDE && A2A), "in-band validity of d is built on the storage-order, tagged-granule form");
+    constexpr int NDB = INB ? 3 : 2;                             // buffers of the published d
     extern __shared__ __attribute__((aligned(16))) char lds_persist[];
     __shared__ double sm1[PBS / 64], sm2[PBS / 64], bc[2];
     __shared__ int s_fail;
@@ -301,7 +342,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     // with sc1 stores), but an ordinary load to the compiler, which may then issue the gathers of several block rows
     // before the first wait (with atomic loads it serialised them: 15 + 8 dependent L2 round trips per product)
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dbuf, 0, (int)((size_t)2 * a.npad * sizeof(double)), 0x00020000);
+        (void*)a.dbuf, 0, (int)((size_t)NDB * a.npad * sizeof(double)), 0x00020000);
     auto gather_d = [&](int32_t col, int32_t parity_off, double (&xv)[DM]) {
         if (WIDE) {     // dm contiguous doubles at 8-byte alignment: 16 B (+ 8 B for dm = 3); dword alignment suffices
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(drsrc, col * (DM * 8), parity_off, AUX_SC1);
@@ -342,6 +383,22 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 __builtin_amdgcn_raw_buffer_store_b64(w2, drsrc, (p * DM + cc) * 8, parity_off, AUX_SC1);
             }
         }
+    };
+    auto arm_d = [&](int32_t p, int32_t buf_off) {                // INB: the lane's words of a buffer <- sentinel
+        u32x4 w;
+        w.x = SENT_LO; w.y = SENT_HI; w.z = SENT_LO; w.w = SENT_HI;
+        __builtin_amdgcn_raw_buffer_store_b128(w, drsrc, p * (DM * 8), buf_off, AUX_SC1);
+        if (DM == 3) {
+            u32x2 w2;
+            w2.x = SENT_LO; w2.y = SENT_HI;
+            __builtin_amdgcn_raw_buffer_store_b64(w2, drsrc, p * (DM * 8) + 16, buf_off, AUX_SC1);
+        }
+    };
+    auto stale_d = [&](const double (&xv)[DM]) -> bool {
+        bool st = false;
+#pragma unroll
+        for (int cc = 0; cc < DM; ++cc) st = st || ((unsigned)__double2hiint(xv[cc]) == SENT_HI);
+        return st;
     };
     // nb (<= CH) consecutive block rows of a slice: columns and values (rows beyond nb: the column of the last one,
     // so that its gather stays in range; no values)
@@ -387,7 +444,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     // work skipping).  Tagged-granule form: wave 0 sweeps the granules during those windows, and VMEM returns in order
     // -- a prefetch of its own would sit in front of every sweep -- so wave 0 does not prefetch (the host hands it
     // one batch less of streamed rows instead)
-    const int npf = ((a.dbg & 16) || (A2A && wave == 0)) ? 0 : max(0, min(CH, Ls[0] - je[0]));
+#ifndef FEMCY_INB_PREFETCH
+#define FEMCY_INB_PREFETCH 1
+#endif
+    const int npf = ((a.dbg & 16) || (A2A && wave == 0) || (INB && !FEMCY_INB_PREFETCH)) ? 0 : max(0, min(CH, Ls[0] - je[0]));
     int32_t pcol[CH];
     double pe[CH][DD];
     const int32_t jpf = npf > 0 ? je[0] : 0;                               // (npf = 0: row 0's column, unused)
@@ -415,6 +475,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             accm = fmax(accm, pabs(bi));
         }
         if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], 0, dd[t]);
+        if (INB && sl[t] >= 0) {                                  // buffers 1 and 2 start armed (drained with the first exchange)
+            arm_d(dpos[t], a.npad * 8);
+            arm_d(dpos[t], 2 * a.npad * 8);
+        }
     }
     unsigned round = 0;
     // across ranks: the cross-rank stage of an exchange (wave 0 of every workgroup; the local result is in `val`),
@@ -425,7 +489,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         constexpr int NV = decltype(nv_tag)::value;
         __syncthreads();
         if (wave == 0) {
-            const bool okx = xrank_reduce<NV>(a, base, (xr_it + 1) & 1, a.tagbase + (uint32_t)(xr_it + 1), val, op);
+            const bool okx = xrank_reduce<NV>(a, base, (xr_it + 1) & 1, mb_tag(a.tagbase, xr_it), val, op);
             if (lane == 0) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) bc[v] = val[v];
@@ -524,6 +588,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 
     // ---- Ad = K d for the wave's rows (d gathered with sc1 loads: the other XCDs wrote it with sc1 stores); returns
     // the lane's part of d.Ad
+    bool pfail = false;                                           // V_INBAND: a gather never saw its value (time-out)
     auto product = [&](const int32_t poff) -> double {
         double acc[SPW][DM];
 #pragma unroll
@@ -543,6 +608,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
+                FEMCY_SETTLE(CH, _Pragma("unroll") for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]))
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
                     if (u < npf) {
@@ -559,10 +625,21 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                 for (int j0 = 0; j0 < RJ; j0 += RB) {
                     double xg[RB][DM];
-#pragma unroll
-                    for (int u = 0; u < RB; ++u)
-                        if (j0 + u < RJ) gather_d(rcl[t][j0 + u], poff, xg[u]);
+                    // (V_INBAND: block row 0 is the diagonal block -- its column is the lane's own d, which is at hand)
+#define FEMCY_REG_GATHER                                                                       \
+    _Pragma("unroll") for (int u = 0; u < RB; ++u) {                                          \
+        if (INB && j0 + u == 0) {                                                              \
+            _Pragma("unroll") for (int cc = 0; cc < DM; ++cc) xg[u][cc] = dd[t][cc];          \
+        } else if (j0 + u < RJ) {                                                              \
+            gather_d(rcl[t][j0 + u], poff, xg[u]);                                             \
+        } else {                                                                               \
+            _Pragma("unroll") for (int cc = 0; cc < DM; ++cc) xg[u][cc] = 0.0;                \
+        }                                                                                      \
+    }
+                    FEMCY_REG_GATHER
                     __builtin_amdgcn_sched_barrier(0);
+                    FEMCY_SETTLE(RB, FEMCY_REG_GATHER)
+#undef FEMCY_REG_GATHER
 #pragma unroll
                     for (int u = 0; u < RB; ++u)
                         if (j0 + u < RJ) {
@@ -582,6 +659,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(lcols[(q + min(u, nb - 1)) * 64 + lane], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
+                FEMCY_SETTLE(CH, _Pragma("unroll") for (int u = 0; u < CH; ++u) gather_d(lcols[(q + min(u, nb - 1)) * 64 + lane], poff, xg[u]))
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
                     if (u < nb) {
@@ -601,6 +679,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
+                FEMCY_SETTLE(CH, _Pragma("unroll") for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]))
 #pragma unroll
                 for (int u = 0; u < CH; ++u)
                     if (u < nb) {
@@ -625,13 +704,14 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 
     auto iteration = [&]() {
         __syncthreads();                                                     // sm1 / sm2 of the previous phase are read
-        const int32_t poff = (it & 1) * a.npad * 8;                           // byte offset of this iteration's d
+        const int32_t poff = (INB ? it % 3 : (it & 1)) * a.npad * 8;          // byte offset of this iteration's d
         double dot = product(poff);
+        if (INB && pfail && lane == 0) s_fail = 1;                           // seen by everybody behind the next barrier
         xr_it = it;
         if (MULTI) {
             // interface rows: the partial sums of this rank go straight into the sharing rank's mailbox (system-scope
             // 8-byte words that validate themselves); they travel while the exchanges below run
-            const uint32_t tag = a.tagbase + (uint32_t)(it + 1);
+            const uint32_t tag = mb_tag(a.tagbase, it);
 #pragma unroll
             for (int t = 0; t < SPW; ++t)
                 if (sl[t] >= 0) {
@@ -651,6 +731,11 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         if (lane == 0) sm1[wave] = dot;
         __syncthreads();
         double dAd;
+        if (INB && s_fail) {                                                 // a gather timed out in this workgroup:
+            if (wave == 0) poison_granules();                                // release everybody with the same verdict
+            done = 3;
+            return;
+        }
         if (A2A) {
             if (wave == 0) {
                 const double ws = (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]);
@@ -695,7 +780,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             if (!xrank_stage(std::integral_constant<int, 1>{}, MB_SA, val, op)) { done = 3; return; }
             dAd = val[0];
             // the neighbour's partial sums of the interface rows, added in ascending rank order on both sides
-            const uint32_t tag = a.tagbase + (uint32_t)(it + 1);
+            const uint32_t tag = mb_tag(a.tagbase, it);
             bool okr = true;
 #pragma unroll
             for (int t = 0; t < SPW; ++t)
@@ -747,15 +832,17 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         } else {
             // ---- d = M r + beta d, published for the next product
             const double beta = rMr_new / rMr;
-            const int32_t noff = (it & 1) * a.npad * 8;
+            const int32_t noff = (INB ? it % 3 : (it & 1)) * a.npad * 8;
 #pragma unroll
             for (int t = 0; t < SPW; ++t) {
 #pragma unroll
                 for (int c = 0; c < DM; ++c) dd[t][c] = mm[t][c] * rr[t][c] + beta * dd[t][c];
                 if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], noff, dd[t]);
+                // V_INBAND: re-arm the buffer the iteration after next publishes into (last read one iteration ago)
+                if (INB && sl[t] >= 0) arm_d(dpos[t], ((it + 1) % 3) * a.npad * 8);
             }
             rMr = rMr_new;
-            if (it < a.maxit) {
+            if (!INB && it < a.maxit) {
                 if (A2A) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's part of d has left
                     __syncthreads();
@@ -793,13 +880,6 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         a.st->done = done;
         a.st->rMr[0] = rMr;
     }
-}
-
-// block columns as storage positions (VAR & 4): bcolp[i] = pos[bcol[i]]
-__global__ void k_bcol_to_pos(int64_t n, const int32_t* __restrict__ bcol, const int32_t* __restrict__ pos,
-                              int32_t* __restrict__ bcolp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bcolp[i] = pos[bcol[i]];
 }
 
 // ------------------------------------------------------------------------------------------------ ceiling probes
@@ -921,7 +1001,7 @@ __global__ void __launch_bounds__(PBS) k_probe_exchange(PersistPcg a, int rounds
 }
 
 int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
-    const int64_t need = 2 * npad + 2 * G + 4 * G + 8 * G + 160;  // + granules (4 G x 16 B) + 8 x 32 + 32 counters
+    const int64_t need = 3 * npad + 2 * G + 4 * G + 8 * G + 160;  // d (<= 3 buffers) + partials + granules (4 G x 16 B) + counters
     if (!c->d_persist || c->persist_cap < need) {
         if (c->d_persist) (void)hipFree(c->d_persist);
         c->d_persist = nullptr;
@@ -929,7 +1009,7 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
         FEMCY_HIP(hipMalloc((void**)&c->d_persist, sizeof(double) * need));
     }
     a->dbuf = c->d_persist;
-    a->part1 = c->d_persist + 2 * npad;
+    a->part1 = c->d_persist + 3 * npad;
     a->part2 = a->part1 + 2 * G;
     a->slots = a->part2 + 4 * G;
     a->xc = reinterpret_cast<unsigned int*>(a->slots + 8 * G);
@@ -944,11 +1024,32 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
 
 }  // namespace
 
+// block columns as storage positions (VAR & 4): bcolp[i] = pos[bcol[i]]
+__global__ void k_bcol_to_pos(int64_t n, const int32_t* __restrict__ bcol, const int32_t* __restrict__ pos,
+                              int32_t* __restrict__ bcolp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bcolp[i] = pos[bcol[i]];
+}
+int ensure_bcolp(Ctx* c) {
+    if (c->bcolp_serial == c->pattern_serial && c->d_bcolp) return FEMCY_OK;
+    if (c->d_bcolp) (void)hipFree(c->d_bcolp);
+    c->d_bcolp = nullptr;
+    const int64_t nb = c->stored_rows * SLICE;
+    FEMCY_HIP(hipMalloc((void**)&c->d_bcolp, std::max<int64_t>(nb, 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_bcol_to_pos, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb,
+                       (const int32_t*)c->d_bcol, (const int32_t*)c->d_pos, c->d_bcolp);
+    FEMCY_HIP(hipGetLastError());
+    c->bcolp_serial = c->pattern_serial;
+    return FEMCY_OK;
+}
+
 // default variant of the persistent kernel (FEMCY_TUNE_PERSIST_VARIANT = -1), chosen by the round-3 measurements
 // 
 #ifndef FEMCY_PERSIST_DEFAULT_VARIANT
 #define FEMCY_PERSIST_DEFAULT_VARIANT 6
 #endif
+
+constexpr int PERSIST_MULTI_RETRY = 16;   // RCCL-loop solves after a cross-rank time-out before the one-launch path is tried again
 
 int64_t persist_streamed_bytes(Ctx* c);
 // does the system of this context take the persistent kernel?  (the multi-rank agreement)
@@ -972,8 +1073,16 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     *handled = false;
     const bool multi = c->comm != nullptr;
     if (!c->opt_persist || c->persist_failed) return FEMCY_OK;
-    if (multi && (!c->persist_multi || c->persist_multi_failed || !c->opt_persist_multi || maxit >= (1 << 20) - 2))
-        return FEMCY_OK;
+    if (multi && c->persist_multi && c->persist_multi_failed && c->opt_persist_multi) {
+        // a time-out is usually host-side skew between the ranks' calls (module load, a Python GC pause), not a broken
+        // node: after PERSIST_MULTI_RETRY solves on the RCCL loop the one-launch path is tried again.  Every rank makes
+        // the same sequence of femcy_pcg calls and learnt of the failure in the same collective, so the counters agree.
+        if (++c->persist_multi_fallbacks >= PERSIST_MULTI_RETRY) {
+            c->persist_multi_failed = false;
+            c->persist_multi_fallbacks = 0;
+        }
+    }
+    if (multi && (!c->persist_multi || c->persist_multi_failed || !c->opt_persist_multi)) return FEMCY_OK;
     const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;   // one workgroup per CU
     if (G < PNX) return FEMCY_OK;
     const int nwx = (G / PNX) * 4;
@@ -1002,146 +1111,154 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     const bool wide = (var & V_WIDE) != 0, a2a = (var & V_A2A) != 0;
     // d in storage order covers the padding lanes of the last slice as well
     const int64_t npad = wide ? (((int64_t)c->nslices * SLICE * c->dm + 1) & ~(int64_t)1) : ((c->n + 1) & ~(int64_t)1);
-    PersistPcg a;
-    {
-        int rc = persist_buffers(c, G, npad, &a);
-        if (rc) return rc;
-    }
-    // slices of each wave: XCD k's waves share the slice range xcd[k] .. xcd[k+1] (the ranges are balanced by stored
-    // block rows); inside it the slices go longest first to the wave with the least rows so far (LPT) -- the sigma-
-    // sorted windows would otherwise hand all long slices to the same waves.  Tagged-granule form: wave 0 of every
-    // workgroup sweeps the granules and does not prefetch, so it starts with a handicap of one batch
-    {
-        std::vector<int64_t> key = {G, SPW, c->pattern_serial, a2a ? 1 : 0};
-        for (int k = 0; k <= PNX; ++k) key.push_back(c->xcd.start[k]);
-        if (key != c->persist_assign_key || !c->d_persist_assign) {
-            std::vector<int32_t> assign((size_t)PNX * nwx * SPW, -1);
-            std::vector<int32_t> order, load(nwx), cnt(nwx);
-            for (int k = 0; k < PNX; ++k) {
-                order.clear();
-                for (int32_t s = c->xcd.start[k]; s < c->xcd.start[k + 1]; ++s) order.push_back(s);
-                std::stable_sort(order.begin(), order.end(),
-                                 [&](int32_t x, int32_t y) { return c->h_slice_len[x] > c->h_slice_len[y]; });
-                for (int w = 0; w < nwx; ++w) load[w] = (a2a && (w % 4) == 0) ? CH : 0;
-                std::fill(cnt.begin(), cnt.end(), 0);
-                for (int32_t s : order) {
-                    int best = -1;
-                    for (int w = 0; w < nwx; ++w)
-                        if (cnt[w] < SPW && (best < 0 || load[w] < load[best])) best = w;
-                    assign[((size_t)k * nwx + best) * SPW + cnt[best]++] = s;
-                    load[best] += c->h_slice_len[s];
-                }
-            }
-            if (c->d_persist_assign) (void)hipFree(c->d_persist_assign);
-            c->d_persist_assign = nullptr;
-            FEMCY_HIP(hipMalloc((void**)&c->d_persist_assign, assign.size() * sizeof(int32_t)));
-            FEMCY_HIP(hipMemcpyAsync(c->d_persist_assign, assign.data(), assign.size() * sizeof(int32_t),
-                                     hipMemcpyHostToDevice, c->stream));
-            FEMCY_HIP(hipStreamSynchronize(c->stream));
-            c->persist_assign_key = key;
-        }
-    }
-    if (wide && (c->bcolp_serial != c->pattern_serial || !c->d_bcolp)) {
-        if (c->d_bcolp) (void)hipFree(c->d_bcolp);
-        c->d_bcolp = nullptr;
-        const int64_t nb = c->stored_rows * SLICE;
-        FEMCY_HIP(hipMalloc((void**)&c->d_bcolp, std::max<int64_t>(nb, 1) * sizeof(int32_t)));
-        hipLaunchKernelGGL(k_bcol_to_pos, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb,
-                           (const int32_t*)c->d_bcol, (const int32_t*)c->d_pos, c->d_bcolp);
-        FEMCY_HIP(hipGetLastError());
-        c->bcolp_serial = c->pattern_serial;
-    }
-    a.assign = c->d_persist_assign;
-    a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = wide ? c->d_bcolp : c->d_bcol; a.node_of = c->d_node_of;
-    a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
-    a.st = c->d_state;
-    a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
-    a.l2_rows = c->opt_persist_l2rows;
-    a.mbox = c->d_mbox; a.peer = c->d_peer_tab; a.mr_tab = c->d_mr_tab; a.owner = c->d_owner;
-    a.rank = c->rank; a.nranks = c->nranks; a.nb_total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
-    c->solve_serial = (c->solve_serial % 4095) + 1;               // 1 .. 4095: a tag is never 0 (the zeroed mailbox)
-    a.tagbase = c->solve_serial << 20;
+    // set-up and launch.  Across ranks every path from here on has to reach the agreement below -- the other ranks are
+    // in it -- so a failure in this part is recorded, voted "bad", and returned only afterwards
     size_t tp = (size_t)-1;
-    bool launched = true;
+    bool launched = true, not_resident = false;
+    auto setup_and_launch = [&]() -> int {
+        PersistPcg a;
+        {
+            int rc = persist_buffers(c, G, npad, &a);
+            if (rc) return rc;
+        }
+        // slices of each wave: XCD k's waves share the slice range xcd[k] .. xcd[k+1] (the ranges are balanced by stored
+        // block rows); inside it the slices go longest first to the wave with the least rows so far (LPT) -- the sigma-
+        // sorted windows would otherwise hand all long slices to the same waves.  Tagged-granule form: wave 0 of every
+        // workgroup sweeps the granules and does not prefetch, so it starts with a handicap of one batch
+        {
+            std::vector<int64_t> key = {G, SPW, c->pattern_serial, a2a ? 1 : 0};
+            for (int k = 0; k <= PNX; ++k) key.push_back(c->xcd.start[k]);
+            if (key != c->persist_assign_key || !c->d_persist_assign) {
+                std::vector<int32_t> assign((size_t)PNX * nwx * SPW, -1);
+                std::vector<int32_t> order, load(nwx), cnt(nwx);
+                for (int k = 0; k < PNX; ++k) {
+                    order.clear();
+                    for (int32_t s = c->xcd.start[k]; s < c->xcd.start[k + 1]; ++s) order.push_back(s);
+                    std::stable_sort(order.begin(), order.end(),
+                                     [&](int32_t x, int32_t y) { return c->h_slice_len[x] > c->h_slice_len[y]; });
+                    for (int w = 0; w < nwx; ++w) load[w] = (a2a && (w % 4) == 0) ? CH : 0;
+                    std::fill(cnt.begin(), cnt.end(), 0);
+                    for (int32_t s : order) {
+                        int best = -1;
+                        for (int w = 0; w < nwx; ++w)
+                            if (cnt[w] < SPW && (best < 0 || load[w] < load[best])) best = w;
+                        assign[((size_t)k * nwx + best) * SPW + cnt[best]++] = s;
+                        load[best] += c->h_slice_len[s];
+                    }
+                }
+                if (c->d_persist_assign) (void)hipFree(c->d_persist_assign);
+                c->d_persist_assign = nullptr;
+                FEMCY_HIP(hipMalloc((void**)&c->d_persist_assign, assign.size() * sizeof(int32_t)));
+                FEMCY_HIP(hipMemcpyAsync(c->d_persist_assign, assign.data(), assign.size() * sizeof(int32_t),
+                                         hipMemcpyHostToDevice, c->stream));
+                FEMCY_HIP(hipStreamSynchronize(c->stream));
+                c->persist_assign_key = key;
+            }
+        }
+        if (wide) {
+            int rc = ensure_bcolp(c);
+            if (rc) return rc;
+        }
+        a.assign = c->d_persist_assign;
+        a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = wide ? c->d_bcolp : c->d_bcol; a.node_of = c->d_node_of;
+        a.vals = c->d_Kvals; a.b = d_b; a.M = c->d_M; a.x = d_x;
+        a.st = c->d_state;
+        a.npad = (int32_t)npad; a.maxit = maxit; a.lds_rows = lds_rows; a.eps = eps;
+        a.l2_rows = c->opt_persist_l2rows;
+        a.mbox = c->d_mbox; a.peer = c->d_peer_tab; a.mr_tab = c->d_mr_tab; a.owner = c->d_owner;
+        a.rank = c->rank; a.nranks = c->nranks; a.nb_total = c->h_nb_ptr.empty() ? 0 : c->h_nb_ptr.back();
+        c->solve_serial = (c->solve_serial % 4095) + 1;               // 1 .. 4095: a tag is never 0 (the zeroed mailbox)
+        a.tagbase = c->solve_serial << 20;
 #define FEMCY_PERSIST_M(DM_, SPW_, RJ_, VAR_, MULTI_)                                                             \
-    do {                                                                                                          \
-        const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>);             \
-        if (lds > 48 * 1024)                                                                                      \
-            FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        /* the grid barrier needs all G workgroups resident; across ranks a refusal here would leave the others */ \
-        /* polling, so it is reported as a failed solve: the agreement after the launch sends everybody to RCCL  */ \
-        if (!coresident(c, fn, PBS, lds, G)) {                                                                    \
-            if (!multi) return FEMCY_OK;                                                                          \
-            launched = false;                                                                                     \
-            break;                                                                                                \
-        }                                                                                                         \
-        tp = timing_begin(c, T_PERSIST);                                                                          \
-        hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>), dim3(G), dim3(PBS), lds, c->stream, a); \
-    } while (0)
+        do {                                                                                                          \
+            const void* fn = reinterpret_cast<const void*>(&k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>);             \
+            if (lds > 48 * 1024)                                                                                      \
+                FEMCY_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+            /* the grid barrier needs all G workgroups resident; across ranks a refusal here would leave the others */ \
+            /* polling, so it is reported as a failed solve: the agreement after the launch sends everybody to RCCL  */ \
+            if (!coresident(c, fn, PBS, lds, G)) {                                                                    \
+                if (!multi) return FEMCY_OK;                                                                          \
+                launched = false;                                                                                     \
+                break;                                                                                                \
+            }                                                                                                         \
+            tp = timing_begin(c, T_PERSIST);                                                                          \
+            hipLaunchKernelGGL((k_pcg_persist<DM_, SPW_, RJ_, VAR_, MULTI_>), dim3(G), dim3(PBS), lds, c->stream, a); \
+        } while (0)
 #define FEMCY_PERSIST(DM_, SPW_, RJ_, VAR_) FEMCY_PERSIST_M(DM_, SPW_, RJ_, VAR_, false)
 #ifdef FEMCY_PERSIST_ALL_VARIANTS
 #define FEMCY_PERSIST_V(DM_, SPW_, RJ_)                                                                           \
-    switch (var & 7) {                                                                                            \
-        case 0: FEMCY_PERSIST(DM_, SPW_, RJ_, 0); break;                                                          \
-        case 1: FEMCY_PERSIST(DM_, SPW_, RJ_, 1); break;                                                          \
-        case 2: FEMCY_PERSIST(DM_, SPW_, RJ_, 2); break;                                                          \
-        case 3: FEMCY_PERSIST(DM_, SPW_, RJ_, 3); break;                                                          \
-        case 4: FEMCY_PERSIST(DM_, SPW_, RJ_, 4); break;                                                          \
-        case 5: FEMCY_PERSIST(DM_, SPW_, RJ_, 5); break;                                                          \
-        case 6: FEMCY_PERSIST(DM_, SPW_, RJ_, 6); break;                                                          \
-        default: FEMCY_PERSIST(DM_, SPW_, RJ_, 7); break;                                                         \
-    }
+        switch (var & 15) {                                                                                           \
+            case 14: FEMCY_PERSIST(DM_, SPW_, RJ_, 14); break;                                                        \
+            case 0: FEMCY_PERSIST(DM_, SPW_, RJ_, 0); break;                                                          \
+            case 1: FEMCY_PERSIST(DM_, SPW_, RJ_, 1); break;                                                          \
+            case 2: FEMCY_PERSIST(DM_, SPW_, RJ_, 2); break;                                                          \
+            case 3: FEMCY_PERSIST(DM_, SPW_, RJ_, 3); break;                                                          \
+            case 4: FEMCY_PERSIST(DM_, SPW_, RJ_, 4); break;                                                          \
+            case 5: FEMCY_PERSIST(DM_, SPW_, RJ_, 5); break;                                                          \
+            case 6: FEMCY_PERSIST(DM_, SPW_, RJ_, 6); break;                                                          \
+            default: FEMCY_PERSIST(DM_, SPW_, RJ_, 7); break;                                                         \
+        }
 #else
-    // the shipped library carries the default variant and the round-2 form (0) of every shape
+        // the shipped library carries the default variant, the other one of {6 (three exchanges), 14 (two exchanges +
+        // in-band d)} and the round-2 form (0) of every shape
+#define FEMCY_PERSIST_ALT_VARIANT (FEMCY_PERSIST_DEFAULT_VARIANT == 14 ? 6 : 14)
 #define FEMCY_PERSIST_V(DM_, SPW_, RJ_)                                                                           \
-    if ((var & 7) == FEMCY_PERSIST_DEFAULT_VARIANT) FEMCY_PERSIST(DM_, SPW_, RJ_, FEMCY_PERSIST_DEFAULT_VARIANT); \
-    else if ((var & 7) == 0) FEMCY_PERSIST(DM_, SPW_, RJ_, 0);                                                    \
-    else { set_error("persistent PCG variant %d is not in this build (default %d, 0; all with "                   \
-                     "-DFEMCY_PERSIST_ALL_VARIANTS)", var, FEMCY_PERSIST_DEFAULT_VARIANT); return FEMCY_EINVAL; }
+        if ((var & 15) == FEMCY_PERSIST_DEFAULT_VARIANT) FEMCY_PERSIST(DM_, SPW_, RJ_, FEMCY_PERSIST_DEFAULT_VARIANT); \
+        else if ((var & 15) == FEMCY_PERSIST_ALT_VARIANT) FEMCY_PERSIST(DM_, SPW_, RJ_, FEMCY_PERSIST_ALT_VARIANT);   \
+        else if ((var & 15) == 0) FEMCY_PERSIST(DM_, SPW_, RJ_, 0);                                                   \
+        else { set_error("persistent PCG variant %d is not in this build (%d, %d, 0; 0..7 and 14 with "               \
+                         "-DFEMCY_PERSIST_ALL_VARIANTS)", var, FEMCY_PERSIST_DEFAULT_VARIANT, FEMCY_PERSIST_ALT_VARIANT); \
+               return FEMCY_EINVAL; }
 #endif
-    // register-resident block rows per slice: what 512 VGPRs per lane hold next to the vectors and the streaming
-    // buffers (dm 3: 5 rows x 3 slices or 3 rows x 4 slices of 19 registers each)
-    if (multi) {
-        // across ranks: the default variant, 3 x 3 blocks (the agreement checked dm == 3); register rows as in the
-        // single-rank kernel of the same shape
-        FEMCY_REQUIRE((var & 7) == FEMCY_PERSIST_DEFAULT_VARIANT, "the multi-rank persistent PCG exists for the default variant only");
-        if (SPW == 3) { FEMCY_PERSIST_M(3, 3, 4, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
-        else { FEMCY_PERSIST_M(3, 4, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
-    } else
+        // register-resident block rows per slice: what 512 VGPRs per lane hold next to the vectors and the streaming
+        // buffers (dm 3: 5 rows x 3 slices or 3 rows x 4 slices of 19 registers each)
+        if (multi) {
+            // across ranks: the default variant, 3 x 3 blocks (the agreement checked dm == 3); register rows as in the
+            // single-rank kernel of the same shape
+            FEMCY_REQUIRE((var & 15) == FEMCY_PERSIST_DEFAULT_VARIANT, "the multi-rank persistent PCG exists for the default variant only");
+            if (SPW == 3) { FEMCY_PERSIST_M(3, 3, 4, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            else { FEMCY_PERSIST_M(3, 4, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+        } else
 #ifdef FEMCY_PERSIST_ONLY_334     // compile-time experiments: one shape only
-    if (c->dm == 3 && SPW == 3 && c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) } else return FEMCY_OK;
+        if (c->dm == 3 && SPW == 3 && c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) } else return FEMCY_OK;
 #else
-    if (c->dm == 3 && SPW == 3) {
-        if (c->opt_persist_rj == 5) { FEMCY_PERSIST_V(3, 3, 5) }
-        else if (c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) }
-        else { FEMCY_PERSIST_V(3, 3, 0) }
-    } else if (c->dm == 3) {
-        if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
-    } else if (SPW == 3) {
-        if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }
-    } else {
-        if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 4, 5) } else { FEMCY_PERSIST_V(2, 4, 0) }
-    }
+        if (c->dm == 3 && SPW == 3) {
+            if (c->opt_persist_rj == 5) { FEMCY_PERSIST_V(3, 3, 5) }
+            else if (c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) }
+            else { FEMCY_PERSIST_V(3, 3, 0) }
+        } else if (c->dm == 3) {
+            if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
+        } else if (SPW == 3) {
+            if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }
+        } else {
+            if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 4, 5) } else { FEMCY_PERSIST_V(2, 4, 0) }
+        }
 #endif
 #undef FEMCY_PERSIST_V
 #undef FEMCY_PERSIST
 #undef FEMCY_PERSIST_M
-    if (launched) timing_end(c, tp);
-    FEMCY_HIP(hipGetLastError());
+        if (launched) timing_end(c, tp);
+        FEMCY_HIP(hipGetLastError());
+        return FEMCY_OK;
+    };
+    const int lrc = setup_and_launch();
+    if (!multi && (lrc || not_resident)) return lrc;
     if (multi) {
         // every rank learns whether the solve completed EVERYWHERE (a time-out on one rank leaves the others'
         // iterates unusable as well); this collective is also what keeps a fast rank's next solve from writing into
         // mailboxes a slow rank is still reading
         FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
         FEMCY_HIP(hipStreamSynchronize(c->stream));
-        double bad = (!launched || c->h_state->done == 3) ? 1.0 : 0.0;
+        double bad = (lrc != FEMCY_OK || !launched || c->h_state->done == 3) ? 1.0 : 0.0;
         FEMCY_HIP(hipMemcpyAsync(c->d_commbuf, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream));
         int rc = comm_allreduce_sum(c, c->d_commbuf, 1);
         if (rc) return rc;
         FEMCY_HIP(hipMemcpyAsync(&bad, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         FEMCY_HIP(hipStreamSynchronize(c->stream));
+        if (lrc) return lrc;                                      // (after the vote: nobody is left alone in it)
         if (bad != 0.0) {
             c->persist_multi_failed = true;
+            c->persist_multi_fallbacks = 0;
             c->timing.barrier_timeouts++;
             return FEMCY_OK;                                      // *handled stays false: the RCCL loop redoes the solve
         }

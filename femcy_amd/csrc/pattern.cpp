@@ -93,6 +93,11 @@ void spmv_split(Ctx* c) {
 int build_pattern(Ctx* c) {
     const int32_t nn = c->nn, ne = c->ne, npe = c->npe, dm = c->dm;
     const int32_t* el = c->h_elems.data();
+    // the products gather x through buffer resources with 32-bit byte offsets (col * dm * 8; out-of-range buffer loads
+    // return 0, i.e. a silently wrong product): a vector must stay below 2 GiB -- 89 M nodes in 3-D, beyond which the
+    // matrix alone (> 100 GB) leaves no room for an element pass on one GPU anyway; partition the mesh instead
+    FEMCY_REQUIRE(((int64_t)nn + SLICE) * dm * 8 < ((int64_t)1 << 31),
+                  "%d nodes x %d DOF exceed the 2 GiB per vector the SpMV gathers address; partition the mesh", nn, dm);
 
     // ---- node -> incident (element, local index), ascending element order
     std::vector<int32_t> ne_ptr(nn + 1, 0);
@@ -155,22 +160,116 @@ int build_pattern(Ctx* c) {
     // ---- SELL-C-sigma: inside windows of `sigma` nodes, rows are stored in order of decreasing length, so the 64
     // rows of a slice have (nearly) equal length and the padding disappears (C3D10: 16 % -> < 2 %); the window keeps
     // a slice's nodes spatially close, so the x-gathers stay local.  pos[a] = storage position of node a.
+    //
+    // Round 4: the windows run over an internal node ORDER, not necessarily the caller's numbering.  With the solver
+    // vectors in storage order (kernels_pcg.hip) a wave's gather of block column j reads positions pos[col(lane, j)]:
+    // what it costs is the number of cache lines those 64 addresses touch.  Lanes are rows of one length class in
+    // ascending order; if the order walks the mesh along lines (a lexicographic coordinate order on a structured
+    // mesh) their j-th neighbours are consecutive members of THEIR class, i.e. consecutive positions: 14 lines per
+    // gather on the C3D10 plate instead of 27 (caller's numbering: corners first, then mid-side nodes by edge);
+    // Morton and reverse Cuthill-McKee orders give 31 (tools/gather_lines.py) -- locality is not the point,
+    // regularity is.  So the candidates (the caller's numbering and the lexicographic orders of the quantised
+    // coordinates, one per axis permutation) are MEASURED on the pattern -- mean lines per gather over sampled slices --
+    // and the best one is taken if it beats the caller's numbering by 10 %.
     const int32_t nslices = (nn + SLICE - 1) / SLICE;
     const int32_t sigma = std::max(SLICE, (c->sell_sigma / SLICE) * SLICE);
     std::vector<int32_t> node_of((size_t)nslices * SLICE, -1), pos(nn);
-    parallel_for((nn + sigma - 1) / sigma, [&](int64_t lo, int64_t hi, int) {
-        std::vector<int32_t> idx;
-        for (int64_t w = lo; w < hi; ++w) {
-            const int32_t a0 = (int32_t)(w * sigma), a1 = std::min(nn, a0 + sigma);
-            idx.resize(a1 - a0);
-            for (int32_t a = a0; a < a1; ++a) idx[a - a0] = a;
-            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return rowlen[x] > rowlen[y]; });
-            for (int32_t k = 0; k < a1 - a0; ++k) {
-                node_of[a0 + k] = idx[k];
-                pos[idx[k]] = a0 + k;
+    auto layout = [&](const std::vector<int32_t>* order, std::vector<int32_t>& node_of_, std::vector<int32_t>& pos_) {
+        parallel_for((nn + sigma - 1) / sigma, [&](int64_t lo, int64_t hi, int) {
+            std::vector<int32_t> idx;
+            for (int64_t w = lo; w < hi; ++w) {
+                const int32_t a0 = (int32_t)(w * sigma), a1 = std::min(nn, a0 + sigma);
+                idx.resize(a1 - a0);
+                for (int32_t a = a0; a < a1; ++a) idx[a - a0] = order ? (*order)[a] : a;
+                std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return rowlen[x] > rowlen[y]; });
+                for (int32_t k = 0; k < a1 - a0; ++k) {
+                    node_of_[a0 + k] = idx[k];
+                    pos_[idx[k]] = a0 + k;
+                }
+            }
+        });
+    };
+    // mean number of 128-byte lines one wave gather touches (dm doubles per lane at pos * dm * 8), over <= 192 slices
+    auto gather_lines = [&](const std::vector<int32_t>& node_of_, const std::vector<int32_t>& pos_) -> double {
+        const int32_t full = nn / SLICE;                         // slices without padding lanes
+        if (full < 1) return 0.0;
+        const int32_t nsamp = std::min<int32_t>(full, 192);
+        int64_t lines = 0, gathers = 0;
+        std::vector<int64_t> ln(2 * SLICE);
+        for (int32_t t = 0; t < nsamp; ++t) {
+            const int32_t s = (int32_t)((int64_t)t * full / nsamp);
+            int32_t L = 0;
+            for (int lane = 0; lane < SLICE; ++lane) L = std::max(L, rowlen[node_of_[(size_t)s * SLICE + lane]]);
+            for (int32_t j = 0; j < L; ++j) {
+                for (int lane = 0; lane < SLICE; ++lane) {
+                    const int32_t a = node_of_[(size_t)s * SLICE + lane];
+                    const int32_t col = j < rowlen[a] ? adj[adj_ptr[a] + j] : a;
+                    const int64_t b0 = (int64_t)pos_[col] * dm * 8;
+                    ln[2 * lane] = b0 >> 7;
+                    ln[2 * lane + 1] = (b0 + dm * 8 - 1) >> 7;
+                }
+                std::sort(ln.begin(), ln.end());
+                lines += std::unique(ln.begin(), ln.end()) - ln.begin();
+                ++gathers;
             }
         }
-    });
+        return gathers ? (double)lines / (double)gathers : 0.0;
+    };
+    c->node_order_used = 0;
+    for (double& v : c->node_order_cost) v = 0.0;
+    layout(nullptr, node_of, pos);
+    if (c->opt_node_order >= 1 && (int64_t)c->h_nodes.size() == (int64_t)nn * dm && nn >= 4 * SLICE) {
+        const double natural = gather_lines(node_of, pos);
+        c->node_order_cost[0] = natural;
+        // coordinates quantised on one common scale (21 bits per axis): grid lines of a structured mesh compare equal
+        double lo[3] = {0, 0, 0}, ext = 0.0;
+        for (int d = 0; d < dm; ++d) {
+            double mn = c->h_nodes[d], mx = mn;
+            for (int32_t a = 1; a < nn; ++a) {
+                mn = std::min(mn, c->h_nodes[(size_t)a * dm + d]);
+                mx = std::max(mx, c->h_nodes[(size_t)a * dm + d]);
+            }
+            lo[d] = mn;
+            ext = std::max(ext, mx - mn);
+        }
+        const double scale = ext > 0.0 ? (double)((1 << 21) - 1) / ext : 0.0;
+        std::vector<uint32_t> q((size_t)nn * dm);
+        for (int32_t a = 0; a < nn; ++a)
+            for (int d = 0; d < dm; ++d) q[(size_t)a * dm + d] = (uint32_t)((c->h_nodes[(size_t)a * dm + d] - lo[d]) * scale + 0.5);
+        static const int perms3[6][3] = {{2, 1, 0}, {2, 0, 1}, {1, 2, 0}, {1, 0, 2}, {0, 2, 1}, {0, 1, 2}};   // slowest .. fastest
+        static const int perms2[2][3] = {{1, 0, 0}, {0, 1, 0}};
+        const int ncand = dm == 3 ? 6 : 2;
+        double best = natural;
+        int best_k = -1;
+        std::vector<int32_t> order(nn), best_node_of, best_pos, cn((size_t)nslices * SLICE, -1), cp(nn);
+        std::vector<std::pair<uint64_t, int32_t>> keyed(nn);
+        for (int k = 0; k < ncand; ++k) {
+            if (c->opt_node_order >= 2 && c->opt_node_order - 2 != k) continue;
+            const int* pm = dm == 3 ? perms3[k] : perms2[k];
+            for (int32_t a = 0; a < nn; ++a) {
+                uint64_t key = 0;
+                for (int d = 0; d < dm; ++d) key = (key << 21) | q[(size_t)a * dm + pm[d]];
+                keyed[a] = {key, a};
+            }
+            std::sort(keyed.begin(), keyed.end());                 // ties (coincident nodes) by node number
+            for (int32_t a = 0; a < nn; ++a) order[a] = keyed[a].second;
+            std::fill(cn.begin(), cn.end(), -1);
+            layout(&order, cn, cp);
+            const double cost = gather_lines(cn, cp);
+            c->node_order_cost[1 + k] = cost;
+            if (c->opt_node_order >= 2 || cost < best) {
+                best = cost;
+                best_k = k;
+                best_node_of = cn;
+                best_pos = cp;
+            }
+        }
+        if (best_k >= 0 && (c->opt_node_order >= 2 || best < 0.9 * natural)) {
+            node_of.swap(best_node_of);
+            pos.swap(best_pos);
+            c->node_order_used = 1 + best_k;
+        }
+    }
     std::vector<int32_t> slice_len(nslices, 0);
     std::vector<int64_t> slice_off(nslices + 1, 0);
     for (int32_t s = 0; s < nslices; ++s) {

@@ -401,7 +401,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         // schedule / layout knobs of the device kernels: accepted, without effect on the host
         case FEMCY_OPT_ASSEMBLY: case FEMCY_OPT_PCG_POLL: case FEMCY_OPT_SPMV_VARIANT: case FEMCY_OPT_EW_GRID:
         case FEMCY_OPT_PCG_GRAPH: case FEMCY_OPT_PCG_PERSIST: case FEMCY_OPT_PCG_SMALL: case FEMCY_OPT_OVERLAP:
-        case FEMCY_OPT_PCG_PERSIST_MULTI:
+        case FEMCY_OPT_PCG_PERSIST_MULTI: case FEMCY_OPT_PCG_STORAGE_ORDER:
+            return FEMCY_OK;
+        case FEMCY_OPT_NODE_ORDER:
+            REQUIRE(!c->have_pattern, "set the node order before femcy_build_pattern");
             return FEMCY_OK;
         default:
             if (option >= 100 && option <= 113) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
@@ -573,6 +576,14 @@ int femcy_get_pattern_info(femcy_ctx* ctx, femcy_pattern_info* out) {
     out->stored_blocks = out->nnzb;                 // block-CSR: no padding
     out->nslices = (c->nn + 63) / 64;
     out->max_node_elems = c->max_node_elems;
+    return FEMCY_OK;
+}
+int femcy_get_node_order(femcy_ctx* ctx, int32_t* used, double* lines) {
+    CTX_OR_FAIL(ctx);
+    REQUIRE(c->have_pattern, "pattern not built");
+    if (used) *used = 0;                                  // the host backend keeps the caller's numbering (block CSR)
+    if (lines)
+        for (int k = 0; k < 7; ++k) lines[k] = 0.0;
     return FEMCY_OK;
 }
 
@@ -1138,6 +1149,8 @@ int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes) {
     return FEMCY_ECOMM
 int femcy_comm_unique_id(void*) { NO_COMM("femcy_comm_unique_id"); }
 int femcy_comm_local_id(void*) { NO_COMM("femcy_comm_local_id"); }
+int femcy_comm_shm_id(void*, int64_t) { NO_COMM("femcy_comm_shm_id"); }
+int femcy_comm_allgather_host(femcy_ctx*, const void*, int32_t, void*) { NO_COMM("femcy_comm_allgather_host"); }
 int femcy_comm_init(femcy_ctx*, int32_t, int32_t, const void*, int32_t, const int32_t*, const int32_t*, int32_t,
                     const uint8_t*) { NO_COMM("femcy_comm_init"); }
 int femcy_comm_set_neighbours(femcy_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*) { NO_COMM("femcy_comm_set_neighbours"); }

@@ -109,6 +109,16 @@ enum femcy_option {
     FEMCY_OPT_EXCHANGE = 8,     /* multi-rank interface exchange: 0 = all-reduce of the packed global interface vector
                                    (default), 1 = send/recv with the neighbouring ranks (needs
                                    femcy_comm_set_neighbours); femcy_comm_tune measures both and sets it */
+    FEMCY_OPT_PCG_STORAGE_ORDER = 13, /* 1 (default): the three-launch PCG of a single rank keeps its vectors in the matrix's
+                                   storage order (b permuted once, x permuted back at the end): lanes of a wavefront are
+                                   rows of one length class in ascending order, so their gathers of d touch neighbouring
+                                   addresses; 0 = node order (what multi-rank runs keep)                          */
+    FEMCY_OPT_NODE_ORDER = 14,  /* internal row order of the matrix, set before femcy_build_pattern; vectors handed
+                                   to / from the caller always keep the caller's numbering.  0 = rows sorted by length
+                                   inside windows of the caller's numbering; 1 = inside windows of the best of the
+                                   lexicographic coordinate orders (one per axis permutation) if its measured gather cost
+                                   (cache lines per wavefront gather, femcy_get_node_order) beats the caller's numbering
+                                   by 10 %; 2 + k = coordinate order k forced (tests)                            */
     FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (up to ~7.8e5
                                    DOF on MI355X) and whose matrix, less the part the kernel keeps on chip, fits the
                                    Infinity Cache are solved by one persistent launch -- vectors and part of the matrix
@@ -219,6 +229,10 @@ int femcy_set_material(femcy_ctx* ctx, int32_t kind, const double* C /*[s*s]*/, 
  * node adjacency -> blocked sliced-ELL matrix, element->slot map, node->element lists */
 int femcy_build_pattern(femcy_ctx* ctx);
 int femcy_get_pattern_info(femcy_ctx* ctx, femcy_pattern_info* out);
+/* which row order femcy_build_pattern took (FEMCY_OPT_NODE_ORDER): used = 0 the caller's numbering, 1 + k = coordinate
+ * order k; lines[0] = mean 128-byte cache lines per wavefront gather with the caller's numbering, lines[1 + k] = with
+ * coordinate order k (0 where not evaluated) */
+int femcy_get_node_order(femcy_ctx* ctx, int32_t* used /* nullable */, double* lines /*[7], nullable*/);
 
 /* ------------------------------------------------------------------------- vector plumbing */
 int femcy_vec_upload(femcy_ctx* ctx, int vec, const double* src, int64_t n);
@@ -328,6 +342,14 @@ int femcy_comm_unique_id(void* id128);
  * one).  Same kernels and call sequence as the RCCL transport -- it is how the multi-rank path is verified on a
  * single GPU.  A rendezvous that is not completed by all ranks within 60 s fails with FEMCY_ECOMM. */
 int femcy_comm_local_id(void* id128);
+/* 128-byte id of a shared-memory group: the ranks are PROCESSES of one host (any devices, also all on one -- which
+ * RCCL refuses) that exchange through a POSIX shared-memory segment; same kernels and call sequence as the other
+ * transports.  max_values = the longest vector one collective carries (doubles; the packed interface vector + 8 is
+ * enough; at least 4096 are reserved).  Produced by one process and handed to the others by the host program (a
+ * pipe, a file, the command line).  It exists so that the cross-process branches of the mailbox path below
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle, kernels of different processes writing into each other's HBM) can run
+ * on a one-GPU box; a rendezvous that is not completed within 60 s fails with FEMCY_ECOMM.  Up to 16 ranks. */
+int femcy_comm_shm_id(void* id128, int64_t max_values);
 /* element partition: this ctx holds one sub-mesh; iface_local_dofs[k] is the local scalar DOF that is
  * entry iface_global_slot[k] of the packed global interface vector (length niface_global), owner[i] = 1
  * if this rank counts local DOF i in dot products (exactly one rank per shared DOF). */
@@ -369,6 +391,10 @@ int femcy_iface_sum(femcy_ctx* ctx, int vec);
  * femcy_pcg then takes the one-launch path on every rank alike; after each such solve the ranks agree through the
  * communicator whether it completed, and a solve that timed out anywhere is redone everywhere by the RCCL loop. */
 int femcy_comm_mailbox_export(femcy_ctx* ctx, void* blob256);
+/* collective helper for the step in the middle: `bytes` host bytes of every rank -> recv[nranks][bytes] on every rank,
+ * through the context's own transport (no communicator: a copy) -- the host program needs no second communication
+ * library to hand the blobs round */
+int femcy_comm_allgather_host(femcy_ctx* ctx, const void* send, int32_t bytes, void* recv /*[nranks*bytes]*/);
 int femcy_comm_mailbox_import(femcy_ctx* ctx, int32_t nblobs, const void* blobs /*[nranks][256]*/);
 int femcy_comm_persist_agree(femcy_ctx* ctx, int32_t* enabled);
 
