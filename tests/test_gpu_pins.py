@@ -207,3 +207,57 @@ def test_consistent_tangent_equals_oracle_complex_step(gpu_ctx_factory, name):
     ctx.set_option(be.OPT_TANGENT, 0)
     ctx.assemble_K(be.VEC_DOF)
     assert abs(ctx.get_K_bsr().tocsr() - Ko).max() > 1e-3 * abs(Ko).max()
+
+
+# ------------------------------------------------------------------------------------------------ round 4: 2-D families
+PLANE = ["CPS3", "CPS4", "CPS6", "CPS8"]
+
+
+def _plane_ele(etype):
+    from femcy_amd import element_zoo as ez
+    return {"CPS3": ez.Element_linear_triangular, "CPS4": ez.Element_linear_quadrilateral,
+            "CPS6": ez.Element_quadratic_triangular, "CPS8": ez.Element_quadratic_quadrilateral}[etype]()
+
+
+def _plane_mat(mkind):
+    from femcy_amd.material_zoo import LinearIsotropicPlaneStrain, LinearIsotropicPlaneStress
+    return (LinearIsotropicPlaneStrain if mkind == "pstrain" else LinearIsotropicPlaneStress)(3.5, 0.3)
+
+
+@pytest.mark.parametrize("etype", PLANE)
+@pytest.mark.parametrize("mkind", ["pstrain", "pstress"])
+def test_one_2d_element_Ke_equals_the_symbolic_matrix(gpu_ctx_factory, etype, mkind):
+    """every assembly variant that exists for 2-D elements against tests/sympy_pins2d.py: the exactly integrated K^e
+    (CPS3, CPS6, CPS4 on affine geometry), the reduced 2 x 2 matrix of the exact integrand for CPS8"""
+    import sympy as sp
+    from femcy_amd import backend as be
+    import sympy_pins2d as sp2
+    Ke, Kr, X, C = sp2.exact_Ke(sp2.ABAQUS[etype], (mkind, sp.Rational(7, 2), sp.Rational(3, 10)))
+    el = np.arange(X.shape[0], dtype=np.int32)[None, :]
+    ctx = _ctx(gpu_ctx_factory, X, el, _plane_ele(etype), _plane_mat(mkind))
+    for mode in (be.ASM_GATHER, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_AUTO, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM):
+        ctx.set_option(be.OPT_ASSEMBLY, mode)
+        ctx.assemble_K(-1)
+        K = ctx.get_K_bsr().toarray()
+        assert np.abs(K - Kr).max() < 1e-13 * np.abs(Kr).max(), mode
+    if etype != "CPS8":
+        assert np.abs(K - Ke).max() < 1e-13 * np.abs(Ke).max()
+
+
+@pytest.mark.parametrize("etype", PLANE)
+@pytest.mark.parametrize("mkind", ["pstrain", "pstress"])
+def test_one_2d_element_homogeneous_deformation(gpu_ctx_factory, etype, mkind):
+    """F, Cauchy stress (plane stress: the synthesised F33 of linear_isotropic_plane_stress.py:72-96) and nodal forces
+    of one element under a homogeneous finite deformation against the closed form"""
+    import sympy as sp
+    from femcy_amd import backend as be
+    import sympy_pins2d as sp2
+    f, u, X, F, sig = sp2.homogeneous_case(sp2.ABAQUS[etype], (mkind, sp.Rational(7, 2), sp.Rational(3, 10)))
+    el = np.arange(X.shape[0], dtype=np.int32)[None, :]
+    ctx = _ctx(gpu_ctx_factory, X, el, _plane_ele(etype), _plane_mat(mkind))
+    ctx.upload(be.VEC_DOF, u)
+    ctx.residual_and_K(be.VEC_DOF, be.VEC_FORCE)
+    assert np.abs(ctx.download(be.VEC_FORCE) - f).max() < 1e-13 * np.abs(f).max()
+    Fg = ctx.gauss_field(be.GP_F).to_numpy()
+    Sg = ctx.gauss_field(be.GP_SIGMA).to_numpy()
+    assert np.abs(Fg - F).max() < 1e-14 and np.abs(Sg - sig).max() < 1e-13 * np.abs(sig).max()
