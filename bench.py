@@ -279,12 +279,291 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         ctx.close()
 
 
+class RankEnv:
+    """what a rank needs to set a problem up: arguments, rank numbers, torch.distributed (or None), the modules"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+
+    def dev(self):
+        return "cuda" if self.on_gpu else "cpu"
+
+    def agreed_elapsed(self, t0):
+        """seconds since t0, maximum over the ranks"""
+        dt = time.perf_counter() - t0
+        if self.use_dist:
+            box = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev())
+            self.dist.all_reduce(box, op=self.dist.ReduceOp.MAX)
+            dt = float(box.item())
+        return dt
+
+    def agree_min(self, flag):
+        if self.use_dist:
+            box = self.torch.tensor([int(flag)], dtype=self.torch.int32, device=self.dev())
+            self.dist.all_reduce(box, op=self.dist.ReduceOp.MIN)
+            return int(box.item())
+        return int(flag)
+
+    def agree_max(self, flag):
+        if self.use_dist:
+            box = self.torch.tensor([int(flag)], dtype=self.torch.int32, device=self.dev())
+            self.dist.all_reduce(box, op=self.dist.ReduceOp.MAX)
+            return int(box.item())
+        return int(flag)
+
+
+def rank_problem(env, cells, quadratic, use_comm, element, material_cls):
+    """this rank's share of the twist plate on `cells` at state S1, ready to step: context, communicator, the interface
+    exchange chosen by measurement, the persistent PCG across ranks agreed and cross-checked, BOTH multi-rank PCG paths
+    timed (so that one record of a multi-GPU run holds the whole decomposition even when a path falls back)."""
+    args, N, rank, be, dist, torch = env.args, env.N, env.rank, env.be, env.dist, env.torch
+    nx, ny, nz = cells
+    elastic = (2.0e11, 0.3)
+    if use_comm:
+        if nz % N == 0:
+            part = env.partition.plate_slab_part(nx, ny, nz, N, rank)      # this rank's cell layers only
+        else:                                                              # odd debug grids: cut the global mesh
+            g = env.meshgen.twist_plate(nx, ny, nz)
+            part = env.partition.build_part(g["nodes"], g["elements"], N, rank)
+        nodes, el = part.nodes, part.elements
+        bcs, _ = env.meshgen.twist_plate_bcs(nodes)
+        ne_global, n_global = 6 * nx * ny * nz, 3 * (nx + 1) * (ny + 1) * (nz + 1)
+    else:
+        part = None
+        # FEMCY_BENCH_RENUM=1 numbers the mid-side nodes of the C3D10 plate next to the corners they connect instead of
+        # behind all corners (measured in this bench: PCG iteration -4 %, row-centric assembly +50 %; default off)
+        mesh = env.meshgen.twist_plate(nx, ny, nz, quadratic=quadratic,
+                                       renumber=quadratic and os.environ.get("FEMCY_BENCH_RENUM", "0") == "1")
+        nodes, el, bcs, elastic = mesh["nodes"], mesh["elements"], mesh["dirichlet_bc_info"], mesh["elastic"]
+        ne_global, n_global = el.shape[0], nodes.size
+    u, cons = s1_state(nodes, bcs, env.user_values)
+
+    ctx = be.Context(env.local_rank)
+    for var, opt in (("FEMCY_BENCH_SIGMA", be.OPT_SELL_SIGMA),            # tuning knob: SELL sorting window
+                     ("FEMCY_BENCH_PERSIST", be.OPT_PCG_PERSIST),         # 0 = the three-kernel PCG loop (comparison records)
+                     ("FEMCY_BENCH_VARIANT", be.TUNE_PERSIST_VARIANT),    # persistent PCG variant bits (comparison records)
+                     ("FEMCY_BENCH_NODE_ORDER", getattr(be, "OPT_NODE_ORDER", None)),
+                     ("FEMCY_BENCH_STORAGE_ORDER", getattr(be, "OPT_PCG_STORAGE_ORDER", None))):
+        if os.environ.get(var) and opt is not None:
+            ctx.set_option(opt, int(os.environ[var]))
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(element)
+    ctx.set_material(material_cls(*elastic))
+    info = ctx.build_pattern()
+    exchange = pmulti = None
+    if use_comm:
+        uid = [be.Context.comm_unique_id() if rank == 0 else None]
+        if env.use_dist:
+            dist.broadcast_object_list(uid, src=0)
+        with Watchdog(args.comm_timeout, "femcy_comm_init (RCCL communicator)"):
+            ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
+        # interface exchange: measure the packed all-reduce against send/recv with the slab neighbours and keep the
+        # faster one (all ranks decide alike from the maximum over the ranks); --exchange pins it
+        exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None}
+        if hasattr(ctx, "comm_set_neighbours"):
+            ctx.comm_set_neighbours(part)
+            if args.exchange == "auto":
+                try:
+                    with Watchdog(args.comm_timeout, "femcy_comm_tune"):
+                        exchange = ctx.comm_tune(20)
+                    failed = 0
+                except be.FemcyError as e:                  # the send/recv form is the newer one: never let it take the
+                    log(f"[bench] rank {rank}: comm_tune failed ({e}); using the all-reduce exchange")     # run down
+                    failed = 1
+                failed = env.agree_max(failed)              # every rank must run the same exchange
+                if failed:
+                    ctx.set_option(be.OPT_EXCHANGE, 0)
+                    exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None, "tune": "failed"}
+            else:
+                ctx.set_option(be.OPT_EXCHANGE, 1 if args.exchange == "neighbour" else 0)
+                exchange["exchange"] = args.exchange
+        # the one-launch PCG on every rank, the ranks' kernels exchanging through mailboxes in each other's HBM
+        # (femcy.h "Persistent PCG across ranks"): blobs all-gathered here, the path agreed collectively; a rank on
+        # which a step fails still takes part in the agreement (with a "no")
+        pmulti = {"enabled": False, "mailbox_round_trip_us": None}
+        if hasattr(ctx, "comm_mailbox_export") and os.environ.get("FEMCY_BENCH_PERSIST_MULTI", "1") != "0":
+            try:                                                 # export may fail on ONE rank: it still joins the
+                blob = ctx.comm_mailbox_export()                 # all-gather below (with None), or the others hang in it
+            except Exception as e:                               # noqa: BLE001
+                log(f"[bench] rank {rank}: mailbox export failed ({e})")
+                blob = None
+            imported = 0
+            try:
+                with Watchdog(args.comm_timeout, "mailbox exchange"):
+                    blobs = [None] * N
+                    if env.use_dist:
+                        dist.all_gather_object(blobs, blob)
+                    else:
+                        blobs = [blob]
+                    if any(b is None for b in blobs):
+                        raise RuntimeError(f"no mailbox on rank(s) {[i for i, b in enumerate(blobs) if b is None]}")
+                    ctx.comm_mailbox_import(blobs)
+                    imported = 1
+            except Exception as e:                               # noqa: BLE001
+                log(f"[bench] rank {rank}: mailbox set-up failed ({e}); this rank votes for the RCCL loop")
+                ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            with Watchdog(args.comm_timeout, "femcy_comm_persist_agree"):
+                pmulti["enabled"] = bool(ctx.comm_persist_agree())
+            pmulti["agreed"] = pmulti["enabled"]
+            # the mailbox round trip between the ranks' kernels (xGMI latency + skew), measured by the solver's own
+            # cross-rank reduction in a one-wave kernel per rank; collective, so only if EVERY rank imported
+            if env.agree_min(imported) and hasattr(ctx, "probe_mailbox"):
+                try:
+                    with Watchdog(args.comm_timeout, "mailbox probe"):
+                        env.barrier()
+                        ok, us = 1, ctx.probe_mailbox(2000)
+                except be.FemcyError as e:
+                    log(f"[bench] rank {rank}: mailbox probe failed ({e})")
+                    ok, us = 0, None
+                if env.agree_min(ok):
+                    pmulti["mailbox_round_trip_us"] = us
+        try:
+            _, nranks_seen, _ = ctx.comm_info() if hasattr(ctx, "comm_info") else (None, N, None)
+        except Exception:                                        # noqa: BLE001
+            nranks_seen = None
+        exchange["communicator_ranks"] = nranks_seen
+
+    ctx.upload(be.VEC_DOF, u)
+    ctx.vector(be.VEC_RHS).fill(0.0)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)           # multi-rank: already summed over the interface
+    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)           # Newton residual = f_int - rhs
+    cons_set = ctx.dofset(cons)            # device-resident *Boundary DOF list (what System_of_equations uses)
+
+    def step(iters=None):
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
+        return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters or args.iters)
+
+    # --exchange auto, second half: femcy_comm_tune compared the bare exchanges (and cross-checked their sums); what
+    # counts is the whole iteration -- the send/recv form splits the product and adds launches, the all-reduce form
+    # moves the whole interface vector through every rank -- so one untimed step is run with each, the maximum over the
+    # ranks is taken, and every rank keeps the faster form.
+    def timed_step_all_ranks(iters=None):
+        env.barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        step(iters)
+        ctx.sync()
+        return env.agreed_elapsed(t0)
+
+    if use_comm and args.exchange == "auto" and exchange.get("tune") != "failed" \
+            and exchange.get("neighbour_us") is not None and exchange["neighbour_us"] >= 0:
+        trial = {}
+        if pmulti and pmulti["enabled"]:
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)          # the trial is about the loop that uses the exchange
+        with Watchdog(2 * args.comm_timeout, "exchange trial steps"):
+            for name, code in (("allreduce", 0), ("neighbour", 1)):
+                ctx.set_option(be.OPT_EXCHANGE, code)
+                step(100)                                        # connections, split lists, clocks
+                trial[name] = min(timed_step_all_ranks(100), timed_step_all_ranks(100))
+        pick = "neighbour" if trial["neighbour"] < trial["allreduce"] else "allreduce"
+        ctx.set_option(be.OPT_EXCHANGE, 1 if pick == "neighbour" else 0)
+        exchange["exchange"] = pick
+        exchange["step_ms_100_iterations"] = {k: v * 1e3 for k, v in trial.items()}
+        if pmulti and pmulti["enabled"]:
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 1)
+
+    # persistent PCG across ranks, second half: one short solve with it and one with the three-launch + collective loop
+    # must give the same numbers (the scalars are global: every rank sees the same ones); otherwise every rank keeps
+    # the loop.  A solve that times out anywhere falls back everywhere by itself.
+    if use_comm and pmulti and pmulti["enabled"]:
+        with Watchdog(2 * args.comm_timeout, "persistent multi-rank PCG cross-check"):
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            ref3 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 1)
+            t_before = ctx.timing()
+            got = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
+            t_after = ctx.timing()
+        took = t_after["solves_persist"] > t_before["solves_persist"]
+        same = got[0] == ref3[0] and abs(got[2] - ref3[2]) <= 1e-8 * abs(ref3[2])
+        verdict = env.agree_min(1 if (took and same) else 0)
+        pmulti.update(took_persistent_path=bool(took), matches_three_launch_loop=bool(same), enabled=bool(verdict))
+        if not verdict:
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            log(f"[bench] rank {rank}: persistent multi-rank PCG not used (took {took}, same {same}): RCCL loop")
+
+    # both multi-rank PCG paths, timed back to back (solves of 100 iterations, best of three, maximum over the ranks):
+    # whatever the run ends up using, the record holds the price of the other one too
+    if use_comm and pmulti is not None:
+        paths = {}
+        with Watchdog(4 * args.comm_timeout, "timing of the multi-rank PCG paths"):
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
+            for name, flag in (("persistent_across_ranks", 1), ("three_launches_plus_collectives", 0)):
+                if flag and not pmulti["enabled"]:
+                    paths[name] = None
+                    continue
+                ctx.set_option(be.OPT_PCG_PERSIST_MULTI, flag)
+                best = None
+                for rep in range(4):
+                    env.barrier()
+                    ctx.sync()
+                    t1 = time.perf_counter()
+                    it = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)[0]
+                    ctx.sync()
+                    dt = env.agreed_elapsed(t1) / max(it, 1) * 1e6
+                    if rep:                                      # the first solve of a path warms it up
+                        best = dt if best is None else min(best, dt)
+                paths[name] = best
+            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 1 if pmulti["enabled"] else 0)
+        pmulti["us_per_iteration"] = paths
+    return {"ctx": ctx, "info": info, "exchange": exchange, "pmulti": pmulti, "ne_global": ne_global, "n_global": n_global,
+            "step": step, "cons_set": cons_set, "cells": cells}
+
+
+def strong_scaling_record(env, element, material_cls, iters=300):
+    """BASELINE's metric reads "1M C3D4 elems, 1/2/4/8 GPU": the SAME 995 328-element plate cut into N z-slabs (strong
+    scaling), measured after the weak-scaling headline of a multi-GPU run: CG iterations / s of whole solves of
+    `iters` iterations with the path the ranks agreed on, both paths' microseconds per iteration, the mailbox probe"""
+    t0 = time.time()
+    cells = env.meshgen.scaling_cells(1)
+    if os.environ.get("FEMCY_BENCH_STRONG_CELLS"):               # debug / CPU tests: a small plate instead
+        cells = tuple(int(v) for v in os.environ["FEMCY_BENCH_STRONG_CELLS"].split(","))
+    prob = rank_problem(env, cells, False, True, element, material_cls)
+    ctx, be = prob["ctx"], env.be
+    try:
+        prob["step"](iters)
+        best = None
+        for _ in range(3):
+            env.barrier()
+            ctx.sync()
+            t1 = time.perf_counter()
+            it = prob["step"](iters)[0]
+            ctx.sync()
+            dt = env.agreed_elapsed(t1)
+            best = dt if best is None else min(best, dt)
+        tm = ctx.timing()
+        return {"workload": f"twist plate C3D4 {cells[0]}x{cells[1]}x{cells[2]} cells, {prob['ne_global']} elements cut into "
+                            f"{env.N} z-slabs (BASELINE's 1 M mesh on {env.N} GPUs)",
+                "scaling": "strong", "n_gpus": env.N, "elements_per_gpu": int(ctx.ne), "dof_per_gpu": int(ctx.n),
+                "cg_iters_per_step": iters, "value": it / best, "unit": "CG iters/s (assembly + Dirichlet + solve)",
+                "ms_per_step": best * 1e3, "interface_exchange": prob["exchange"],
+                "persistent_pcg_across_ranks": prob["pmulti"],
+                "solves_persist": int(tm["solves_persist"]), "solves_three": int(tm["solves_three"]),
+                "barrier_timeouts": int(tm["barrier_timeouts"]), "wall_s": time.time() - t0}
+    finally:
+        ctx.close()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=500, help="PCG iterations per step")
+    ap.add_argument("--iters", type=int, default=1000,
+                    help="PCG iterations per step (the reference's own solve of this system -- eps = 1e-3 -- takes 891)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the contract's line): 995 328 elements per GPU; strong: BASELINE's 1 M-element "
+                         "plate cut into N z-slabs.  A weak run on N > 1 GPUs appends a short strong-scaling record "
+                         "(`strong_scaling`) unless --no-strong")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, --scaling weak: skip the appended strong-scaling record")
     ap.add_argument("--workload", choices=("c3d4", "c3d10"), default="c3d4",
                     help="c3d4 = BASELINE configs[2]/[3] (the metric's configuration); c3d10 = configs[4], single GPU")
     ap.add_argument("--sample", type=int, default=16, help="time every k-th SpMV launch with HIP events (1 = all)")
@@ -358,36 +637,16 @@ def main():
             else:
                 dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
     # ------------------------------------------------------------------ problem (deterministic, O(local) per rank)
     t0 = time.time()
+    strong = args.scaling == "strong"
     if args.cells:
         nx, ny, nz = tuple(int(v) for v in args.cells.split(","))
     else:
-        nx, ny, nz = (48, 6, 72) if quadratic else meshgen.scaling_cells(N)
+        nx, ny, nz = (48, 6, 72) if quadratic else (meshgen.scaling_cells(1) if strong else meshgen.scaling_cells(N))
     use_comm = N > 1 or args.force_comm
-    elastic = (2.0e11, 0.3)
-    if use_comm:
-        if nz % N == 0:
-            part = partition.plate_slab_part(nx, ny, nz, N, rank)      # this rank's cell layers only
-        else:                                                          # odd debug grids: cut the global mesh
-            g = meshgen.twist_plate(nx, ny, nz)
-            part = partition.build_part(g["nodes"], g["elements"], N, rank)
-        nodes, el = part.nodes, part.elements
-        bcs, _ = meshgen.twist_plate_bcs(nodes)
-        ne_global, n_global = 6 * nx * ny * nz, 3 * (nx + 1) * (ny + 1) * (nz + 1)
-    else:
-        part = None
-        # FEMCY_BENCH_RENUM=1 numbers the mid-side nodes of the C3D10 plate next to the corners they connect instead of
-        # behind all corners (measured in this bench: PCG iteration -4 %, row-centric assembly +50 %; default off)
-        mesh = meshgen.twist_plate(nx, ny, nz, quadratic=quadratic,
-                                   renumber=quadratic and os.environ.get("FEMCY_BENCH_RENUM", "0") == "1")
-        nodes, el, bcs, elastic = mesh["nodes"], mesh["elements"], mesh["dirichlet_bc_info"], mesh["elastic"]
-        ne_global, n_global = el.shape[0], nodes.size
-    u, cons = s1_state(nodes, bcs, user_dirichletBC_values)
+    env = RankEnv(args=args, N=N, rank=rank, local_rank=local_rank, use_dist=use_dist, on_gpu=on_gpu, dist=dist, torch=torch,
+                  be=be, meshgen=meshgen, partition=partition, user_values=user_dirichletBC_values)
 
     # ------------------------------------------------------------------ CPU baseline leg (rank 0, N = 1 only), FIRST:
     # it is host work (20-40 s); running it before the device leg keeps the GPU-busy part of the command contiguous
@@ -398,148 +657,15 @@ def main():
         except Exception as e:   # the checker must never take the GPU number down with it
             log(f"[bench] cpu_baseline failed: {e!r}")
 
-    ctx = be.Context(local_rank)
-    if os.environ.get("FEMCY_BENCH_SIGMA"):                 # tuning knob: SELL sorting window
-        ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
-    if os.environ.get("FEMCY_BENCH_PERSIST"):               # 0 = the three-kernel PCG loop (comparison records)
-        ctx.set_option(be.OPT_PCG_PERSIST, int(os.environ["FEMCY_BENCH_PERSIST"]))
-    if os.environ.get("FEMCY_BENCH_VARIANT"):               # persistent PCG variant bits (comparison records)
-        ctx.set_option(be.TUNE_PERSIST_VARIANT, int(os.environ["FEMCY_BENCH_VARIANT"]))
-    ctx.set_mesh(nodes, el)
-    ctx.set_element(Element_quadratic_tetrahedral() if quadratic else Element_linear_tetrahedral())
-    ctx.set_material(LinearIsotropic(*elastic))
-    info = ctx.build_pattern()
-    if use_comm:
-        uid = [be.Context.comm_unique_id() if rank == 0 else None]
-        if use_dist:
-            dist.broadcast_object_list(uid, src=0)
-        with Watchdog(args.comm_timeout, "femcy_comm_init (RCCL communicator)"):
-            ctx.comm_init(rank, N, uid[0], part.iface_local_dofs, part.iface_global_slot, part.niface_global, part.owner)
-        # interface exchange: measure the packed all-reduce against send/recv with the slab neighbours and keep the
-        # faster one (all ranks decide alike from the maximum over the ranks); --exchange pins it
-        exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None}
-        if hasattr(ctx, "comm_set_neighbours"):
-            ctx.comm_set_neighbours(part)
-            if args.exchange == "auto":
-                try:
-                    with Watchdog(args.comm_timeout, "femcy_comm_tune"):
-                        exchange = ctx.comm_tune(20)
-                    failed = 0
-                except be.FemcyError as e:                  # the send/recv form is the newer one: never let it take the
-                    log(f"[bench] rank {rank}: comm_tune failed ({e}); using the all-reduce exchange")     # run down
-                    failed = 1
-                if use_dist:                                # every rank must run the same exchange
-                    flag = torch.tensor([failed], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                    failed = int(flag.item())
-                if failed:
-                    ctx.set_option(be.OPT_EXCHANGE, 0)
-                    exchange = {"exchange": "allreduce", "allreduce_us": None, "neighbour_us": None, "tune": "failed"}
-            else:
-                ctx.set_option(be.OPT_EXCHANGE, 1 if args.exchange == "neighbour" else 0)
-                exchange["exchange"] = args.exchange
-        # the one-launch PCG on every rank, the ranks' kernels exchanging through mailboxes in each other's HBM
-        # (femcy.h "Persistent PCG across ranks"): blobs all-gathered here, the path agreed collectively; a rank on
-        # which a step fails still takes part in the agreement (with a "no")
-        pmulti = {"enabled": False}
-        if hasattr(ctx, "comm_mailbox_export") and os.environ.get("FEMCY_BENCH_PERSIST_MULTI", "1") != "0":
-            try:                                                 # export may fail on ONE rank: it still joins the
-                blob = ctx.comm_mailbox_export()                 # all-gather below (with None), or the others hang in it
-            except Exception as e:                               # noqa: BLE001
-                log(f"[bench] rank {rank}: mailbox export failed ({e})")
-                blob = None
-            try:
-                with Watchdog(args.comm_timeout, "mailbox exchange"):
-                    blobs = [None] * N
-                    if use_dist:
-                        dist.all_gather_object(blobs, blob)
-                    else:
-                        blobs = [blob]
-                    if any(b is None for b in blobs):
-                        raise RuntimeError(f"no mailbox on rank(s) {[i for i, b in enumerate(blobs) if b is None]}")
-                    ctx.comm_mailbox_import(blobs)
-            except Exception as e:                               # noqa: BLE001
-                log(f"[bench] rank {rank}: mailbox set-up failed ({e}); this rank votes for the RCCL loop")
-                ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
-            with Watchdog(args.comm_timeout, "femcy_comm_persist_agree"):
-                pmulti["enabled"] = bool(ctx.comm_persist_agree())
-    else:
-        exchange = None
-        pmulti = None
+    prob = rank_problem(env, (nx, ny, nz), quadratic, use_comm,
+                        Element_quadratic_tetrahedral() if quadratic else Element_linear_tetrahedral(), LinearIsotropic)
+    ctx, info, exchange, pmulti = prob["ctx"], prob["info"], prob["exchange"], prob["pmulti"]
+    ne_global, n_global, step, cons_set = prob["ne_global"], prob["n_global"], prob["step"], prob["cons_set"]
+    barrier, agreed_elapsed = env.barrier, env.agreed_elapsed
     n, ne = ctx.n, ctx.ne
     if rank == 0:
         log(f"[bench] {args.workload} cells {nx}x{ny}x{nz}: {ne_global} elements / {n_global} DOF global, {ne} elements "
             f"/ {n} DOF per rank, nnzb {info.nnzb}, setup {time.time()-t0:.1f}s")
-
-    ctx.upload(be.VEC_DOF, u)
-    ctx.vector(be.VEC_RHS).fill(0.0)
-    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)           # multi-rank: already summed over the interface
-    ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)           # Newton residual = f_int - rhs
-
-    cons_set = ctx.dofset(cons)            # device-resident *Boundary DOF list (what System_of_equations uses)
-
-    def step():
-        ctx.assemble_K(be.VEC_DOF)
-        ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
-        return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
-
-    def agreed_elapsed(t0):
-        dt = time.perf_counter() - t0
-        if use_dist:
-            box = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(box, op=dist.ReduceOp.MAX)
-            dt = float(box.item())
-        return dt
-
-    # --exchange auto, second half: femcy_comm_tune compared the bare exchanges (and cross-checked their sums); what
-    # counts is the whole iteration -- the send/recv form splits the product and adds launches, the all-reduce form
-    # moves the whole interface vector through every rank -- so one untimed step is run with each, the maximum over the
-    # ranks is taken, and every rank keeps the faster form.
-    def timed_step_all_ranks():
-        barrier()
-        ctx.sync()
-        t0 = time.perf_counter()
-        step()
-        ctx.sync()
-        return agreed_elapsed(t0)
-
-    if use_comm and args.exchange == "auto" and exchange is not None and exchange.get("tune") != "failed" \
-            and exchange.get("neighbour_us") is not None and exchange["neighbour_us"] >= 0:
-        trial = {}
-        with Watchdog(2 * args.comm_timeout, "exchange trial steps"):
-            for name, code in (("allreduce", 0), ("neighbour", 1)):
-                ctx.set_option(be.OPT_EXCHANGE, code)
-                step()                                           # connections, split lists, clocks
-                trial[name] = min(timed_step_all_ranks(), timed_step_all_ranks())
-        pick = "neighbour" if trial["neighbour"] < trial["allreduce"] else "allreduce"
-        ctx.set_option(be.OPT_EXCHANGE, 1 if pick == "neighbour" else 0)
-        exchange["exchange"] = pick
-        exchange["step_ms"] = {k: v * 1e3 for k, v in trial.items()}
-
-    # persistent PCG across ranks, second half: one short solve with it and one with the three-launch + collective loop
-    # must give the same numbers (the scalars are global: every rank sees the same ones); otherwise every rank keeps
-    # the loop.  A solve that times out anywhere falls back everywhere by itself (and stays there).
-    if use_comm and pmulti and pmulti["enabled"]:
-        with Watchdog(2 * args.comm_timeout, "persistent multi-rank PCG cross-check"):
-            ctx.assemble_K(be.VEC_DOF)
-            ctx.dofset_dirichlet_newton(cons_set, be.VEC_RESIDUAL)
-            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
-            ref3 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
-            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 1)
-            t_before = ctx.timing()
-            got = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=25)
-            t_after = ctx.timing()
-        took = t_after["solves_persist"] > t_before["solves_persist"]
-        same = got[0] == ref3[0] and abs(got[2] - ref3[2]) <= 1e-8 * abs(ref3[2])
-        verdict = 1 if (took and same) else 0
-        if use_dist:
-            box = torch.tensor([verdict], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(box, op=dist.ReduceOp.MIN)
-            verdict = int(box.item())
-        pmulti.update(took_persistent_path=bool(took), matches_three_launch_loop=bool(same), enabled=bool(verdict))
-        if not verdict:
-            ctx.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
-            log(f"[bench] rank {rank}: persistent multi-rank PCG not used (took {took}, same {same}): RCCL loop")
 
     # untimed pre-warm on top of the W warmup steps: a fresh box needs ~1 s of load before the GPU sits at its
     # sustained clocks (first bench of a cold box measured 4-6 % low with 2 warmup steps = 46 ms of work), and an
@@ -613,10 +739,11 @@ def main():
 
     asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
     per_gpu = ELEMS_PER_GPU[args.workload]
-    scale = ne_global / per_gpu
+    scale = ne_global / per_gpu                                       # weak: N; strong (one 1 M mesh for all N): 1
     kflop_per_elem = 57.0 if quadratic else 2.9                       # as-written dense contraction
     etype = "C3D10" if quadratic else "C3D4"
-    which = ("BASELINE configs[4]" if quadratic else "BASELINE configs[2] at N=1, configs[3] at N=8")
+    which = ("BASELINE configs[4]" if quadratic else
+             ("BASELINE configs[2], cut into N slabs" if strong else "BASELINE configs[2] at N=1, configs[3] at N=8"))
 
     result = {
         "metric": "CG iters/sec + element-stiffness assemblies/sec, 1M C3D4 elems, 1/2/4/8 GPU",
@@ -624,13 +751,14 @@ def main():
         "unit": f"CG iters/s x (global elements / {per_gpu})",
         "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"twist plate {etype} {nx}x{ny}x{nz} cells, {ne_global} elements, {n_global} DOF "
                                f"({which}), state S1 (t=0.05), "
                                f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
                    "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters,
-                   "parallelism": f"element z-slabs x{N}, slab-local mesh generation" if N > 1 else "single GPU",
+                   "parallelism": (f"element z-slabs x{N}, slab-local mesh generation" +
+                                   (" (strong scaling: the 1 M mesh cut into N)" if strong else "")) if N > 1 else "single GPU",
                    "launcher": "self-launched torch.distributed.run" if os.environ.get("FEMCY_BENCH_SELF_LAUNCHED") else
                                ("torch.distributed.run" if world_env is not None else "single process"),
                    "interface_exchange": exchange, "persistent_pcg_across_ranks": pmulti},
@@ -646,7 +774,25 @@ def main():
     }
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu
+        if isinstance(cpu, dict) and isinstance(cpu.get("host_backend"), dict):     # scalars survive flattening parsers
+            for k, v in cpu["host_backend"].items():
+                if isinstance(v, (int, float)):
+                    cpu[f"host_backend_{k}"] = v
     ctx.close()
+
+    # ------------------------------------------------------------------ strong scaling beside the weak-scaling line:
+    # BASELINE's metric names ONE mesh ("1M C3D4 elems") on 1 / 2 / 4 / 8 GPUs
+    if use_comm and not strong and not args.no_strong and not quadratic and \
+            (not args.cells or os.environ.get("FEMCY_BENCH_STRONG_CELLS")):
+        try:
+            rec = strong_scaling_record(env, Element_linear_tetrahedral(), LinearIsotropic)
+        except Exception as e:                                   # noqa: BLE001  (never lose the headline line)
+            log(f"[bench] rank {rank}: strong-scaling record failed: {e!r}")
+            rec = {"error": repr(e)}
+        # a failure on ANY rank voids the record (the others may have timed a fallback path)
+        if env.agree_max(1 if "error" in rec else 0) and "error" not in rec:
+            rec = {"error": "failed on another rank"}
+        result["strong_scaling"] = rec
 
     # ------------------------------------------------------------------ the HBM-bound configurations, same invocation
     if rank == 0 and N == 1 and on_gpu and args.hbm_bound == "auto" and not args.cells and not quadratic \
@@ -714,7 +860,11 @@ def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):
             # SURVEY.md 8d's storage-independent figure (what BASELINE's metric prices): above the HBM peak because the
             # bytes the kernel keeps on chip are counted
             "algorithmic_bytes_per_launch": int(alg_launch), "algorithmic_gbs": alg_gbs,
-            "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS, "hbm_peak": HBM_PEAK_GBS}
+            "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS, "hbm_peak": HBM_PEAK_GBS,
+            # SURVEY 8d's fraction under the name the round-3 verdict asked for: > 1 because the matrix part the kernel
+            # keeps in registers / LDS and all vectors never move, and the rest streams from the Infinity Cache -- NOT
+            # an HBM-bandwidth claim (the HBM-bound fractions are in `hbm_bound`)
+            "frac_8d_vs_hbm": alg_gbs / HBM_PEAK_GBS, "frac_8d_vs_hbm_note": "cache-resident: bytes that never reach HBM are counted"}
     if peak and exch:
         stream_us = streamed / (peak * 1e9) * 1e6
         floor = stream_us + 3 * exch
@@ -722,6 +872,9 @@ def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):
                               "floor_us_per_iteration": floor, "measured_us_per_iteration": us_iter,
                               "frac": floor / us_iter,
                               "not_in_the_floor": "gathers of d, resident-row multiplies, wave / workgroup reductions, vector updates"}
+        # the same as scalar keys (nested objects did not survive into the driver's parsed record in round 3)
+        roof.update(time_model_stream_us=stream_us, time_model_exchange_us=exch, time_model_exchanges_per_iteration=3,
+                    time_model_floor_us_per_iteration=floor, time_model_frac=floor / us_iter)
     return roof
 
 

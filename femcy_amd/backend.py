@@ -67,7 +67,7 @@ EXPORTS = [
     "femcy_comm_tune", "femcy_iface_sum",
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
     "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
-    "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order",
+    "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order", "femcy_probe_mailbox",
 ]
 
 
@@ -160,7 +160,7 @@ def _bind(lib, kind):
         "femcy_persist_streamed_bytes": [p, C.POINTER(i64)],
         "femcy_comm_mailbox_export": [p, p], "femcy_comm_mailbox_import": [p, i32, p],
         "femcy_comm_shm_id": [p, i64], "femcy_comm_allgather_host": [p, p, i32, p],
-        "femcy_get_node_order": [p, C.POINTER(i32), p],
+        "femcy_get_node_order": [p, C.POINTER(i32), p], "femcy_probe_mailbox": [p, i32, C.POINTER(f64)],
         "femcy_comm_persist_agree": [p, C.POINTER(i32)],
     }
     for name, args in sig.items():
@@ -456,6 +456,12 @@ class Context:
         self._call("femcy_probe_exchange", int(rounds), int(form), C.byref(us))
         return us.value
 
+    def probe_mailbox(self, rounds: int = 2000) -> float:
+        """collective: microseconds per cross-rank mailbox reduction between the ranks' kernels"""
+        us = C.c_double()
+        self._call("femcy_probe_mailbox", int(rounds), C.byref(us))
+        return float(us.value)
+
     def persist_streamed_bytes(self) -> int:
         out = C.c_int64()
         self._call("femcy_persist_streamed_bytes", C.byref(out))
@@ -530,6 +536,12 @@ class Context:
         ng = C.c_int64()
         self._call("femcy_comm_info", None, None, C.byref(ng))
         self.n_global = int(ng.value)
+
+    def comm_info(self):
+        """(rank, ranks of the communicator, DOF count of the whole system); (0, 1, n) without a communicator"""
+        r, k, ng = C.c_int32(), C.c_int32(), C.c_int64()
+        self._call("femcy_comm_info", C.byref(r), C.byref(k), C.byref(ng))
+        return int(r.value), int(k.value), int(ng.value)
 
     def comm_set_neighbours(self, part):
         """part: a `femcy_amd.partition.Part` (nb_ranks / nb_ptr / nb_dofs)."""

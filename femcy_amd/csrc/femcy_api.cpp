@@ -1147,6 +1147,11 @@ int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* u
     FEMCY_REQUIRE(us_per_exchange, "null output");
     return probe_exchange(c, rounds, form, us_per_exchange);
 }
+int femcy_probe_mailbox(femcy_ctx* ctx, int32_t rounds, double* us_per_round) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(us_per_round, "null output");
+    return probe_mailbox(c, rounds, us_per_round);
+}
 int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes) {
     CTX_OR_FAIL(ctx);
     FEMCY_REQUIRE(bytes, "null output");

@@ -1000,6 +1000,24 @@ __global__ void __launch_bounds__(PBS) k_probe_exchange(PersistPcg a, int rounds
     }
 }
 
+// one cross-rank reduction of the persistent multi-rank PCG, repeated: a single wave per rank writes its value into
+// every rank's mailbox and polls its own (xrank_reduce, the code the solver runs) -- the mailbox round trip between
+// the ranks' kernels, link latency and skew included.  out[0] = sum of the reduced values, out[1] = -1 on a time-out
+__global__ void __launch_bounds__(64) k_probe_mailbox(PersistPcg a, int rounds, double* __restrict__ out) {
+    double acc = 0.0;
+    bool ok = true;
+    for (int r = 0; r < rounds && ok; ++r) {
+        double val[1] = {(double)(a.rank + 1)};
+        const int op[1] = {0};
+        ok = xrank_reduce<1>(a, MB_SA, r & 1, mb_tag(a.tagbase, r), val, op);
+        acc += val[0];
+    }
+    if (threadIdx.x == 0) {
+        out[0] = acc;
+        out[1] = ok ? 0.0 : -1.0;
+    }
+}
+
 int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
     const int64_t need = 3 * npad + 2 * G + 4 * G + 8 * G + 160;  // d (<= 3 buffers) + partials + granules (4 G x 16 B) + counters
     if (!c->d_persist || c->persist_cap < need) {
@@ -1062,10 +1080,14 @@ bool persist_pattern_fits(Ctx* c) {
     for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
     if (maxrange > 4 * nwx || c->dm != 3) return false;          // (the multi-rank kernel is instantiated for 3 x 3 blocks)
     if (c->opt_persist >= 2) return true;
-    // the single-rank rules of pcg_persist_solve, evaluated here once so that every rank applies the same verdict: the
-    // chip is filled 1.5 times over, and the streamed part of the matrix fits the Infinity Cache
-    if (c->nslices < G + G / 2) return false;
-    return persist_streamed_bytes(c) <= c->persist_max_bytes;
+    // evaluated here once so that every rank applies the same verdict: the streamed part of the matrix fits the
+    // Infinity Cache.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
+    // as fast) does not apply across ranks: what the one-launch path competes with there is three launches PLUS two
+    // collectives per iteration (49 us against 32 at 1 M elements per rank; a strong-scaling slab of the 1 M plate on
+    // 8 ranks has 375 slices)
+    if (c->nslices < G / 2) return false;
+    const int64_t row_bytes = (int64_t)(c->dm * c->dm * 8 + 4) * 64;
+    return c->stored_rows * row_bytes <= c->persist_max_bytes || persist_streamed_bytes(c) <= c->persist_max_bytes;
 }
 
 // eligibility + launch; *handled = false when the system does not qualify (too small, too large, ranks not agreed)
@@ -1377,6 +1399,61 @@ int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange
     (void)hipEventDestroy(e1);
     FEMCY_HIP(hipGetLastError());
     *us_per_exchange = (us[1] - us[0]) / rounds;
+    return FEMCY_OK;
+}
+
+// collective: every rank launches the single-wave probe at the same time (the caller synchronises the ranks first);
+// us_per_round = one mailbox all-to-all + poll between the ranks' kernels
+int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round) {
+    FEMCY_REQUIRE(c->comm && c->d_mbox && c->d_peer_tab, "femcy_comm_mailbox_import must come first");
+    FEMCY_REQUIRE(c->persist_multi_local, "the mailboxes of this communicator are not usable (femcy_comm_mailbox_import)");
+    FEMCY_REQUIRE(rounds >= 1 && rounds <= (1 << 19), "probe_mailbox: rounds 1..2^19");
+    PersistPcg a{};
+    a.mbox = c->d_mbox;
+    a.peer = c->d_peer_tab;
+    a.rank = c->rank;
+    a.nranks = c->nranks;
+    a.xspin_limit = (uint32_t)std::min<uint64_t>((uint64_t)c->barrier_spin_limit * 16, 1u << 30);
+    hipEvent_t e0, e1;
+    FEMCY_HIP(hipEventCreate(&e0));
+    FEMCY_HIP(hipEventCreate(&e1));
+    double us[2] = {0, 0};
+    int rc = FEMCY_OK;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {                // rounds and 2 x rounds: the difference is launch-free
+        c->solve_serial = (c->solve_serial % 4095) + 1;
+        a.tagbase = c->solve_serial << 20;
+        const int r = rounds * (pass + 1);
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(k_probe_mailbox, dim3(1), dim3(64), 0, c->stream, a, r, c->d_part2);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FEMCY_EHIP; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        us[pass] = (double)ms * 1e3;
+        double res[2] = {0, 0};
+        if (hipMemcpy(res, c->d_part2, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = FEMCY_EHIP; break; }
+        const double want = (double)r * (c->nranks * (c->nranks + 1) / 2.0);
+        if (res[1] != 0.0 || res[0] != want) {
+            set_error("probe_mailbox: a poll timed out or a value was wrong (flag %g, sum %.17g, expected %.17g)", res[1], res[0], want);
+            rc = FEMCY_ECOMM;
+        }
+        // the ranks leave a pass together: nobody's next pass may write entries a slow rank still polls for
+        double flag = rc ? 1.0 : 0.0;
+        (void)hipMemcpy(c->d_commbuf, &flag, sizeof(double), hipMemcpyHostToDevice);
+        int rc2 = comm_allreduce_sum(c, c->d_commbuf, 1);
+        if (!rc) rc = rc2;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(&flag, c->d_commbuf, sizeof(double), hipMemcpyDeviceToHost);
+        if (!rc && flag != 0.0) {
+            set_error("probe_mailbox: failed on another rank");
+            rc = FEMCY_ECOMM;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == FEMCY_EHIP) set_error("probe_mailbox: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc) return rc;
+    *us_per_round = (us[1] - us[0]) / rounds;
     return FEMCY_OK;
 }
 

@@ -1150,6 +1150,7 @@ int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes) {
 int femcy_comm_unique_id(void*) { NO_COMM("femcy_comm_unique_id"); }
 int femcy_comm_local_id(void*) { NO_COMM("femcy_comm_local_id"); }
 int femcy_comm_shm_id(void*, int64_t) { NO_COMM("femcy_comm_shm_id"); }
+int femcy_probe_mailbox(femcy_ctx*, int32_t, double*) { NO_COMM("femcy_probe_mailbox"); }
 int femcy_comm_allgather_host(femcy_ctx*, const void*, int32_t, void*) { NO_COMM("femcy_comm_allgather_host"); }
 int femcy_comm_init(femcy_ctx*, int32_t, int32_t, const void*, int32_t, const int32_t*, const int32_t*, int32_t,
                     const uint8_t*) { NO_COMM("femcy_comm_init"); }

@@ -332,6 +332,11 @@ int femcy_timing_reset(femcy_ctx* ctx);
 int femcy_probe_stream(femcy_ctx* ctx, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass,
                        int64_t* bytes_per_pass /* nullable */);
 int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* us_per_exchange);
+/* femcy_probe_mailbox (collective, after femcy_comm_mailbox_import): one cross-rank reduction of the persistent
+ *   multi-rank PCG -- a wave per rank writes its value into every rank's mailbox and polls its own, the solver's own
+ *   code -- averaged over `rounds` inside one launch per rank: the mailbox round trip between the ranks' kernels, link
+ *   (xGMI) latency included.  The sums are checked; FEMCY_ECOMM on a time-out. */
+int femcy_probe_mailbox(femcy_ctx* ctx, int32_t rounds, double* us_per_round);
 int femcy_persist_streamed_bytes(femcy_ctx* ctx, int64_t* bytes);
 
 /* ------------------------------------------------------------------- multi-GPU (new work) */

@@ -65,6 +65,10 @@ class MockContext:
         from types import SimpleNamespace
         self.part = SimpleNamespace(iface_local_dofs=np.asarray(iface_local_dofs), iface_global_slot=np.asarray(iface_global_slot),
                                     niface_global=niface_global, owner=np.asarray(owner))
+        self.comm = (rank, nranks)
+
+    def comm_info(self):
+        return self.comm[0], self.comm[1], self.n
 
     # ---- persistent PCG across ranks: the host side of the mailbox set-up (blobs gathered, imported, agreed).  The
     # mock has no one-launch kernel, so it agrees and then reports the three-launch path: bench.py's cross-check must
@@ -196,7 +200,15 @@ def test_bench_two_ranks_on_cpu(tmp_path):
     # the mailbox set-up ran on the ranks, the agreement said yes, and the cross-check -- the mock's solves are never
     # the persistent kernel -- switched the path off again, on every rank alike
     pm = d["config"]["persistent_pcg_across_ranks"]
-    assert pm == {"enabled": False, "took_persistent_path": False, "matches_three_launch_loop": True}, pm
+    assert {k: pm[k] for k in ("enabled", "agreed", "took_persistent_path", "matches_three_launch_loop")} == \
+        {"enabled": False, "agreed": True, "took_persistent_path": False, "matches_three_launch_loop": True}, pm
+    # round 4: both multi-rank PCG paths are timed whatever the run ends up using, the communicator's rank count and
+    # the mailbox probe (absent in the mock) are part of the record
+    assert pm["us_per_iteration"]["persistent_across_ranks"] is None
+    assert pm["us_per_iteration"]["three_launches_plus_collectives"] > 0
+    assert pm["mailbox_round_trip_us"] is None
+    assert d["config"]["interface_exchange"]["communicator_ranks"] == 2
+    assert "strong_scaling" not in d                             # --cells: a debug grid has no 1 M-mesh counterpart
 
 
 # ------------------------------------------------------------------------------------------------ round 3
@@ -223,6 +235,22 @@ def test_bench_self_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["launcher"] == "self-launched torch.distributed.run"
     assert d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2
+
+
+def test_bench_appends_a_strong_scaling_record():
+    """a weak-scaling run on N > 1 ranks also cuts ONE mesh into N slabs (BASELINE: "1M C3D4 elems, 1/2/4/8 GPU") and
+    reports it under `strong_scaling`; --scaling strong makes that the headline instead"""
+    out = _self_launch({"FEMCY_BENCH_STRONG_CELLS": "4,2,8"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["scaling"] == "weak"
+    st = d["strong_scaling"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["elements_per_gpu"] == 6 * 4 * 2 * 8 // 2
+    assert st["value"] > 0 and st["persistent_pcg_across_ranks"]["us_per_iteration"]["three_launches_plus_collectives"] > 0
+    out = _self_launch({}, extra_args=("--scaling", "strong"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["scaling"] == "strong" and "strong_scaling" not in d and d["config"]["elements_per_gpu"] == 6 * 4 * 2 * 6 // 2
 
 
 def test_bench_self_launch_reports_a_failed_rank():

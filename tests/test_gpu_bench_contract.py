@@ -29,6 +29,8 @@ def test_bench_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and r["launches_timed"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "CG iters/s" and c["sample"]
+    # round 4: the host-backend point also as scalar keys (nested objects got lost in the driver's parsed record)
+    assert c["host_backend_value"] == c["host_backend"]["value"] > 0 and c["host_backend_threads"] >= 1
     assert d["value"] > 0 and d["cg_iters_per_s"] > 0 and d["assemblies_per_s"] > 0
 
 
@@ -49,6 +51,13 @@ def test_bench_c3d10_workload_and_forced_comm():
         assert d["roofline"]["bound"] == "hbm" and d["roofline"]["traffic"] is None       # non-standard --cells
         if "--force-comm" in extra:
             assert d["config"]["interface_exchange"]["exchange"] == extra[-1]
+            # round 4: a communicator run reports BOTH PCG paths, the rank count RCCL saw and the mailbox probe
+            pm = d["config"]["persistent_pcg_across_ranks"]
+            assert d["config"]["interface_exchange"]["communicator_ranks"] == 1
+            assert pm["us_per_iteration"]["three_launches_plus_collectives"] > 0
+            if pm["enabled"]:
+                assert pm["us_per_iteration"]["persistent_across_ranks"] > 0
+            assert pm["mailbox_round_trip_us"] is None or 0.0 < pm["mailbox_round_trip_us"] < 1000.0
 
 
 def test_bench_headline_workload_runs_the_persistent_pcg():
@@ -79,6 +88,11 @@ def test_bench_headline_workload_runs_the_persistent_pcg():
     assert tmod["exchanges_per_iteration"] == 3 and 0.3 < tmod["exchange_us"] < 20.0
     assert abs(tmod["floor_us_per_iteration"] - (tmod["stream_us"] + 3 * tmod["exchange_us"])) < 1e-9
     assert 0.1 < tmod["frac"] <= 1.0
+    # round 4: the same as scalar keys, and SURVEY 8d's fraction of the HBM peak under its own name (> 1 here: the
+    # bytes that never reach HBM are counted -- labelled as such)
+    assert r["time_model_floor_us_per_iteration"] == tmod["floor_us_per_iteration"] and r["time_model_frac"] == tmod["frac"]
+    assert r["time_model_exchanges_per_iteration"] == 3 and r["time_model_stream_us"] == tmod["stream_us"]
+    assert r["frac_8d_vs_hbm"] == r["algorithmic_frac_of_hbm_peak"] and "cache-resident" in r["frac_8d_vs_hbm_note"]
     assert 10.0 < r["avg_launch_us"] / 100 < 60.0                                      # us per iteration inside the launch
     assert abs(d["pcg_us_per_iter"] - r["avg_launch_us"] / 100) < 5.0                  # the solve IS that launch (+ Jacobi, copy-back)
     assert "hbm_bound" not in d
