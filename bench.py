@@ -241,13 +241,17 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         ctx.dofset_dirichlet_newton(cs, be.VEC_RESIDUAL)
         ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)          # warm: clocks, caches, lazy allocations
         spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
+        # (a) the product through the public entry point femcy_spmv (vectors in the caller's node order)
         ctx.set_option(be.OPT_TIMING, 1)
         ctx.timing_reset()
         for _ in range(spmv_reps):
             ctx.spmv(be.VEC_RESIDUAL, be.VEC_TMP0)
         tm = ctx.timing()
-        spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
-        ctx.set_option(be.OPT_TIMING, 16)
+        api_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
+        api_n = int(tm["spmv_launches"])
+        # (b) the product as the PCG runs it (round 4: vectors in storage order) -- dispatch-attached events on every
+        # 4th launch inside whole solves; this is the kernel of the path, and the figure reported as `spmv`
+        ctx.set_option(be.OPT_TIMING, 4)
         ctx.timing_reset()
         its = 0
         for _ in range(3):
@@ -256,7 +260,18 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
             its += ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)[0]
         tm = ctx.timing()
         ctx.set_option(be.OPT_TIMING, 0)
-        iter_us = tm["pcg_ms"] * 1e3 / max(its, 1)
+        spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1) if tm["spmv_launches"] else api_us
+        spmv_n = int(tm["spmv_launches"]) or api_n
+        # the sampled dispatches cost a pipeline drain each (~5 us on every 4th iteration): the iteration time comes from
+        # a second set of solves with sparse sampling
+        ctx.set_option(be.OPT_TIMING, 64)
+        ctx.timing_reset()
+        its = 0
+        for _ in range(3):
+            its += ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)[0]
+        tm2 = ctx.timing()
+        ctx.set_option(be.OPT_TIMING, 0)
+        iter_us = tm2["pcg_ms"] * 1e3 / max(its, 1)
         asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
         path = ("persistent" if tm["solves_persist"] else "three-kernel")
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
@@ -264,8 +279,9 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
         rec = {"workload": name, "elements": int(ctx.ne), "dof": int(ctx.n), "stored_matrix_mb": info.stored_blocks * 76 / 1e6,
                "pcg_path": path,
-               "spmv": {"kernel": f"k_spmv<{ctx.dm}>", "bound": "hbm", "avg_launch_us": spmv_us,
-                        "launches_timed": int(spmv_reps), "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
+               "spmv": {"kernel": f"k_spmv<{ctx.dm}> inside the PCG solves (vectors in storage order)", "bound": "hbm",
+                        "avg_launch_us": spmv_us, "launches_timed": spmv_n, "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
+                        "through_femcy_spmv_us": api_us, "through_femcy_spmv_frac": spmv_b / (api_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                         "frac_of_copy_probe": (spmv_gbs / probe) if probe else None,
                         "read_stream_probe_gbs": rprobe, "frac_of_read_stream_probe": (spmv_gbs / rprobe) if rprobe else None},
@@ -342,7 +358,15 @@ def rank_problem(env, cells, quadratic, use_comm, element, material_cls):
         ne_global, n_global = el.shape[0], nodes.size
     u, cons = s1_state(nodes, bcs, env.user_values)
 
-    ctx = be.Context(env.local_rank)
+    # FEMCY_BENCH_ALL_ON_GPU0=1 (with FEMCY_BENCH_TRANSPORT=shm, FEMCY_BENCH_DIST_BACKEND=gloo, FEMCY_BENCH_DEVICE=cpu): the N
+    # ranks of this very program as N processes on ONE GPU -- RCCL refuses that, the shared-memory transport does not --
+    # each with 1/N of the CUs' worth of persistent workgroups so that the ranks' kernels are co-resident.  Rates mean
+    # nothing then; what it exercises is every host step of a multi-GPU run plus the cross-process mailbox path
+    # (tools/r04_gpu2.sh).
+    one_gpu = os.environ.get("FEMCY_BENCH_ALL_ON_GPU0") == "1"
+    ctx = be.Context(0 if one_gpu else env.local_rank)
+    if one_gpu and N > 1:
+        ctx.set_option(107, max(8, (256 // N) // 8 * 8))        # FEMCY_TUNE_PERSIST_WGS
     for var, opt in (("FEMCY_BENCH_SIGMA", be.OPT_SELL_SIGMA),            # tuning knob: SELL sorting window
                      ("FEMCY_BENCH_PERSIST", be.OPT_PCG_PERSIST),         # 0 = the three-kernel PCG loop (comparison records)
                      ("FEMCY_BENCH_VARIANT", be.TUNE_PERSIST_VARIANT),    # persistent PCG variant bits (comparison records)
@@ -356,7 +380,10 @@ def rank_problem(env, cells, quadratic, use_comm, element, material_cls):
     info = ctx.build_pattern()
     exchange = pmulti = None
     if use_comm:
-        uid = [be.Context.comm_unique_id() if rank == 0 else None]
+        if os.environ.get("FEMCY_BENCH_TRANSPORT") == "shm":     # processes of one host, no RCCL (see above)
+            uid = [be.Context.comm_shm_id(1 << 20) if rank == 0 else None]
+        else:
+            uid = [be.Context.comm_unique_id() if rank == 0 else None]
         if env.use_dist:
             dist.broadcast_object_list(uid, src=0)
         with Watchdog(args.comm_timeout, "femcy_comm_init (RCCL communicator)"):

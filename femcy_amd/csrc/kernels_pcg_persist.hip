@@ -1003,18 +1003,24 @@ __global__ void __launch_bounds__(PBS) k_probe_exchange(PersistPcg a, int rounds
 // one cross-rank reduction of the persistent multi-rank PCG, repeated: a single wave per rank writes its value into
 // every rank's mailbox and polls its own (xrank_reduce, the code the solver runs) -- the mailbox round trip between
 // the ranks' kernels, link latency and skew included.  out[0] = sum of the reduced values, out[1] = -1 on a time-out
+// out[2] = ticks of the constant-rate wall clock (s_memrealtime) spent in rounds 1 .. rounds - 1 (round 0 absorbs the
+// skew between the ranks' launches)
 __global__ void __launch_bounds__(64) k_probe_mailbox(PersistPcg a, int rounds, double* __restrict__ out) {
     double acc = 0.0;
     bool ok = true;
+    unsigned long long t0 = 0;
     for (int r = 0; r < rounds && ok; ++r) {
+        if (r == 1) t0 = wall_clock64();
         double val[1] = {(double)(a.rank + 1)};
         const int op[1] = {0};
         ok = xrank_reduce<1>(a, MB_SA, r & 1, mb_tag(a.tagbase, r), val, op);
         acc += val[0];
     }
+    const unsigned long long t1 = wall_clock64();
     if (threadIdx.x == 0) {
         out[0] = acc;
         out[1] = ok ? 0.0 : -1.0;
+        out[2] = (double)(t1 - t0);
     }
 }
 
@@ -1414,30 +1420,25 @@ int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round) {
     a.rank = c->rank;
     a.nranks = c->nranks;
     a.xspin_limit = (uint32_t)std::min<uint64_t>((uint64_t)c->barrier_spin_limit * 16, 1u << 30);
-    hipEvent_t e0, e1;
-    FEMCY_HIP(hipEventCreate(&e0));
-    FEMCY_HIP(hipEventCreate(&e1));
-    double us[2] = {0, 0};
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
     int rc = FEMCY_OK;
-    for (int pass = 0; pass < 2 && !rc; ++pass) {                // rounds and 2 x rounds: the difference is launch-free
+    double ticks = 0.0;
+    {
         c->solve_serial = (c->solve_serial % 4095) + 1;
         a.tagbase = c->solve_serial << 20;
-        const int r = rounds * (pass + 1);
-        (void)hipEventRecord(e0, c->stream);
+        const int r = rounds + 1;                                // round 0 is not timed (launch skew between the ranks)
         hipLaunchKernelGGL(k_probe_mailbox, dim3(1), dim3(64), 0, c->stream, a, r, c->d_part2);
-        (void)hipEventRecord(e1, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FEMCY_EHIP; break; }
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        us[pass] = (double)ms * 1e3;
-        double res[2] = {0, 0};
-        if (hipMemcpy(res, c->d_part2, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = FEMCY_EHIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = FEMCY_EHIP;
+        double res[3] = {0, 0, 0};
+        if (!rc && hipMemcpy(res, c->d_part2, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) rc = FEMCY_EHIP;
         const double want = (double)r * (c->nranks * (c->nranks + 1) / 2.0);
-        if (res[1] != 0.0 || res[0] != want) {
+        if (!rc && (res[1] != 0.0 || res[0] != want)) {
             set_error("probe_mailbox: a poll timed out or a value was wrong (flag %g, sum %.17g, expected %.17g)", res[1], res[0], want);
             rc = FEMCY_ECOMM;
         }
-        // the ranks leave a pass together: nobody's next pass may write entries a slow rank still polls for
+        ticks = res[2];
+        // the ranks leave together: nobody's next solve may write entries a slow rank still polls for
         double flag = rc ? 1.0 : 0.0;
         (void)hipMemcpy(c->d_commbuf, &flag, sizeof(double), hipMemcpyHostToDevice);
         int rc2 = comm_allreduce_sum(c, c->d_commbuf, 1);
@@ -1449,11 +1450,9 @@ int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round) {
             rc = FEMCY_ECOMM;
         }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (rc == FEMCY_EHIP) set_error("probe_mailbox: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc) return rc;
-    *us_per_round = (us[1] - us[0]) / rounds;
+    *us_per_round = ticks / (double)khz * 1e3 / rounds;
     return FEMCY_OK;
 }
 

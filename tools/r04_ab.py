@@ -131,9 +131,46 @@ def order(wl):
         ctx.close()
 
 
+def knobs(wl):
+    """launch-shape knobs of the storage-order product inside the PCG: wavefronts per slice x workgroups per XCD x share of
+    the matrix kept on the default cache policy (per mille; -1 = the 235 MB rule)"""
+    m, quad, u, cons = problem(wl)
+    ctx, info = make_ctx(m, quad, [(be.OPT_PCG_PERSIST, 0)])
+    cs = state(ctx, u, cons)
+    spmv_b = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * ctx.n
+    iter_b = spmv_b + 88 * ctx.n
+    combos = [(0, 256, -1), (4, 512, -1), (4, 1024 // 2, 500), (2, 256, -1), (2, 512, -1), (1, 512, -1), (4, 256, 400), (4, 256, 800),
+              (0, 256, -1)]
+    for wps, cap, keep in combos:
+        try:
+            ctx.set_option(be.OPT_SPMV_VARIANT, wps)
+            ctx.set_option(101, cap)
+            ctx.set_option(110, keep)
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)
+            res = []
+            for _ in range(2):
+                ctx.set_option(be.OPT_TIMING, 4)
+                ctx.timing_reset()
+                its = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=200)[0]
+                tm = ctx.timing()
+                spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
+                ctx.set_option(be.OPT_TIMING, 64)
+                ctx.timing_reset()
+                its = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)[0]
+                tm = ctx.timing()
+                ctx.set_option(be.OPT_TIMING, 0)
+                res.append((spmv_us, tm["pcg_ms"] * 1e3 / its))
+            print(f"  {wl} wps {wps} wg/xcd {cap} keep {keep}: " + "  ".join(f"SpMV {a:6.2f} us ({spmv_b / a / 1e3 / HBM:.3f}) PCG {b:6.2f} us/it ({iter_b / b / 1e3 / HBM:.3f})" for a, b in res), flush=True)
+        except be.FemcyError as e:
+            print(f"  wps {wps} cap {cap} keep {keep}: FAILED {e}", flush=True)
+    ctx.close()
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     if what == "persist":
         persist(*(sys.argv[2:3]))
+    elif what == "knobs":
+        knobs(sys.argv[2] if len(sys.argv) > 2 else "c3d10")
     else:
         order(sys.argv[2] if len(sys.argv) > 2 else "c3d10")
