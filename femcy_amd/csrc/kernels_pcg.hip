@@ -363,10 +363,8 @@ __global__ void __launch_bounds__(BS) k_update_xr(XcdRanges er, int np1, const d
                                                   const double* __restrict__ dAd_reduced, PcgState* st,
                                                   const double2* __restrict__ Ad, const double2* __restrict__ M,
                                                   double2* __restrict__ r, const uint8_t* __restrict__ owner,
-                                                  double* __restrict__ part2, double* __restrict__ pair_out,
-                                                  unsigned int* __restrict__ ticket) {
+                                                  double* __restrict__ part2) {
     __shared__ double sm1[BS / 64], sm2[BS / 64];
-    __shared__ int s_last;
     if (st->done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->skip = 1;
         return;
@@ -442,39 +440,13 @@ __global__ void __launch_bounds__(BS) k_update_xr(XcdRanges er, int np1, const d
         }
     }
     const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
-    if (!MULTI) {
-        if (threadIdx.x == 0) {
-            part2[2 * blockIdx.x] = s;
-            part2[2 * blockIdx.x + 1] = m;
-        }
-        return;
-    }
-    // multi-rank: the rank's (r.M.r, max|r|) pair is what the collective behind this kernel carries.  The workgroup that
-    // arrives last reduces the partials of all of them -- in index order, so the result does not depend on who is
-    // last -- instead of a single-block launch of its own (4 us per iteration of the three-launch loop).  Hand-off:
-    // write-through partials, drained, one relaxed ticket per workgroup, write-through-aware loads on the reader
-    // (cdna_hip_programming.md Guideline 16, R1); the ticket re-arms itself.
     if (threadIdx.x == 0) {
-        __hip_atomic_store(part2 + 2 * blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(part2 + 2 * blockIdx.x + 1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev + 1 == gridDim.x;
+        part2[2 * blockIdx.x] = s;
+        part2[2 * blockIdx.x + 1] = m;
     }
-    __syncthreads();
-    if (!s_last) return;
-    double ps = 0.0, pm = 0.0;
-    for (int k = threadIdx.x; k < (int)gridDim.x; k += BS) {
-        ps += __hip_atomic_load(part2 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pm = fmax(pm, __hip_atomic_load(part2 + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    ps = block_sum(ps, sm1);
-    pm = block_max(pm, sm2);
-    if (threadIdx.x == 0) {
-        pair_out[0] = ps;
-        pair_out[1] = pm;
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (round 4: letting the last-arriving workgroup reduce the pairs of a multi-rank run -- write-through partials, a
+    // ticket per workgroup -- instead of the single-block launch behind this kernel was built and measured: the fan-in
+    // of 512 tickets costs more than the launch it saves, 53.2 against 49.8 us per iteration; dropped)
 }
 
 // x += alpha d (this iteration's alpha, old d), then d = M r + beta d; publish scalars and the stopping decision
@@ -1382,14 +1354,13 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
 #define FEMCY_XR(NT_, MU_)                                                                                         \
     hipLaunchKernelGGL((k_update_xr<NT_, MU_>), dim3(g), dim3(BS), 0, c->stream, er, np1, c->d_part1, dAd_red,       \
                        c->d_state, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                \
-                       (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2,                                  \
-                       multi ? c->d_commbuf + c->niface_global + 2 : (double*)nullptr,                              \
-                       multi ? reinterpret_cast<unsigned int*>(c->d_commbuf + c->niface_global + 6) : (unsigned int*)nullptr)
+                       (const uint8_t*)(multi ? c->d_owner : nullptr), c->d_part2)
         if (multi) { if (c->vec_nt) FEMCY_XR(true, true); else FEMCY_XR(false, true); }
         else       { if (c->vec_nt) FEMCY_XR(true, false); else FEMCY_XR(false, false); }
 #undef FEMCY_XR
-        if (multi) {      // the pair was reduced by the last workgroup of k_update_xr
+        if (multi) {
             double* pair = c->d_commbuf + c->niface_global + 2;
+            hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(BS), 0, c->stream, g, c->d_part2, pair);
             if ((rc = comm_allgather(c, pair, c->d_gather, 2))) return rc;
         }
 #define FEMCY_UD(NT_)                                                                              \

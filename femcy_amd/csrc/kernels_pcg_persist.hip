@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr int DD = DM * DM, NP = DD / 2;
     constexpr bool NT = (VAR & V_NT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
     constexpr bool INB = (VAR & V_INBAND) != 0;
+#ifndef FEMCY_PERSIST_OWN_DIAG
+#define FEMCY_PERSIST_OWN_DIAG 0
+#endif
+    // block row 0 of a slice is the diagonal block: its column is the lane's own d, which is in registers
+    constexpr bool OWN_DIAG = INB || (FEMCY_PERSIST_OWN_DIAG && WIDE);
     static_assert(!INB || (WIDE && A2A), "in-band validity of d is built on the storage-order, tagged-granule form");
     constexpr int NDB = INB ? 3 : 2;                             // buffers of the published d
     extern __shared__ __attribute__((aligned(16))) char lds_persist[];
@@ -625,10 +630,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                 for (int j0 = 0; j0 < RJ; j0 += RB) {
                     double xg[RB][DM];
-                    // (V_INBAND: block row 0 is the diagonal block -- its column is the lane's own d, which is at hand)
+                    // (OWN_DIAG: block row 0 is the diagonal block -- its column is the lane's own d, which is at hand)
 #define FEMCY_REG_GATHER                                                                       \
     _Pragma("unroll") for (int u = 0; u < RB; ++u) {                                          \
-        if (INB && j0 + u == 0) {                                                              \
+        if (OWN_DIAG && j0 + u == 0) {                                                         \
             _Pragma("unroll") for (int cc = 0; cc < DM; ++cc) xg[u][cc] = dd[t][cc];          \
         } else if (j0 + u < RJ) {                                                              \
             gather_d(rcl[t][j0 + u], poff, xg[u]);                                             \

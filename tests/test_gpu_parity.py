@@ -455,7 +455,9 @@ def test_pcg_single_rank_communicator(gpu_ctx_factory):
     it1, r01, rm1 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-8)
     x1 = ctx.download(be.VEC_X)
     assert it0 == it1 and r00 == r01
-    assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-12
+    # (the single-rank loop runs in storage order since round 4, the communicator loop in node order: the same
+    # recurrence with differently grouped partial sums -- 4e-11 on the converged solution)
+    assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_plate_C3D10.inp", "ellip_dense_CPS3_0d04.inp",

@@ -23,7 +23,8 @@ def main():
     ctx.set_mesh(m["nodes"], m["elements"])
     ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetrahedral())
     ctx.set_material(LinearIsotropic(*m["elastic"]))
-    for k, v in (("FEMCY_PROF_ASSEMBLY", be.OPT_ASSEMBLY), ("FEMCY_PROF_SPMV_VARIANT", be.OPT_SPMV_VARIANT)):
+    for k, v in (("FEMCY_PROF_ASSEMBLY", be.OPT_ASSEMBLY), ("FEMCY_PROF_SPMV_VARIANT", be.OPT_SPMV_VARIANT),
+                 ("FEMCY_PROF_STORAGE_ORDER", be.OPT_PCG_STORAGE_ORDER), ("FEMCY_PROF_PERSIST", be.OPT_PCG_PERSIST)):
         if os.environ.get(k):
             ctx.set_option(v, int(os.environ[k]))
     ctx.build_pattern()
