@@ -260,8 +260,19 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
             its += ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)[0]
         tm = ctx.timing()
         ctx.set_option(be.OPT_TIMING, 0)
-        spmv_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1) if tm["spmv_launches"] else api_us
-        spmv_n = int(tm["spmv_launches"]) or api_n
+        sampled_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1) if tm["spmv_launches"] else api_us
+        # (c) the same kernel, 200 launches back to back between ONE pair of HIP events (femcy_probe_spmv): launch-to-launch
+        # time = kernel + the ~1.5 us boundary.  Dispatch-attached events on single launches inside a solve read ~5 us
+        # high (the profiled packet drains the pipeline; 71.1 against 65.8 us in rocprofv3's kernel trace of the same
+        # run, profiles/r04_kernel_stats_bench_c3d10.txt), so THIS is the figure reported as `spmv`
+        spmv_us, spmv_n = sampled_us, int(tm["spmv_launches"]) or api_n
+        how = "dispatch-attached HIP events on every 4th product launch inside the PCG solves"
+        if hasattr(ctx, "probe_spmv"):
+            try:
+                spmv_us, spmv_n = min(ctx.probe_spmv(200, True) for _ in range(3)), 200
+                how = "200 launches back to back between one pair of HIP events, best of 3 (kernel + launch boundary)"
+            except be.FemcyError as e:
+                log(f"[bench] femcy_probe_spmv failed: {e}")
         # the sampled dispatches cost a pipeline drain each (~5 us on every 4th iteration): the iteration time comes from
         # a second set of solves with sparse sampling
         ctx.set_option(be.OPT_TIMING, 64)
@@ -281,6 +292,7 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
                "pcg_path": path,
                "spmv": {"kernel": f"k_spmv<{ctx.dm}> inside the PCG solves (vectors in storage order)", "bound": "hbm",
                         "avg_launch_us": spmv_us, "launches_timed": spmv_n, "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
+                        "timed_as": how, "sampled_inside_pcg_us": sampled_us,
                         "through_femcy_spmv_us": api_us, "through_femcy_spmv_frac": spmv_b / (api_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                         "frac_of_copy_probe": (spmv_gbs / probe) if probe else None,
@@ -750,6 +762,15 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "peak_source": "spec (MI355X_MICROARCH.md)",
                 "frac_of_copy_probe": (achieved / probe) if probe else None,
                 "bytes_per_launch": int(spmv_bytes), "avg_launch_us": spmv_us, "launches_timed": int(tm["spmv_launches"])}
+    if not persist and on_gpu and rank == 0 and not use_comm and hasattr(ctx, "probe_spmv"):
+        # the product launch to launch (200 back-to-back launches, one HIP event pair): see hbm_bound_record
+        try:
+            b2b = min(ctx.probe_spmv(200, os.environ.get("FEMCY_BENCH_STORAGE_ORDER", "1") != "0") for _ in range(3))
+            roof["launch_to_launch_us"] = b2b
+            roof["launch_to_launch_gbs"] = spmv_bytes / (b2b * 1e-6) / 1e9
+            roof["launch_to_launch_frac"] = roof["launch_to_launch_gbs"] / HBM_PEAK_GBS
+        except be.FemcyError as e:
+            log(f"[bench] femcy_probe_spmv failed: {e}")
     if not persist and on_gpu and rank == 0:
         rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
         roof["read_stream_probe_gbs"] = rprobe

@@ -67,7 +67,7 @@ EXPORTS = [
     "femcy_comm_tune", "femcy_iface_sum",
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
     "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
-    "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order", "femcy_probe_mailbox",
+    "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order", "femcy_probe_mailbox", "femcy_probe_spmv",
 ]
 
 
@@ -161,6 +161,7 @@ def _bind(lib, kind):
         "femcy_comm_mailbox_export": [p, p], "femcy_comm_mailbox_import": [p, i32, p],
         "femcy_comm_shm_id": [p, i64], "femcy_comm_allgather_host": [p, p, i32, p],
         "femcy_get_node_order": [p, C.POINTER(i32), p], "femcy_probe_mailbox": [p, i32, C.POINTER(f64)],
+        "femcy_probe_spmv": [p, i32, i32, C.POINTER(f64)],
         "femcy_comm_persist_agree": [p, C.POINTER(i32)],
     }
     for name, args in sig.items():
@@ -455,6 +456,12 @@ class Context:
         us = C.c_double()
         self._call("femcy_probe_exchange", int(rounds), int(form), C.byref(us))
         return us.value
+
+    def probe_spmv(self, reps: int = 100, storage_order: bool = True) -> float:
+        """microseconds from launch to launch of `reps` back-to-back products (one HIP event pair around the batch)"""
+        us = C.c_double()
+        self._call("femcy_probe_spmv", int(reps), 1 if storage_order else 0, C.byref(us))
+        return float(us.value)
 
     def probe_mailbox(self, rounds: int = 2000) -> float:
         """collective: microseconds per cross-rank mailbox reduction between the ranks' kernels"""

@@ -316,6 +316,7 @@ bool coresident(Ctx* c, const void* fn, int block, size_t lds, int grid);
 int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass, int64_t* bytes_per_pass);
 int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange);
 int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
+int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
 int64_t persist_streamed_bytes(Ctx* c);
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);

@@ -1147,6 +1147,10 @@ int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* u
     FEMCY_REQUIRE(us_per_exchange, "null output");
     return probe_exchange(c, rounds, form, us_per_exchange);
 }
+int femcy_probe_spmv(femcy_ctx* ctx, int32_t reps, int32_t storage_order, double* us_per_launch) {
+    CTX_OR_FAIL(ctx);
+    return probe_spmv(c, reps, storage_order, us_per_launch);
+}
 int femcy_probe_mailbox(femcy_ctx* ctx, int32_t rounds, double* us_per_round) {
     CTX_OR_FAIL(ctx);
     FEMCY_REQUIRE(us_per_round, "null output");

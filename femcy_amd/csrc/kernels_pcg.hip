@@ -778,6 +778,48 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
     return launch_spmv_impl(c, d_x, d_y, d_partials, nblocks_out, c->xcd, c->spmv_grid, nullptr, 0, pos_space);
 }
 
+// `reps` products back to back on the context's stream between one pair of HIP events, on the PCG's own vectors (d -> Ad)
+// in node order or in storage order: the launch-to-launch time of the product as the three-launch loop issues it,
+// kernel + the ~1.5 us boundary between dependent launches.  (Dispatch-attached events on single launches inside a
+// solve read ~5 us high: the profiled packet drains the pipeline -- round 4: 71.1 us against 65.8 us in rocprofv3's
+// kernel trace of the same run.)
+int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch) {
+    FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
+    FEMCY_REQUIRE(reps >= 1 && reps <= 100000 && us_per_launch, "probe_spmv: reps 1..1e5");
+    const bool pos = storage_order != 0;
+    if (pos) {
+        int rc = ensure_bcolp(c);
+        if (rc) return rc;
+    }
+    // x = the Jacobi vector of the last solve (any finite data does; zero after femcy_set_mesh), y = Ad; the stop flag of
+    // the last solve must not turn the launches into no-ops
+    FEMCY_HIP(hipMemsetAsync(&c->d_state->done, 0, sizeof(int32_t), c->stream));
+    hipEvent_t e0, e1;
+    FEMCY_HIP(hipEventCreate(&e0));
+    FEMCY_HIP(hipEventCreate(&e1));
+    int rc = FEMCY_OK;
+    const int keep = c->opt_timing;
+    c->opt_timing = 0;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {                // 5 warm-up launches, then the timed batch
+        const int n = pass ? reps : 5;
+        if (pass) (void)hipEventRecord(e0, c->stream);
+        for (int k = 0; k < n && !rc; ++k) rc = launch_spmv(c, c->d_M, c->d_Ad, c->d_part1, nullptr, pos);
+    }
+    c->opt_timing = keep;
+    (void)hipEventRecord(e1, c->stream);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) {
+        set_error("probe_spmv: stream synchronisation failed");
+        rc = FEMCY_EHIP;
+    }
+    float ms = 0.f;
+    if (!rc) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *us_per_launch = (double)ms * 1e3 / reps;
+    return FEMCY_OK;
+}
+
 // the slices that hold at least one interface node, then all others (ascending inside each half, so the interior
 // half keeps the spatial order the XCD ranges rely on)
 int split_prepare(Ctx* c) {

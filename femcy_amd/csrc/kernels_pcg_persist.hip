@@ -272,9 +272,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     constexpr bool NT = (VAR & V_NT) != 0, A2A = (VAR & V_A2A) != 0, WIDE = (VAR & V_WIDE) != 0;
     constexpr bool INB = (VAR & V_INBAND) != 0;
 #ifndef FEMCY_PERSIST_OWN_DIAG
-#define FEMCY_PERSIST_OWN_DIAG 0
+#define FEMCY_PERSIST_OWN_DIAG 1
 #endif
-    // block row 0 of a slice is the diagonal block: its column is the lane's own d, which is in registers
+    // block row 0 of a slice is the diagonal block: its column is the lane's own d, which is in registers -- no gather
+    // for it (round 4: 27.30 -> 27.07 us per iteration at 1 M C3D4, bit-identical iterates; profiles/r04_persist_inband.txt)
     constexpr bool OWN_DIAG = INB || (FEMCY_PERSIST_OWN_DIAG && WIDE);
     static_assert(!INB || (WIDE && A2A), "in-band validity of d is built on the storage-order, tagged-granule form");
     constexpr int NDB = INB ? 3 : 2;                             // buffers of the published d
@@ -1210,7 +1211,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
             /* the grid barrier needs all G workgroups resident; across ranks a refusal here would leave the others */ \
             /* polling, so it is reported as a failed solve: the agreement after the launch sends everybody to RCCL  */ \
             if (!coresident(c, fn, PBS, lds, G)) {                                                                    \
-                if (!multi) return FEMCY_OK;                                                                          \
+                not_resident = true;                                                                                  \
                 launched = false;                                                                                     \
                 break;                                                                                                \
             }                                                                                                         \

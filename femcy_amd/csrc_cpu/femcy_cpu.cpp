@@ -1133,6 +1133,10 @@ int femcy_probe_stream(femcy_ctx*, int64_t, int32_t, int32_t, double*, int64_t*)
     set_error("femcy_probe_stream measures a GPU: not available in the CPU backend");
     return FEMCY_EINVAL;
 }
+int femcy_probe_spmv(femcy_ctx*, int32_t, int32_t, double*) {
+    set_error("femcy_probe_spmv measures a GPU: not available in the CPU backend");
+    return FEMCY_EINVAL;
+}
 int femcy_probe_exchange(femcy_ctx*, int32_t, int32_t, double*) {
     set_error("femcy_probe_exchange measures a GPU: not available in the CPU backend");
     return FEMCY_EINVAL;

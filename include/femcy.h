@@ -332,6 +332,10 @@ int femcy_timing_reset(femcy_ctx* ctx);
 int femcy_probe_stream(femcy_ctx* ctx, int64_t bytes, int32_t reps, int32_t mode, double* us_per_pass,
                        int64_t* bytes_per_pass /* nullable */);
 int femcy_probe_exchange(femcy_ctx* ctx, int32_t rounds, int32_t form, double* us_per_exchange);
+/* femcy_probe_spmv: `reps` launches of compute_Ad back to back between ONE pair of HIP events on the context's stream, on
+ *   the PCG's own vectors, in the caller's node order (storage_order = 0) or in storage order (1, what the three-launch
+ *   PCG of a single rank runs): microseconds from launch to launch = kernel + the boundary between dependent launches. */
+int femcy_probe_spmv(femcy_ctx* ctx, int32_t reps, int32_t storage_order, double* us_per_launch);
 /* femcy_probe_mailbox (collective, after femcy_comm_mailbox_import): one cross-rank reduction of the persistent
  *   multi-rank PCG -- a wave per rank writes its value into every rank's mailbox and polls its own, the solver's own
  *   code -- averaged over `rounds` inside one launch per rank: the mailbox round trip between the ranks' kernels, link

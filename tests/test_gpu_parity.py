@@ -720,3 +720,57 @@ def test_sell_sigma_row_order_is_transparent(gpu_ctx_factory, name):
         # to the solve tolerance either way
         assert abs(it - it0) <= max(2, it0 // 50)
         assert np.linalg.norm(xs - x0) <= 2e-5 * np.linalg.norm(x0)
+
+
+# ------------------------------------------------------------------------------------------------ round 4
+@pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_plate_C3D10.inp", "ellip_CPS8.inp"])
+def test_internal_row_order_and_storage_order_are_transparent(gpu_ctx_factory, name):
+    """FEMCY_OPT_NODE_ORDER (rows sorted inside windows of a coordinate order instead of the caller's numbering;
+    1 = the measured choice, 2 + k = coordinate order k forced) and FEMCY_OPT_PCG_STORAGE_ORDER (the three-launch PCG
+    keeps its vectors in storage order) change where things are stored, never what the caller sees: K entry for entry,
+    the reference-layout export, K x, PCG iterates; vectors go in and come out in the caller's numbering"""
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    dm = inp.nodes.shape[1]
+    x = np.cos(np.arange(inp.nodes.size) * 0.3)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in inp.dirichlet_bc_info]))
+    outs = []
+    forced = (2, 3) if dm == 2 else (2, 4, 7)
+    for order, storage in [(0, 1), (0, 0), (1, 1)] + [(k, 1) for k in forced] + [(forced[-1], 0)]:
+        ctx = gpu_ctx_factory()
+        ctx.set_option(be.OPT_NODE_ORDER, order)
+        ctx.set_option(be.OPT_PCG_STORAGE_ORDER, storage)
+        ctx.set_option(be.OPT_PCG_SMALL, 0)                     # the three-launch loop is what the options act on
+        ctx.set_option(be.OPT_PCG_PERSIST, 0)
+        ctx.set_mesh(inp.nodes, el)
+        ctx.set_element(inp.ELE)
+        ctx.set_material(mat)
+        info = ctx.build_pattern()
+        used, lines = ctx.node_order()
+        if order == 0:
+            assert used == 0 and lines[0] == 0.0                # nothing evaluated
+        elif order >= 2:
+            assert used == order - 1 and lines[used] > 0.0      # forced: coordinate order k = order - 2
+        else:
+            assert lines[0] > 0.0 and (used == 0 or lines[used] < 0.9 * lines[0])
+        with pytest.raises(be.FemcyError):
+            ctx.set_option(be.OPT_NODE_ORDER, 0)                # only before the pattern exists
+        ctx.upload(be.VEC_DOF, smooth_disp(inp.nodes, 0.01))
+        ctx.assemble_K(be.VEC_DOF)
+        ij, A = ctx.get_K_ell()
+        ctx.upload(be.VEC_TMP0, x)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        ctx.upload(be.VEC_RESIDUAL, x)
+        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        r7 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=7)
+        x7 = ctx.download(be.VEC_X)
+        tm = ctx.timing()
+        assert tm["solves_three"] >= 1 and tm["solves_persist"] == 0 and tm["solves_small"] == 0
+        outs.append((ctx.get_K_bsr().tocsr(), ij, A, ctx.download(be.VEC_TMP1), r7, x7, info.nnzb))
+    K0, ij0, A0, y0, r0, x0, nnzb0 = outs[0]
+    for K, ij, A, y, r7, x7, nnzb in outs[1:]:
+        assert nnzb == nnzb0 and abs(K - K0).max() == 0.0
+        assert np.array_equal(ij, ij0) and np.array_equal(A, A0)          # the reference layout does not see the order
+        assert rel(y, y0) < 1e-14
+        assert r7[0] == r0[0] == 7 and abs(r7[2] - r0[2]) <= 1e-10 * r0[2]
+        assert np.linalg.norm(x7 - x0) <= 1e-10 * np.linalg.norm(x0)

@@ -91,3 +91,35 @@ def test_persistent_pcg_across_processes_on_one_gpu(gpu_ctx_factory, tmp_path, n
             assert np.linalg.norm(z[f"x_{multi}_conv"] - xr[gd]) <= 1e-6 * np.linalg.norm(xr)
     # every rank reports the same global scalars (replicas are bit-identical)
     assert len({json.dumps(i["res_1"]) for i in infos}) == 1
+
+
+def test_both_interface_exchanges_across_processes(gpu_ctx_factory, tmp_path):
+    """the three-launch + collective loop across 3 processes: packed all-reduce and neighbour send / recv (overlapped
+    with the interior product, and not) through the shared-memory transport give the single-context iterates;
+    femcy_comm_tune cross-checks the two forms on every rank and all ranks take the same choice"""
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    m = meshgen.twist_plate(24, 6, 96)
+    nodes, el = m["nodes"], m["elements"]
+    cons_g = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in m["dirichlet_bc_info"]]))
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(Element_linear_tetrahedral())
+    ctx.set_material(LinearIsotropic(*m["elastic"]))
+    ctx.build_pattern()
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, np.sin(np.arange(nodes.size) * 0.11) * 1e3)
+    ctx.dirichlet_newton(cons_g, be.VEC_RESIDUAL)
+    (kr, r0r, rmr), xr = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=40), ctx.download(be.VEC_X)
+    infos = launch(3, 0, "exchange", tmp_path)
+    assert len({i["tune"]["exchange"] for i in infos}) == 1                  # one decision for the whole job
+    for r, i in enumerate(infos):
+        assert i["tune"]["allreduce_us"] > 0 and i["tune"]["neighbour_us"] > 0, i["tune"]     # cross-check passed
+        assert i["counts"][0] == 0 and i["counts"][1] == 3
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        gd = (z["l2g"][:, None] * 3 + np.arange(3)[None, :]).ravel()
+        for key in ("0_1", "1_1", "1_0"):
+            kk, r0k, rmk = i[f"res_{key}"]
+            assert kk == kr and abs(r0k - r0r) <= 1e-12 * r0r and abs(rmk - rmr) <= 1e-9 * rmr
+            assert np.linalg.norm(z[f"x_{key}"] - xr[gd]) <= 1e-9 * np.linalg.norm(xr)

@@ -64,6 +64,18 @@ def main():
                 t1 = c.timing()
                 info[f"res_{multi}"] = res
                 info[f"counts_{multi}"] = [t1[k] - t0[k] for k in ("solves_persist", "solves_three", "barrier_timeouts")]
+        elif scenario == "exchange":
+            # the three-launch + collective loop with both interface exchanges (packed all-reduce; send / recv with the
+            # slab neighbours, overlapped and not), chosen by femcy_comm_tune's measurement with its cross-check
+            c.set_option(be.OPT_PCG_PERSIST_MULTI, 0)
+            info["tune"] = c.comm_tune(10)
+            for code, overlap in ((0, 1), (1, 1), (1, 0)):
+                c.set_option(be.OPT_EXCHANGE, code)
+                c.set_option(be.OPT_OVERLAP, overlap)
+                info[f"res_{code}_{overlap}"] = list(c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=40))
+                arrays[f"x_{code}_{overlap}"] = c.download(be.VEC_X)
+            t1 = c.timing()
+            info["counts"] = [t1[k] for k in ("solves_persist", "solves_three", "barrier_timeouts")]
         elif scenario == "timing":
             iters = int(os.environ.get("XPROC_ITERS", "300"))
             for multi in (1, 0):
