@@ -57,6 +57,7 @@ struct PcgState {
     int32_t it_k3;   // iteration index handed from k_update_xr to k_update_d
     int32_t done;    // 0 running, 1 converged, 2 NaN/breakdown: written by k_update_d, tested by k_spmv / k_update_xr
     int32_t skip;    // `done` as k_update_xr saw it, handed to the k_update_d of the same iteration
+    unsigned long long xround;   // launches of k_update_fused so far (its granule tag); never reset by a solve
 };
 
 // contiguous slice range of each XCD for the SpMV (balanced by stored blocks), passed by value
@@ -179,6 +180,10 @@ struct Ctx {
     int64_t persist_cap = 0;
     int32_t* d_bcolp = nullptr;       // block columns as storage positions (PCG with its vectors in storage order)
     int64_t bcolp_serial = -1;
+    int opt_fused_update = 0;         // FEMCY_OPT_PCG_FUSED_UPDATE: single-rank three-launch loop with ONE vector kernel per iteration
+                                      // (measured slower than the two kernels: default off)
+    bool fused_failed = false;        // its in-kernel exchange timed out once: two kernels from then on
+    double* d_fused = nullptr;        // granules of k_update_fused ([1024][2] x 16 B)
     int opt_pos_space = 1;            // FEMCY_OPT_PCG_STORAGE_ORDER: the three-kernel PCG of a single rank keeps r, d, M, Ad, x
                                       // in storage order (gathers of neighbouring lanes then hit neighbouring addresses)
     double* d_posb = nullptr;         // right-hand side / solution in storage order

@@ -258,7 +258,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_persist);
     dev_free(&c->d_persist_assign);
     dev_free(&c->d_bcolp);
-    dev_free(&c->d_posb); dev_free(&c->d_posx);
+    dev_free(&c->d_posb); dev_free(&c->d_posx); dev_free(&c->d_fused);
     dev_free(&c->d_probe);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
@@ -354,7 +354,8 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case FEMCY_TUNE_BARRIER_SPIN_LIMIT:
             FEMCY_REQUIRE(value >= 0 && value <= (1ll << 30), "spin limit out of range");
             c->barrier_spin_limit = (uint32_t)value;
-            c->persist_failed = c->small_failed = false;
+            c->persist_failed = c->small_failed = c->fused_failed = false;
+            if (c->d_fused) FEMCY_HIP(hipMemsetAsync(c->d_fused, 0, 1024 * 2 * 16, c->stream));
             break;
         case FEMCY_OPT_PCG_PERSIST_MULTI:
             FEMCY_REQUIRE(value == 0 || value == 1, "persistent multi-rank PCG: 0 (off) or 1 (when every rank agreed)");
@@ -419,6 +420,13 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value >= SLICE && value <= (1 << 24), "sorting window must be in [64, 2^24] nodes");
             FEMCY_REQUIRE(!c->have_pattern, "set the sorting window before femcy_build_pattern");
             c->sell_sigma = (int32_t)value;
+            break;
+        case FEMCY_OPT_PCG_FUSED_UPDATE:
+            FEMCY_REQUIRE(value == 0 || value == 1, "fused vector update: 0 (two kernels) or 1");
+            pcg_graph_reset(c);
+            c->opt_fused_update = (int)value;
+            c->fused_failed = false;
+            if (c->d_fused) FEMCY_HIP(hipMemsetAsync(c->d_fused, 0, 1024 * 2 * 16, c->stream));
             break;
         case FEMCY_OPT_PCG_STORAGE_ORDER:
             FEMCY_REQUIRE(value == 0 || value == 1, "storage-order PCG: 0 (node order) or 1");

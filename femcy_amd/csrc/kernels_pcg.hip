@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 #include "ctx.hpp"
 #include "wave_reduce.hpp"
+#include "granule.hpp"
 
 namespace femcy {
 
@@ -532,6 +533,123 @@ __global__ void __launch_bounds__(BS) k_update_d(XcdRanges er, int np2, const do
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new)
             st->done = 2;
         else if (rmax < eps * r0)
+            st->done = 1;
+    }
+}
+
+// ---- round 4: the two vector kernels of an iteration as ONE launch (single rank; FEMCY_OPT_PCG_FUSED_UPDATE, default
+// OFF: measured 1.5 us per iteration SLOWER than the two kernels on MI355X -- a kernel boundary costs ~1.5 us here, a
+// grid-wide exchange 2.6-3.3 us, and the loads the boundary lets the second kernel issue early are serialised behind
+// the exchange; profiles/r04_ab_fused_update.txt.  Kept as a tested option and as the record of that measurement).  k_update_xr and k_update_d are
+// latency-bound launches (5.6-6.7 us each for 18-26 MB) separated by a kernel boundary whose only purpose is the
+// grid-wide (r.M.r, max|r|); here that reduction is an in-kernel exchange of tagged granules (granule.hpp: one 16-byte
+// write-through store per workgroup, one wave sweeps), r and M stay in registers across it and d / x are already
+// in flight when it starts: one boundary and 16 n bytes less per iteration.  Every thread owns <= U double2 of its
+// XCD's element range.  The tag is a launch counter kept in PcgState (never reset: tags grow for the life of the
+// context), so no granule is ever re-armed; every workgroup of the launch is resident (checked by the host) and the
+// sweep is bounded -- a time-out poisons the granules, sets done = 3 and the host redoes the solve with the two
+// kernels and stays there.
+template <bool NT, int U>
+__global__ void __launch_bounds__(BS) k_update_fused(XcdRanges er, int np1, const double* __restrict__ part1, PcgState* st,
+                                                     const double2* __restrict__ Ad, const double2* __restrict__ M,
+                                                     double2* __restrict__ r, double2* __restrict__ d,
+                                                     double2* __restrict__ x, double* __restrict__ slots,
+                                                     uint32_t spin_limit) {
+    __shared__ double sm1[BS / 64], sm2[BS / 64], bc[2];
+    __shared__ int s_fail;
+    if (st->done) return;          // written by an earlier launch only: every workgroup of this one reads the same value
+    const int G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xk = blockIdx.x % NXCD;
+    const int64_t stride = (int64_t)(G / NXCD) * BS;
+    const int64_t lo = er.start[xk], hi = er.start[xk + 1];
+    const int64_t base = lo + (int64_t)(blockIdx.x / NXCD) * BS + tid;
+    if (tid == 0) s_fail = 0;
+    double pv[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int k = tid + u * BS;
+        pv[u] = part1[k < np1 ? k : MAX_PARTIALS];
+    }
+    double2 av[U], mv[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = max(lo, min(base + u * stride, hi - 1));
+        av[u] = ld2<NT>(Ad + i);
+        mv[u] = ld2<NT>(M + i);
+        rv[u] = ld2<NT>(r + i);
+    }
+    const int it = st->iters;
+    const unsigned long long tag = st->xround + 1;      // stable: written by block 0 of the previous launch at its end
+    double v = 0.0;
+#pragma unroll
+    for (int u = 0; u < PU; ++u) v += pv[u];
+    for (int k = tid + PU * BS; k < np1; k += BS) v += part1[k];
+    const double dAd = block_sum(v, sm1);
+    const double rMr_old = st->rMr[it & 1];
+    const double alpha = rMr_old / dAd;
+    double rMr = 0.0, rm = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + u * stride;
+        if (i < hi) {
+            rv[u].x = rv[u].x - alpha * av[u].x;
+            rv[u].y = rv[u].y - alpha * av[u].y;
+            st2<NT>(r + i, rv[u]);
+            rMr += rv[u].x * mv[u].x * rv[u].x + rv[u].y * mv[u].y * rv[u].y;
+            rm = fmax(rm, fmax(nan_to_inf_abs(rv[u].x), nan_to_inf_abs(rv[u].y)));
+        }
+    }
+    // d and x of this thread: requested before the exchange, used behind it (av's registers are free now)
+    double2 dv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = max(lo, min(base + u * stride, hi - 1));
+        dv[u] = ld2<NT>(d + i);
+        xv[u] = ld2<NT>(x + i);
+    }
+    const double s = block_sum(rMr, sm1), m = block_max(rm, sm2);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)slots, 0, G * 2 * 16, 0x00020000);
+    if (wave == 0) {
+        if (lane == 0) granule_store(srsrc, 2 * blockIdx.x, s, tag);
+        if (lane == 1) granule_store(srsrc, 2 * blockIdx.x + 1, m, tag);
+        double o[2];
+        const int op[2] = {0, 1};
+        const bool okx = granule_sweep<2>(srsrc, 0, G, tag, spin_limit, o, op);
+        if (!okx && lane < 2) granule_store(srsrc, 2 * blockIdx.x + lane, 0.0, TAG_POISON);
+        if (lane == 0) {
+            bc[0] = o[0];
+            bc[1] = o[1];
+            if (!okx) s_fail = 1;
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) st->done = 3;                     // every workgroup that gets here writes the same verdict
+        return;
+    }
+    const double rMr_new = bc[0], rmax = bc[1];
+    const double beta = rMr_new / rMr_old;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + u * stride;
+        if (i < hi) {
+            xv[u].x = xv[u].x + alpha * dv[u].x;
+            xv[u].y = xv[u].y + alpha * dv[u].y;
+            dv[u].x = mv[u].x * rv[u].x + beta * dv[u].x;
+            dv[u].y = mv[u].y * rv[u].y + beta * dv[u].y;
+            st2<NT>(x + i, xv[u]);
+            st2<NT>(d + i, dv[u]);
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        st->rMr[(it + 1) & 1] = rMr_new;
+        st->rmax = rmax;
+        st->alpha = alpha;
+        st->iters = it + 1;
+        st->xround = tag;
+        if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new)
+            st->done = 2;
+        else if (rmax < st->eps * st->r0)
             st->done = 1;
     }
 }
@@ -1334,6 +1452,30 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     int64_t emax = 1;
     for (int k = 0; k < NXCD; ++k) emax = std::max<int64_t>(emax, er.start[k + 1] - er.start[k]);
     const int g = NXCD * (int)std::max<int64_t>(1, std::min<int64_t>((emax + BS - 1) / BS, std::max(1, c->ew_cap / NXCD)));
+    // one vector kernel per iteration (k_update_fused) when every thread can keep its share in registers (<= 8 double2)
+    // and all workgroups are resident; otherwise -- and across ranks, where a collective sits between the two -- the
+    // two kernels
+    int fused_g = 0, fused_u = 0;
+    if (!multi && c->opt_fused_update && !c->fused_failed) {
+        const int64_t bpx_min = (emax + (int64_t)BS * 8 - 1) / ((int64_t)BS * 8);
+        const int64_t bpx = std::max<int64_t>(bpx_min, g / NXCD);
+        if (bpx <= 128) {
+            const int64_t per = (emax + bpx * BS - 1) / (bpx * BS);
+            fused_u = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
+            fused_g = (int)bpx * NXCD;
+            const void* fn = nullptr;
+#define FEMCY_FUSED_FN(NT_) (fused_u == 1 ? (const void*)&k_update_fused<NT_, 1> : fused_u == 2 ? (const void*)&k_update_fused<NT_, 2> \
+                             : fused_u == 4 ? (const void*)&k_update_fused<NT_, 4> : (const void*)&k_update_fused<NT_, 8>)
+            fn = c->vec_nt ? FEMCY_FUSED_FN(true) : FEMCY_FUSED_FN(false);
+#undef FEMCY_FUSED_FN
+            if (!coresident(c, fn, BS, 0, fused_g)) fused_g = 0;
+        }
+        if (fused_g && !c->d_fused) {
+            FEMCY_HIP(hipMalloc((void**)&c->d_fused, 1024 * 2 * 16));
+            FEMCY_HIP(hipMemsetAsync(c->d_fused, 0, 1024 * 2 * 16, c->stream));
+        }
+    }
+    const bool fused = fused_g > 0;
     hipLaunchKernelGGL(k_pcg_init, dim3(g), dim3(BS), 0, c->stream, n2, (const double2*)vb, (const double2*)c->d_M,
                        (double2*)vx, (double2*)c->d_r, (double2*)c->d_d, (const uint8_t*)(multi ? c->d_owner : nullptr),
                        c->d_part2);
@@ -1393,6 +1535,21 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
                                    c->niface_local, c->d_iface_dof, c->d_iface_slot, c->d_commbuf, c->d_Ad);
             dAd_red = slot;
         }
+        if (fused) {
+#define FEMCY_FU(NT_, U_)                                                                                          \
+    hipLaunchKernelGGL((k_update_fused<NT_, U_>), dim3(fused_g), dim3(BS), 0, c->stream, er, np1, c->d_part1, c->d_state,  \
+                       (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r, (double2*)c->d_d, (double2*)vx, \
+                       c->d_fused, c->barrier_spin_limit)
+#define FEMCY_FU_U(NT_)                                                                                            \
+    do {                                                                                                           \
+        if (fused_u == 1) FEMCY_FU(NT_, 1); else if (fused_u == 2) FEMCY_FU(NT_, 2);                               \
+        else if (fused_u == 4) FEMCY_FU(NT_, 4); else FEMCY_FU(NT_, 8);                                            \
+    } while (0)
+            if (c->vec_nt) FEMCY_FU_U(true); else FEMCY_FU_U(false);
+#undef FEMCY_FU_U
+#undef FEMCY_FU
+            return FEMCY_OK;
+        }
 #define FEMCY_XR(NT_, MU_)                                                                                         \
     hipLaunchKernelGGL((k_update_xr<NT_, MU_>), dim3(g), dim3(BS), 0, c->stream, er, np1, c->d_part1, dAd_red,       \
                        c->d_state, (const double2*)c->d_Ad, (const double2*)c->d_M, (double2*)c->d_r,                \
@@ -1420,7 +1577,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     // iteration SLOWER at 548 535 DOF (GPU-bound), so "auto" (1) only uses it below 2e5 DOF; 2 forces it on
     const bool want_graph = c->opt_graph == 2 || (c->opt_graph == 1 && c->n < 200000);
     const bool use_graph = want_graph && !multi && !c->opt_timing && maxit >= P;
-    if (use_graph && (!c->pcg_graph || c->pcg_graph_x != vx || c->pcg_graph_iters != P || c->pcg_graph_g != g ||
+    if (use_graph && (!c->pcg_graph || c->pcg_graph_x != vx || c->pcg_graph_iters != P || c->pcg_graph_g != g + 4096 * fused_g ||
                       c->pcg_graph_np1 != c->spmv_grid)) {
         pcg_graph_reset(c);
         hipGraph_t graph = nullptr;
@@ -1437,7 +1594,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         (void)hipGraphDestroy(graph);
         c->pcg_graph_x = vx;
         c->pcg_graph_iters = P;
-        c->pcg_graph_g = g;
+        c->pcg_graph_g = g + 4096 * fused_g;
         c->pcg_graph_np1 = c->spmv_grid;
     }
 
@@ -1458,6 +1615,15 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
         FEMCY_HIP(hipMemcpyAsync(c->h_state, c->d_state, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
         FEMCY_HIP(hipStreamSynchronize(c->stream));
         if (c->h_state->done || it >= maxit) finished = true;
+    }
+    if (fused && c->h_state->done == 3) {
+        // the in-kernel exchange of k_update_fused timed out (a workgroup was not resident: shared GPU, CU mask): the
+        // solve is redone with the two vector kernels, which this context keeps from now on
+        c->fused_failed = true;
+        c->timing.barrier_timeouts++;
+        pcg_graph_reset(c);
+        timing_end(c, th);
+        return pcg_solve(c, d_b, d_x, eps, maxit, iters, r0, rmax);
     }
     if (pos) {
         const int pg = (npos + BS - 1) / BS;

@@ -218,7 +218,8 @@ int build_pattern(Ctx* c) {
     c->node_order_used = 0;
     for (double& v : c->node_order_cost) v = 0.0;
     layout(nullptr, node_of, pos);
-    if (c->opt_node_order >= 1 && (int64_t)c->h_nodes.size() == (int64_t)nn * dm && nn >= 4 * SLICE) {
+    // (the measured choice needs a few full slices to measure on; a forced order is always applied)
+    if (c->opt_node_order >= 1 && (int64_t)c->h_nodes.size() == (int64_t)nn * dm && (c->opt_node_order >= 2 || nn >= 4 * SLICE)) {
         const double natural = gather_lines(node_of, pos);
         c->node_order_cost[0] = natural;
         // coordinates quantised on one common scale (21 bits per axis): grid lines of a structured mesh compare equal

@@ -113,6 +113,13 @@ enum femcy_option {
                                    storage order (b permuted once, x permuted back at the end): lanes of a wavefront are
                                    rows of one length class in ascending order, so their gathers of d touch neighbouring
                                    addresses; 0 = node order (what multi-rank runs keep)                          */
+    FEMCY_OPT_PCG_FUSED_UPDATE = 15, /* 0 (default) = two vector kernels per iteration of the three-launch PCG; 1 = ONE (r update,
+                                   the grid-wide (r.M.r, max|r|) as an in-kernel exchange of tagged granules, d and x
+                                   update; single rank, <= 8 double2 per thread at <= 1024 resident workgroups; a
+                                   time-out of the exchange falls back to the two kernels for good).  Built and measured
+                                   in round 4: the exchange (2.6-3.3 us) costs more than the kernel boundary it removes
+                                   (1.5 us) -- 80.5 -> 82.0 us per iteration on the C3D10 plate, 42.3 -> 43.8 at 1 M C3D4
+                                   (profiles/r04_ab_fused_update.txt) -- so it stays an option                    */
     FEMCY_OPT_NODE_ORDER = 14,  /* internal row order of the matrix, set before femcy_build_pattern; vectors handed
                                    to / from the caller always keep the caller's numbering.  0 = rows sorted by length
                                    inside windows of the caller's numbering; 1 = inside windows of the best of the

@@ -751,6 +751,8 @@ def test_internal_row_order_and_storage_order_are_transparent(gpu_ctx_factory, n
             assert used == 0 and lines[0] == 0.0                # nothing evaluated
         elif order >= 2:
             assert used == order - 1 and lines[used] > 0.0      # forced: coordinate order k = order - 2
+        elif inp.nodes.shape[0] < 256:
+            assert used == 0 and lines[0] == 0.0                # too few full slices to measure on: caller's numbering
         else:
             assert lines[0] > 0.0 and (used == 0 or lines[used] < 0.9 * lines[0])
         with pytest.raises(be.FemcyError):

@@ -339,3 +339,41 @@ def test_ceiling_probes(plate):
     info = ctx.pattern_info()
     sb = ctx.persist_streamed_bytes()
     assert 0 <= sb < info.stored_blocks * 76
+
+
+# ------------------------------------------------------------------------------------------------ round 4
+def test_fused_vector_update_equals_the_two_kernels_and_falls_back(plate):
+    """FEMCY_OPT_PCG_FUSED_UPDATE: the three-launch loop with ONE vector kernel per iteration (r update, in-kernel
+    exchange of (r.M.r, max|r|), d and x update) runs the same recurrence as the two kernels: iteration counts equal,
+    iterates to rounding (the reduction is grouped by workgroup in both, in a different order), bit-reproducible.  A spin
+    limit of 0 makes the exchange give up: the solve is redone by the two kernels -- same answer -- the time-out is
+    counted and the context stays on the two kernels."""
+    be, ctx, K, bb = plate["be"], plate["ctx"], plate["K"], plate["bb"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 0)
+    ctx.set_option(107, 0)
+    res = {}
+    for flag in (0, 1):
+        ctx.set_option(be.OPT_PCG_FUSED_UPDATE, flag)
+        res[flag] = [_solve(ctx, be, eps, maxit) for eps, maxit in ((0.0, 1), (0.0, 7), (0.0, 40), (1e-10, 10 ** 6))]
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(res[0][:3], res[1][:3]), (1e-13, 1e-12, 1e-10)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    (it0, _, _), x0 = res[0][3]
+    (it1, r01, rm1), x1 = res[1][3]
+    assert abs(it0 - it1) <= max(2, it0 // 50) and rm1 < 1e-10 * r01 and np.abs(K @ x1 - bb).max() < 1.2e-9 * r01
+    (it2, _, rm2), x2 = _solve(ctx, be, 1e-10, 10 ** 6)
+    assert it2 == it1 and rm2 == rm1 and np.array_equal(x2, x1)
+    # the time-out path
+    t0 = ctx.timing()
+    try:
+        ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 0)
+        (itb, r0b, rmb), xb = _solve(ctx, be, 0.0, 40)
+        (itc, _, rmc), xc = _solve(ctx, be, 0.0, 40)               # stays on the two kernels: no second time-out
+        t1 = ctx.timing()
+        assert t1["barrier_timeouts"] - t0["barrier_timeouts"] == 1 and t1["solves_three"] - t0["solves_three"] == 2
+        (it0, _, rm0), x0 = res[0][2]
+        assert itb == itc == it0 == 40 and rmb == rmc == rm0 and np.array_equal(xb, x0) and np.array_equal(xc, x0)
+    finally:
+        ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 1 << 20)
+        ctx.set_option(be.OPT_PCG_FUSED_UPDATE, 0)                 # the default (the fused form measured slower)
+        ctx.set_option(be.OPT_PCG_PERSIST, 1)
