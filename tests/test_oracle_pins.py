@@ -446,3 +446,25 @@ def test_homogeneous_deformation_pins_the_2d_large_deformation_path(etype, mkind
     assert np.abs(so - sig).max() < 1e-13 * np.abs(sig).max()
     assert np.abs(fo - f).max() < 1e-13 * np.abs(f).max()
     assert np.abs(f.reshape(-1, 2).sum(axis=0)).max() < 1e-14 * np.abs(f).max()      # self-equilibrated
+
+
+def test_plane_stress_large_deformation_force_has_no_symmetric_tangent():
+    """why the opt-in consistent tangent (FEMCY_OPT_TANGENT) does not exist for plane stress: the reference synthesises
+    F33 = 1 - nu / (1 - nu) (F00 + F11 - 2) instead of deriving it from an energy
+    (linear_isotropic_plane_stress.py:72-96), so the exact derivative of its internal force (complex step) is NOT
+    symmetric -- 5e-3 relative at 5 % strain -- and a conjugate-gradient solver cannot use it; the plane-strain law on
+    the same deck and displacement has a symmetric derivative to rounding."""
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    et = list(inp.eSets)[0]
+    params = oracle_material(list(inp.materials.values())[0]).params
+    topo = orc.Topology(inp.nodes, inp.eSets[et], elem_def(et))
+    L = np.ptp(inp.nodes, axis=0).max()
+    x = inp.nodes / L
+    u = (0.05 * L * np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]), 0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0]],
+                             axis=1)).ravel()
+    asym = {}
+    for kind in ("pstress", "pstrain"):
+        K = orc.consistent_tangent(topo, u, orc.Material(kind, params))
+        K = K.toarray() if hasattr(K, "toarray") else np.asarray(K)
+        asym[kind] = np.abs(K - K.T).max() / np.abs(K).max()
+    assert asym["pstrain"] < 1e-12 and asym["pstress"] > 1e-3, asym
