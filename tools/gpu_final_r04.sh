@@ -25,12 +25,15 @@ for n in 2 4; do
     timeout 600 python bench.py --gpus $n --cells 48,12,144 --steps 3 --warmup 1 --iters 200 --prewarm 0 --no-cpu-baseline --comm-timeout 120 \
     > $OUT/bench_shm_n$n.json 2> $OUT/bench_shm_n$n.err
 done
+# libraries built beside the shipped one (csrc/build.sh with FEMCY_EXTRA_FLAGS / FEMCY_OUT): _inbnp = -DFEMCY_INB_PREFETCH=0 (variant 14
+# without the prefetch batch), _noowndiag = -DFEMCY_PERSIST_OWN_DIAG=0 (the diagonal block's d gathered like the others)
 (timeout 300 python tools/r04_ab.py persist; FEMCY_HIP_LIB=$R/femcy_amd/libfemcy_hip_inbnp.so timeout 300 python tools/r04_ab.py persist; \
- FEMCY_HIP_LIB=$R/femcy_amd/libfemcy_hip_owndiag.so timeout 300 python tools/r04_ab.py persist) 2>&1 | grep -v amdgpu.ids > $OUT/persist_inband.txt
+ FEMCY_HIP_LIB=$R/femcy_amd/libfemcy_hip_noowndiag.so timeout 300 python tools/r04_ab.py persist) 2>&1 | grep -v "amdgpu.ids\|^+ " > $OUT/persist_inband.txt
 cat $OUT/persist_inband.txt
 (timeout 400 python tools/r04_ab.py order c3d10; timeout 400 python tools/r04_ab.py order c3d10) 2>&1 | grep -v amdgpu.ids > $OUT/ab_order_c3d10.txt
 (timeout 500 python tools/r04_ab.py order c3d4_8m; timeout 500 python tools/r04_ab.py order c3d4_8m) 2>&1 | grep -v amdgpu.ids > $OUT/ab_order_c3d4_8m.txt
 (timeout 400 python tools/r04_ab.py knobs c3d10; timeout 400 python tools/r04_ab.py knobs c3d4_8m) 2>&1 | grep -v amdgpu.ids > $OUT/spmv_knobs.txt
+(for wl in c3d10 c3d4 c3d4_8m; do timeout 400 python tools/r04_ab.py fused $wl; done) 2>&1 | grep -v amdgpu.ids > $OUT/ab_fused.txt
 (timeout 300 python tools/microbench.py 12; timeout 300 python tools/microbench.py 6 1) 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/microbench.txt
 cd /tmp
 for wl in c3d4 c3d10; do
