@@ -891,7 +891,10 @@ def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):
     if hasattr(ctx, "probe_stream") and streamed > 0:
         try:
             peak = max(ctx.probe_stream(max(streamed, 1 << 20), 30, 0)[0] for _ in range(3))
-            form = 1 if (variant >= 0 and (variant & 2)) else int(os.environ.get("FEMCY_BENCH_EXCHANGE_FORM", "0"))
+            # the exchange form the kernel uses: tagged granules (form 1) for the library's default variant (6) and every
+            # variant with bit 1; per-XCD counters + data (form 0) otherwise
+            eff = variant if variant >= 0 else 6
+            form = int(os.environ.get("FEMCY_BENCH_EXCHANGE_FORM", "1" if (eff & 2) else "0"))
             exch = min(ctx.probe_exchange(2000, form) for _ in range(3))
         except be.FemcyError as e:
             log(f"[bench] ceiling probes failed: {e}")
@@ -919,6 +922,7 @@ def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):
         roof["time_model"] = {"stream_us": stream_us, "exchange_us": exch, "exchanges_per_iteration": 3,
                               "floor_us_per_iteration": floor, "measured_us_per_iteration": us_iter,
                               "frac": floor / us_iter,
+                              "exchange_form": "tagged granules" if form == 1 else "per-XCD counters + data",
                               "not_in_the_floor": "gathers of d, resident-row multiplies, wave / workgroup reductions, vector updates"}
         # the same as scalar keys (nested objects did not survive into the driver's parsed record in round 3)
         roof.update(time_model_stream_us=stream_us, time_model_exchange_us=exch, time_model_exchanges_per_iteration=3,

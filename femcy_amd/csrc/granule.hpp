@@ -35,6 +35,9 @@ __device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, i
                                               uint32_t spin_limit, double (&out)[NV], const int (&op)[NV]) {
     const int lane = threadIdx.x & 63;
     uint32_t spins = 0;
+#ifdef FEMCY_SWEEP_PRIO
+    __builtin_amdgcn_s_setprio(FEMCY_SWEEP_PRIO);   /* experiment: the sweeping wave ahead of the CU's streaming waves */
+#endif
     for (;;) {
         double acc[NV];
 #pragma unroll
@@ -53,13 +56,19 @@ __device__ __forceinline__ bool granule_sweep(const __amdgpu_buffer_rsrc_t rs, i
                 acc[v] = op[v] ? fmax(acc[v], val) : acc[v] + val;
             }
         }
+#ifdef FEMCY_SWEEP_PRIO
+        if (__any(poison) || __all(ok)) __builtin_amdgcn_s_setprio(0);
+#endif
         if (__any(poison)) return false;
         if (__all(ok)) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) out[v] = op[v] ? wave_max(acc[v]) : wave_sum(acc[v]);
             return true;
         }
-        __builtin_amdgcn_s_sleep(1);
+#ifndef FEMCY_GRANULE_SLEEP
+#define FEMCY_GRANULE_SLEEP 1      /* s_sleep units (64 cycles) between sweeps; 0 = poll back to back (measured: no gain) */
+#endif
+        if (FEMCY_GRANULE_SLEEP) __builtin_amdgcn_s_sleep(FEMCY_GRANULE_SLEEP);
         if (++spins > spin_limit) return false;
     }
 }

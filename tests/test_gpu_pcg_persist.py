@@ -377,3 +377,19 @@ def test_fused_vector_update_equals_the_two_kernels_and_falls_back(plate):
         ctx.set_option(be.TUNE_BARRIER_SPIN_LIMIT, 1 << 20)
         ctx.set_option(be.OPT_PCG_FUSED_UPDATE, 0)                 # the default (the fused form measured slower)
         ctx.set_option(be.OPT_PCG_PERSIST, 1)
+
+
+def test_probe_spmv_times_the_product_in_both_orders(plate):
+    """femcy_probe_spmv: launch-to-launch time of the product on the PCG's own vectors, node order and storage order;
+    does not disturb the next solve"""
+    be, ctx = plate["be"], plate["ctx"]
+    ctx.set_option(be.OPT_PCG_PERSIST, 0)
+    ref = _solve(ctx, be, 0.0, 9)
+    for order in (False, True):
+        us = ctx.probe_spmv(50, order)
+        assert 0.5 < us < 500.0, us
+    got = _solve(ctx, be, 0.0, 9)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+    with pytest.raises(be.FemcyError):
+        ctx.probe_spmv(0, True)
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)

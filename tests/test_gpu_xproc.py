@@ -73,6 +73,7 @@ def test_persistent_pcg_across_processes_on_one_gpu(gpu_ctx_factory, tmp_path, n
     for i in infos:
         assert i["finegrained"] == 1 and i["has_ipc"] == 1, i            # the fine-grained mailbox has an IPC handle
         assert i["agreed"], i                                            # ... that every peer could open
+        assert 0.05 < i["mailbox_round_trip_us"] < 200.0, i              # femcy_probe_mailbox between the processes' kernels
         assert i["counts_1"] == [5, 0, 0], i["counts_1"]                 # five solves, all one-launch, no time-out
         assert i["counts_0"] == [0, 5, 0], i["counts_0"]
     for r, i in enumerate(infos):

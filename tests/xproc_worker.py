@@ -43,6 +43,8 @@ def main():
         info["peer_pids"] = [int.from_bytes(b[16:24], "little") for b in blobs]
         c.comm_mailbox_import(blobs)
         info["agreed"] = bool(c.comm_persist_agree())
+        if info["agreed"]:
+            info["mailbox_round_trip_us"] = c.probe_mailbox(500)         # the solver's cross-rank reduction, between processes
         c.assemble_K(-1)
         c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
         cons = np.unique(np.concatenate([p.localize_nodes(ns) * 3 + d for ns, d in cons_nodes]))

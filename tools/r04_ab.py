@@ -61,7 +61,8 @@ def persist(wl="c3d4"):
     state(ctx, u, cons)
     print(f"lib {os.path.basename(be.LIB_PATH)}  {wl}: n {ctx.n}, streamed {ctx.persist_streamed_bytes() / 1e6:.1f} MB / iteration", flush=True)
     ref = None
-    for var, rj in ((6, 4), (14, 4), (14, 5), (6, 4), (14, 4)):
+    combos = ((6, 4), (6, 4), (6, 4)) if os.environ.get("ONLY6") else ((6, 4), (14, 4), (14, 5), (6, 4), (14, 4))
+    for var, rj in combos:
         try:
             ctx.set_option(be.TUNE_PERSIST_VARIANT, var)
             ctx.set_option(105, rj)
