@@ -10,6 +10,11 @@ import os
 import sys
 import time
 
+# numpy's BLAS pool spinning after a norm() eats the container's CPU quota and stalls the host for 35-75 ms now and then
+# (visible as one slow repetition in three in the first round-4 records): one thread is enough here
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
