@@ -180,6 +180,15 @@ struct Ctx {
     int64_t persist_cap = 0;
     int32_t* d_bcolp = nullptr;       // block columns as storage positions (PCG with its vectors in storage order)
     int64_t bcolp_serial = -1;
+    // ---- footprint product (k_spmv_fp): per (slice, wave part) the sorted list of storage positions its block rows
+    // refer to, and the block columns as 16-bit indices into that list; the wave stages x of its footprint in LDS with
+    // coalesced loads and gathers from there
+    int opt_spmv_fp = 0;              // FEMCY_OPT_SPMV_FOOTPRINT (0 off, 1 on where the footprints fit the LDS)
+    uint16_t* d_lcol = nullptr;       // [stored_rows * 64]
+    int32_t* d_fp_ptr = nullptr;      // [nslices * wps + 1]
+    int32_t* d_fp = nullptr;
+    int32_t fp_cap = 0;               // longest footprint (entries), 0 = not usable
+    int64_t fp_serial = -1;           // pattern_serial * 8 + wps the arrays were built for
     int opt_fused_update = 0;         // FEMCY_OPT_PCG_FUSED_UPDATE: single-rank three-launch loop with ONE vector kernel per iteration
                                       // (measured slower than the two kernels: default off)
     bool fused_failed = false;        // its in-kernel exchange timed out once: two kernels from then on
@@ -323,6 +332,7 @@ int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange
 int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
 int64_t persist_streamed_bytes(Ctx* c);
+int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);

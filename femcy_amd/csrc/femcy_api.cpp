@@ -259,6 +259,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_persist_assign);
     dev_free(&c->d_bcolp);
     dev_free(&c->d_posb); dev_free(&c->d_posx); dev_free(&c->d_fused);
+    dev_free(&c->d_lcol); dev_free(&c->d_fp_ptr); dev_free(&c->d_fp);
     dev_free(&c->d_probe);
     if (c->ev_iface) (void)hipEventDestroy(c->ev_iface);
     if (c->ev_xchg) (void)hipEventDestroy(c->ev_xchg);
@@ -420,6 +421,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value >= SLICE && value <= (1 << 24), "sorting window must be in [64, 2^24] nodes");
             FEMCY_REQUIRE(!c->have_pattern, "set the sorting window before femcy_build_pattern");
             c->sell_sigma = (int32_t)value;
+            break;
+        case FEMCY_OPT_SPMV_FOOTPRINT:
+            FEMCY_REQUIRE(value == 0 || value == 1, "footprint product: 0 (gathers from global memory) or 1 (footprint staged in LDS)");
+            pcg_graph_reset(c);
+            c->opt_spmv_fp = (int)value;
             break;
         case FEMCY_OPT_PCG_FUSED_UPDATE:
             FEMCY_REQUIRE(value == 0 || value == 1, "fused vector update: 0 (two kernels) or 1");

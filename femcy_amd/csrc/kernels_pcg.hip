@@ -209,6 +209,122 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
     }
 }
 
+// ---- footprint product (round 4, storage order only; ensure_footprint in pattern.cpp).  Same partition of the work as
+// k_spmv -- XCD-contiguous slice ranges, WPS waves per slice, matrix stream policy -- but x is not gathered from global
+// memory block by block: the wave first stages the x entries of its FOOTPRINT (the sorted distinct positions its block
+// rows refer to) in its own LDS region with coalesced 16 + 8 byte loads, then reads them from there through 16-bit
+// local column indices.  A wave-level LDS sync suffices (no workgroup barrier: the region is the wave's own).
+__device__ __forceinline__ void fp_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int DM, int WPS, bool NT>
+__global__ void __launch_bounds__(BS) k_spmv_fp(int32_t npos, XcdRanges xr, const int32_t* __restrict__ slice_len,
+                                                const int64_t* __restrict__ slice_off,
+                                                const uint16_t* __restrict__ lcol, const int32_t* __restrict__ fp_ptr,
+                                                const int32_t* __restrict__ fp, const double* __restrict__ vals,
+                                                const double* __restrict__ x, double* __restrict__ y,
+                                                double* __restrict__ partials, const int32_t* __restrict__ done,
+                                                int32_t keep_permille, int32_t nreal, int32_t fcap) {
+    extern __shared__ __attribute__((aligned(16))) double xs_all[];      // [BS / 64][fcap][DM]
+    __shared__ double sm[BS / 64];
+    __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
+    if (done && *done) return;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)std::min<size_t>((size_t)npos * DM * sizeof(double), 0x7fffffffu), 0x00020000);
+    constexpr int SPB = (BS / 64) / WPS;
+    constexpr int DD = DM * DM, NP = DD / 2;
+    const int k = blockIdx.x % NXCD;
+    const int bpx = gridDim.x / NXCD;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int part = wave % WPS;
+    double* __restrict__ xs = xs_all + (size_t)wave * fcap * DM;
+    const int s_end = xr.start[k + 1];
+    const int ntask = (s_end - xr.start[k] + SPB - 1) / SPB;
+    double dot = 0.0;
+    for (int task = blockIdx.x / NXCD; task < ntask; task += bpx) {
+        const int s = xr.start[k] + task * SPB + wave / WPS;
+        const bool active = s < s_end;
+        double acc[DM];
+#pragma unroll
+        for (int r = 0; r < DM; ++r) acc[r] = 0.0;
+        if (active) {
+            const int32_t L = slice_len[s];
+            const int32_t chunk = (L + WPS - 1) / WPS;
+            const int32_t j0 = part * chunk, j1 = min(L, j0 + chunk);
+            const int64_t off = slice_off[s];
+            // ---- stage the footprint (the previous task's reads of this region are complete: same wave, program order)
+            const int32_t f0 = fp_ptr[(int64_t)s * WPS + part], F = fp_ptr[(int64_t)s * WPS + part + 1] - f0;
+            fp_wave_sync();
+            for (int32_t i = lane; i < F; i += 64) {
+                const int32_t p = NT ? __builtin_nontemporal_load(&fp[f0 + i]) : fp[f0 + i];
+                double xv[DM];
+                gather_x<DM>(xrsrc, p, xv);
+#pragma unroll
+                for (int cc = 0; cc < DM; ++cc) xs[i * DM + cc] = xv[cc];
+            }
+            fp_wave_sync();
+            const uint16_t* __restrict__ lc = lcol + off * SLICE + lane;
+            const double2* __restrict__ vp = reinterpret_cast<const double2*>(vals + off * (int64_t)(DD * SLICE)) + lane;
+            const double* __restrict__ vs = vals + off * (int64_t)(DD * SLICE) + NP * (2 * SLICE) + lane;
+            auto rows = [&](auto nt_tag) {
+                constexpr bool N = decltype(nt_tag)::value;
+#pragma unroll FEMCY_SPMV_UNROLL
+                for (int32_t j = j0; j < j1; ++j) {
+                    const int32_t col = N ? __builtin_nontemporal_load(&lc[(int64_t)j * SLICE]) : lc[(int64_t)j * SLICE];
+                    double e[DD];
+#pragma unroll
+                    for (int kp = 0; kp < NP; ++kp) {
+                        typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                        const nt_d2* tp = reinterpret_cast<const nt_d2*>(&vp[(int64_t)j * (DD * SLICE / 2) + kp * SLICE]);
+                        const nt_d2 t = N ? __builtin_nontemporal_load(tp) : *tp;
+                        e[2 * kp] = t.x;
+                        e[2 * kp + 1] = t.y;
+                    }
+                    if (DD & 1) e[DD - 1] = N ? __builtin_nontemporal_load(&vs[(int64_t)j * (DD * SLICE)]) : vs[(int64_t)j * (DD * SLICE)];
+                    double xv[DM];
+#pragma unroll
+                    for (int cc = 0; cc < DM; ++cc) xv[cc] = xs[col * DM + cc];
+#pragma unroll
+                    for (int r = 0; r < DM; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < DM; ++cc) acc[r] += e[r * DM + cc] * xv[cc];
+                }
+            };
+            if (NT && (int64_t)(s - xr.start[k]) * 1000 >= (int64_t)keep_permille * (s_end - xr.start[k]))
+                rows(std::true_type{});
+            else
+                rows(std::false_type{});
+        }
+        if (WPS > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < DM; ++r) red[(wave * DM + r) * 64 + lane] = acc[r];
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int w = 1; w < WPS; ++w)
+#pragma unroll
+                    for (int r = 0; r < DM; ++r) acc[r] += red[((wave + w) * DM + r) * 64 + lane];
+            }
+        }
+        if (active && part == 0) {
+            const int64_t a = (int64_t)s * SLICE + lane;
+            const bool real = a < nreal;
+#pragma unroll
+            for (int r = 0; r < DM; ++r) {
+                y[a * DM + r] = real ? acc[r] : 0.0;
+                if (real) dot += x[a * DM + r] * acc[r];
+            }
+        }
+    }
+    if (partials) {
+        const double t = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    }
+}
+
 // M = 1/diag(K) (M_init, conjugateGradientSolver.py:48-51): diagonal block is stored row 0 of the slice
 template <int DM>
 __global__ void __launch_bounds__(BS) k_jacobi(int32_t nn, const int32_t* __restrict__ pos,
@@ -875,6 +991,44 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
         else SPMV_LAUNCH_NT(DM_, WPS_, false);          \
     } while (0)
     const int wps = c->spmv_wps;
+    // storage order, single launch over all slices: the footprint product where its arrays exist and fit the LDS
+    if (pos_space && !slice_list && c->opt_spmv_fp) {
+        int rc = ensure_footprint(c);
+        if (rc) return rc;
+        const size_t lds = (size_t)(BS / 64) * c->fp_cap * c->dm * sizeof(double);
+        if (c->fp_cap > 0 && lds <= (size_t)60 * 1024) {
+#define SPMV_FP_ARGS                                                                                            \
+    c->nslices * SLICE, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const uint16_t*)c->d_lcol,  \
+        (const int32_t*)c->d_fp_ptr, (const int32_t*)c->d_fp, (const double*)c->d_Kvals, d_x, d_y, d_partials, done,     \
+        (int32_t)c->spmv_keep_permille, c->nn, c->fp_cap
+#define SPMV_FP_LAUNCH_NT(DM_, WPS_, NT_)                                                                        \
+    do {                                                                                                        \
+        if (lds > 48 * 1024)                                                                                    \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_fp<DM_, WPS_, NT_>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        if (ev)                                                                                                 \
+            hipExtLaunchKernelGGL((k_spmv_fp<DM_, WPS_, NT_>), dim3(grid), dim3(BS), lds, c->stream, ea, eb, 0, SPMV_FP_ARGS); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_spmv_fp<DM_, WPS_, NT_>), dim3(grid), dim3(BS), lds, c->stream, SPMV_FP_ARGS); \
+    } while (0)
+#define SPMV_FP_LAUNCH(DM_, WPS_)                              \
+    do {                                                       \
+        if (c->spmv_nt) SPMV_FP_LAUNCH_NT(DM_, WPS_, true);    \
+        else SPMV_FP_LAUNCH_NT(DM_, WPS_, false);              \
+    } while (0)
+            if (c->dm == 3) {
+                if (wps == 1) SPMV_FP_LAUNCH(3, 1); else if (wps == 2) SPMV_FP_LAUNCH(3, 2); else SPMV_FP_LAUNCH(3, 4);
+            } else {
+                if (wps == 1) SPMV_FP_LAUNCH(2, 1); else if (wps == 2) SPMV_FP_LAUNCH(2, 2); else SPMV_FP_LAUNCH(2, 4);
+            }
+#undef SPMV_FP_LAUNCH
+#undef SPMV_FP_LAUNCH_NT
+#undef SPMV_FP_ARGS
+            FEMCY_HIP(hipGetLastError());
+            if (nblocks_out) *nblocks_out = grid;
+            return FEMCY_OK;
+        }
+    }
     if (c->dm == 3) {
         if (wps == 1) SPMV_LAUNCH(3, 1);
         else if (wps == 2) SPMV_LAUNCH(3, 2);

@@ -90,6 +90,60 @@ void spmv_split(Ctx* c) {
     c->spmv_grid = std::min(per, std::max(1, c->spmv_bpx_cap)) * NX;   // <= 2048 workgroups: larger ranges are looped inside the kernel
 }
 
+// Footprints of the storage-order product (k_spmv_fp).  A wave multiplies block rows j0 .. j1 of one slice (its part of
+// the slice when long rows are shared by WPS waves); the storage positions those (j1 - j0) x 64 blocks refer to -- its
+// footprint -- are listed once, sorted (neighbouring positions: the staging loads coalesce), and the block columns are
+// re-expressed as 16-bit indices into that list.  On the 1 M C3D4 plate a wave's 914 references have 437 distinct
+// targets in 12 runs; the wave then issues 14 coalesced staging loads instead of 30 gather instructions of 13 lines each.
+int ensure_footprint(Ctx* c) {
+    const int wps = c->spmv_wps;
+    const int64_t key = c->pattern_serial * 8 + wps;
+    if (c->fp_serial == key) return FEMCY_OK;
+    c->fp_serial = key;
+    c->fp_cap = 0;
+    const int32_t nslices = c->nslices;
+    const int64_t ntask = (int64_t)nslices * wps;
+    std::vector<std::vector<int32_t>> lists((size_t)ntask);
+    std::vector<uint16_t> lcol((size_t)c->stored_rows * SLICE, 0);
+    bool ok = true;
+    parallel_for(nslices, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> tmp;
+        for (int64_t s = lo; s < hi; ++s) {
+            const int32_t L = c->h_slice_len[s];
+            const int32_t chunk = (L + wps - 1) / wps;
+            const int64_t off = c->h_slice_off[s];
+            for (int w = 0; w < wps; ++w) {
+                const int32_t j0 = w * chunk, j1 = std::min(L, j0 + chunk);
+                tmp.clear();
+                for (int32_t j = j0; j < j1; ++j)
+                    for (int lane = 0; lane < SLICE; ++lane) tmp.push_back(c->h_pos[c->h_bcol[(off + j) * SLICE + lane]]);
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                if (tmp.size() > 65535) ok = false;
+                for (int32_t j = j0; j < j1; ++j)
+                    for (int lane = 0; lane < SLICE; ++lane) {
+                        const int32_t p = c->h_pos[c->h_bcol[(off + j) * SLICE + lane]];
+                        lcol[(off + j) * SLICE + lane] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), p) - tmp.begin());
+                    }
+                lists[(size_t)s * wps + w] = tmp;
+            }
+        }
+    });
+    if (!ok) return FEMCY_OK;                                    // fp_cap stays 0: the gather product is used
+    std::vector<int32_t> ptr((size_t)ntask + 1, 0);
+    size_t cap = 0;
+    for (int64_t t = 0; t < ntask; ++t) {
+        ptr[t + 1] = ptr[t] + (int32_t)lists[t].size();
+        cap = std::max(cap, lists[t].size());
+    }
+    std::vector<int32_t> fp((size_t)ptr[ntask]);
+    for (int64_t t = 0; t < ntask; ++t) std::copy(lists[t].begin(), lists[t].end(), fp.begin() + ptr[t]);
+    int rc;
+    if ((rc = upload(&c->d_lcol, lcol)) || (rc = upload(&c->d_fp_ptr, ptr)) || (rc = upload(&c->d_fp, fp))) return rc;
+    c->fp_cap = (int32_t)((cap + 1) & ~(size_t)1);
+    return FEMCY_OK;
+}
+
 int build_pattern(Ctx* c) {
     const int32_t nn = c->nn, ne = c->ne, npe = c->npe, dm = c->dm;
     const int32_t* el = c->h_elems.data();

@@ -401,7 +401,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         // schedule / layout knobs of the device kernels: accepted, without effect on the host
         case FEMCY_OPT_ASSEMBLY: case FEMCY_OPT_PCG_POLL: case FEMCY_OPT_SPMV_VARIANT: case FEMCY_OPT_EW_GRID:
         case FEMCY_OPT_PCG_GRAPH: case FEMCY_OPT_PCG_PERSIST: case FEMCY_OPT_PCG_SMALL: case FEMCY_OPT_OVERLAP:
-        case FEMCY_OPT_PCG_PERSIST_MULTI: case FEMCY_OPT_PCG_STORAGE_ORDER: case FEMCY_OPT_PCG_FUSED_UPDATE:
+        case FEMCY_OPT_PCG_PERSIST_MULTI: case FEMCY_OPT_PCG_STORAGE_ORDER: case FEMCY_OPT_PCG_FUSED_UPDATE: case FEMCY_OPT_SPMV_FOOTPRINT:
             return FEMCY_OK;
         case FEMCY_OPT_NODE_ORDER:
             REQUIRE(!c->have_pattern, "set the node order before femcy_build_pattern");

@@ -120,6 +120,11 @@ enum femcy_option {
                                    in round 4: the exchange (2.6-3.3 us) costs more than the kernel boundary it removes
                                    (1.5 us) -- 80.5 -> 82.0 us per iteration on the C3D10 plate, 42.3 -> 43.8 at 1 M C3D4
                                    (profiles/r04_ab_fused_update.txt) -- so it stays an option                    */
+    FEMCY_OPT_SPMV_FOOTPRINT = 16, /* storage-order product of the three-launch PCG: 1 = every wave first stages the x entries
+                                   of its footprint (the sorted distinct positions its block rows refer to) in LDS with
+                                   coalesced loads and gathers from there through 16-bit local columns; 0 = gathers from
+                                   global memory per block (default: measured 0 ... 6 % faster than the footprint form,
+                                   profiles/r04_ab_footprint_product.txt)                                          */
     FEMCY_OPT_NODE_ORDER = 14,  /* internal row order of the matrix, set before femcy_build_pattern; vectors handed
                                    to / from the caller always keep the caller's numbering.  0 = rows sorted by length
                                    inside windows of the caller's numbering; 1 = inside windows of the best of the

@@ -726,8 +726,9 @@ def test_sell_sigma_row_order_is_transparent(gpu_ctx_factory, name):
 @pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_plate_C3D10.inp", "ellip_CPS8.inp"])
 def test_internal_row_order_and_storage_order_are_transparent(gpu_ctx_factory, name):
     """FEMCY_OPT_NODE_ORDER (rows sorted inside windows of a coordinate order instead of the caller's numbering;
-    1 = the measured choice, 2 + k = coordinate order k forced) and FEMCY_OPT_PCG_STORAGE_ORDER (the three-launch PCG
-    keeps its vectors in storage order) change where things are stored, never what the caller sees: K entry for entry,
+    1 = the measured choice, 2 + k = coordinate order k forced), FEMCY_OPT_PCG_STORAGE_ORDER (the three-launch PCG
+    keeps its vectors in storage order) and FEMCY_OPT_SPMV_FOOTPRINT (its product stages x in LDS per wave) change
+    where things are stored and fetched from, never what the caller sees: K entry for entry,
     the reference-layout export, K x, PCG iterates; vectors go in and come out in the caller's numbering"""
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
@@ -736,9 +737,12 @@ def test_internal_row_order_and_storage_order_are_transparent(gpu_ctx_factory, n
     cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in inp.dirichlet_bc_info]))
     outs = []
     forced = (2, 3) if dm == 2 else (2, 4, 7)
-    for order, storage in [(0, 1), (0, 0), (1, 1)] + [(k, 1) for k in forced] + [(forced[-1], 0)]:
+    for order, storage in [(0, 1), (0, 0), (1, 1)] + [(k, 1) for k in forced] + [(forced[-1], 0), (0, 2), (forced[0], 2)]:
         ctx = gpu_ctx_factory()
         ctx.set_option(be.OPT_NODE_ORDER, order)
+        if storage == 2:                                        # storage order + the footprint product (x staged in LDS per wave)
+            ctx.set_option(be.OPT_SPMV_FOOTPRINT, 1)
+            storage = 1
         ctx.set_option(be.OPT_PCG_STORAGE_ORDER, storage)
         ctx.set_option(be.OPT_PCG_SMALL, 0)                     # the three-launch loop is what the options act on
         ctx.set_option(be.OPT_PCG_PERSIST, 0)

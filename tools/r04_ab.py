@@ -172,6 +172,37 @@ def knobs(wl):
     ctx.close()
 
 
+def footprint(wl):
+    """the storage-order product with gathers from global memory against the footprint product (FEMCY_OPT_SPMV_FOOTPRINT)"""
+    m, quad, u, cons = problem(wl)
+    ctx, info = make_ctx(m, quad, [(be.OPT_PCG_PERSIST, 0)])
+    state(ctx, u, cons)
+    spmv_b = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * ctx.n
+    iter_b = spmv_b + 88 * ctx.n
+    ref = None
+    for flag in (0, 1, 0, 1):
+        ctx.set_option(be.OPT_SPMV_FOOTPRINT, flag)
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)
+        b2b = min(ctx.probe_spmv(200, True) for _ in range(3))
+        res = []
+        for _ in range(3):
+            ctx.set_option(be.OPT_TIMING, 1 << 20)
+            ctx.timing_reset()
+            its = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)[0]
+            tm = ctx.timing()
+            ctx.set_option(be.OPT_TIMING, 0)
+            res.append(tm["pcg_ms"] * 1e3 / its)
+        r30 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+        x30 = ctx.download(be.VEC_X)
+        conv = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=1e-3)
+        if ref is None:
+            ref = x30.copy()
+        print(f"  {wl} footprint {flag}: SpMV launch to launch {b2b:7.2f} us ({spmv_b / b2b / 1e3 / HBM:.3f} of HBM) | PCG " +
+              " ".join(f"{v:7.2f}" for v in res) + f" us/it ({iter_b / min(res) / 1e3 / HBM:.3f}) | 30 its rmax {r30[2]:.9e} |x-x0|/|x0| "
+              f"{np.linalg.norm(x30 - ref) / np.linalg.norm(ref):.1e} | eps 1e-3: {conv[0]} its", flush=True)
+    ctx.close()
+
+
 def fused(wl):
     """the single-rank three-launch loop with two vector kernels per iteration against ONE (FEMCY_OPT_PCG_FUSED_UPDATE)"""
     m, quad, u, cons = problem(wl)
@@ -206,6 +237,8 @@ if __name__ == "__main__":
     what = sys.argv[1]
     if what == "persist":
         persist(*(sys.argv[2:3]))
+    elif what == "footprint":
+        footprint(sys.argv[2] if len(sys.argv) > 2 else "c3d10")
     elif what == "fused":
         fused(sys.argv[2] if len(sys.argv) > 2 else "c3d10")
     elif what == "knobs":
