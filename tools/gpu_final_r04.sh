@@ -19,6 +19,7 @@ timeout 300 python bench.py --workload c3d10 --steps 10 --no-cpu-baseline > $OUT
 FEMCY_BENCH_STORAGE_ORDER=0 timeout 300 python bench.py --workload c3d10 --steps 10 --no-cpu-baseline > $OUT/bench_c3d10_node_order_vectors.json 2> $OUT/bench_c3d10_nov.err
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --hbm-bound off --force-comm > $OUT/bench_forcecomm_persistent.json 2> $OUT/bench_forcecomm_persistent.err
 FEMCY_BENCH_PERSIST_MULTI=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --hbm-bound off --force-comm > $OUT/bench_forcecomm_rccl.json 2> $OUT/bench_forcecomm_rccl.err
+timeout 300 python bench.py --steps 3 --warmup 1 --iters 200 --prewarm 0 --no-cpu-baseline --hbm-bound off --force-comm --force-dist --no-strong > $OUT/bench_forcecomm_forcedist.json 2> $OUT/bench_forcecomm_forcedist.err; echo "force-dist rc $?"
 for n in 2 4; do
   FEMCY_BENCH_TRANSPORT=shm FEMCY_BENCH_ALL_ON_GPU0=1 FEMCY_BENCH_DIST_BACKEND=gloo FEMCY_BENCH_DEVICE=cpu GPU_MAX_HW_QUEUES=16 \
     FEMCY_BENCH_STRONG_CELLS=96,12,144 \
@@ -33,7 +34,8 @@ cat $OUT/persist_inband.txt
 (timeout 400 python tools/r04_ab.py order c3d10; timeout 400 python tools/r04_ab.py order c3d10) 2>&1 | grep -v amdgpu.ids > $OUT/ab_order_c3d10.txt
 (timeout 500 python tools/r04_ab.py order c3d4_8m; timeout 500 python tools/r04_ab.py order c3d4_8m) 2>&1 | grep -v amdgpu.ids > $OUT/ab_order_c3d4_8m.txt
 (timeout 400 python tools/r04_ab.py knobs c3d10; timeout 400 python tools/r04_ab.py knobs c3d4_8m) 2>&1 | grep -v amdgpu.ids > $OUT/spmv_knobs.txt
-(for wl in c3d10 c3d4 c3d4_8m; do timeout 400 python tools/r04_ab.py fused $wl; done) 2>&1 | grep -v amdgpu.ids > $OUT/ab_fused.txt
+(for wl in c3d10 c3d4 c3d4_8m; do timeout 400 python tools/r04_ab.py fused $wl; done) 2>&1 | grep -v "amdgpu.ids\|^+ " > $OUT/ab_fused.txt
+(for wl in c3d4 c3d10 c3d4_8m; do timeout 500 python tools/r04_ab.py footprint $wl; done) 2>&1 | grep -v "amdgpu.ids\|^+ " > $OUT/ab_footprint.txt
 (timeout 300 python tools/microbench.py 12; timeout 300 python tools/microbench.py 6 1) 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/microbench.txt
 cd /tmp
 for wl in c3d4 c3d10; do
