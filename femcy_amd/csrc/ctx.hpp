@@ -92,6 +92,7 @@ struct Ctx {
 
     // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
     int32_t nslices = 0;
+    int32_t* d_asm_order = nullptr;   // row-centric assembly (rows4): slices by decreasing work (workgroup b takes entry b)
     XcdRanges xcd{};                  // SpMV: slice range per XCD
     int32_t spmv_grid = 0;            // 8 * max blocks per XCD
     int32_t spmv_wps = 1;             // wavefronts per slice (1, 2 or 4)

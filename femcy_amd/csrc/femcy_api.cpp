@@ -243,7 +243,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
-    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx);
+    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
     for (auto& v : c->d_vec) dev_free(&v);

@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
 //     leaves zeros, applies the material constants and stores its five pieces.
 // Deterministic for the same reason as rows2 (fixed step order, ds_add_f64 of one instruction applied in lane order).
 template <int NPE, int NGP, bool CUBIC>
-__global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax,
+__global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax, const int32_t* __restrict__ order,
                                                         const int32_t* __restrict__ ne_ptr,
                                                         const int32_t* __restrict__ ne_idx,
                                                         const uint16_t* __restrict__ slotj,
@@ -1027,8 +1027,15 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     double* rec = wbase + (size_t)grp * (EPG * RD + VOLW + accw + 2);      // this half's records
     double* vl = rec + EPG * RD;
     double* acc = vl + VOLW;
-    const int32_t s = blockIdx.x;
-    if (s >= nslices) return;
+    // workgroup b takes the b-th slice in order of decreasing work (pattern.cpp: `asm_order`).  Workgroups are dispatched
+    // in index order and run on XCD b % 8 (observed; speed only): longest first gives every XCD an even share of every
+    // weight class and lets the short slices fill the tail.  Round 4: in plain slice order a row order whose long rows
+    // recur with a period that is a multiple of 8 slices (the coordinate orders of FEMCY_OPT_NODE_ORDER) put twice the
+    // work on one XCD -- 303 -> 483 us with identical instruction counts, profiles/r04_pmc_rows4_node_order.txt --
+    // and contiguous per-XCD ranges (balanced by blocks: 392 us, by work: 355 us) lose the mixing of long and short
+    // slices the caller's numbering happens to have (its corner rows come first)
+    if ((int32_t)blockIdx.x >= nslices) return;
+    const int32_t s = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
     const int64_t off_v = slice_off[s];
     const int64_t off = ((int64_t)__builtin_amdgcn_readfirstlane((int32_t)(off_v >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)off_v);
@@ -1633,13 +1640,15 @@ int launch_assemble(Ctx* c) {
         const size_t lds = (size_t)4 * 2 * (EPG * RD + volw + accw + 2) * sizeof(double);
         FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS4 assembly needs %zu B of LDS per workgroup (longest row: %d "
                       "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
+        const int r4_grid = c->nslices;
 #define FEMCY_ROWS4(CUB_)                                                                                              \
     do {                                                                                                               \
         if (lds > 48 * 1024)                                                                                           \
             FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_>),               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,    \
-                           R4_LMAX, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen, c->d_node_of,         \
+        hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_>), dim3(r4_grid), dim3(bs), lds, c->stream, c->nslices,       \
+                           R4_LMAX, (const int32_t*)c->d_asm_order, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen,  \
+                           c->d_node_of,                                                                               \
                            c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
                            c->d_Kvals);                                                                                \
     } while (0)

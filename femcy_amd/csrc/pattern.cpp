@@ -412,6 +412,23 @@ int build_pattern(Ctx* c) {
         }
     });
 
+    // ---- launch order of the row-centric assembly (one workgroup per slice): slices by decreasing WORK, which for that
+    // kernel is (row, incident element) pairs plus a per-row constant -- a C3D10 corner row has 24 elements, a mid-side
+    // row 4-8.  Workgroups are dispatched in index order and land on XCD b % 8, so longest-first (a) hands every XCD an
+    // even share of every weight class whatever the row order is, (b) lets the short slices fill the tail.
+    std::vector<int32_t> asm_order(nslices);
+    {
+        std::vector<int64_t> work(nslices, 0);
+        for (int32_t s = 0; s < nslices; ++s) {
+            asm_order[s] = s;
+            for (int lane = 0; lane < SLICE; ++lane) {
+                const int32_t a = node_of[(size_t)s * SLICE + lane];
+                if (a >= 0) work[s] += (ne_ptr[a + 1] - ne_ptr[a]) + 2;
+            }
+        }
+        std::stable_sort(asm_order.begin(), asm_order.end(), [&](int32_t x, int32_t y) { return work[x] > work[y]; });
+    }
+
     // ---- commit to the context
     c->nslices = nslices;
     c->stored_rows = stored_rows;
@@ -438,6 +455,7 @@ int build_pattern(Ctx* c) {
     if ((rc = upload(&c->d_tpos, tpos))) return rc;
     if ((rc = upload(&c->d_ne_ptr, ne_ptr))) return rc;
     if ((rc = upload(&c->d_ne_idx, ne_idx))) return rc;
+    if ((rc = upload(&c->d_asm_order, asm_order))) return rc;
 
     if (c->d_Kvals) (void)hipFree(c->d_Kvals);
     size_t kbytes = (size_t)stored_rows * dm * dm * SLICE * sizeof(double);

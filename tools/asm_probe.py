@@ -19,6 +19,8 @@ m = (meshgen.twist_plate(48, 6, 72, quadratic=True, renumber=os.environ.get("FEM
 ctx = be.Context(0)
 if os.environ.get("FEMCY_BENCH_SIGMA"):
     ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
+if os.environ.get("FEMCY_PROBE_NODE_ORDER"):                    # FEMCY_OPT_NODE_ORDER: 0 caller's numbering, 1 measured choice
+    ctx.set_option(be.OPT_NODE_ORDER, int(os.environ["FEMCY_PROBE_NODE_ORDER"]))
 ctx.set_mesh(m["nodes"], m["elements"])
 ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetrahedral())
 ctx.set_material(LinearIsotropic(*m["elastic"]))
