@@ -45,7 +45,7 @@ OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neig
 OPT_PCG_STORAGE_ORDER = 13   # 1 (default) = the single-rank three-launch PCG keeps its vectors in storage order
 OPT_PCG_FUSED_UPDATE = 15    # 1 = one vector kernel per iteration in the single-rank three-launch PCG (default 0: measured slower)
 OPT_SPMV_FOOTPRINT = 16      # 1 = storage-order product with the wave's x footprint staged in LDS
-OPT_NODE_ORDER = 14      # 0 = caller's numbering, 1 = measured choice among coordinate orders, 2 + k = forced (before build_pattern)
+OPT_NODE_ORDER = 14      # 0 = caller's numbering, 1 (default) = measured choice among coordinate orders, 2 + k = forced (before build_pattern)
 OPT_PCG_PERSIST = 11     # 1 (default) = persistent one-launch PCG (single rank, <= ~7e5 DOF, matrix <= Infinity Cache); 2 = any matrix size
 OPT_PCG_PERSIST_MULTI = 12   # 1 (default) = the persistent kernel across ranks once the mailboxes are exchanged and agreed
 OPT_PCG_SMALL = 10       # 1 (default) = one persistent launch per solve for systems that fit LDS

@@ -199,9 +199,9 @@ struct Ctx {
     double* d_posb = nullptr;         // right-hand side / solution in storage order
     double* d_posx = nullptr;
     int64_t pos_cap = 0;
-    int opt_node_order = 0;           // FEMCY_OPT_NODE_ORDER: 0 = rows sorted inside windows of the caller's numbering,
-                                      // 1 = inside windows of the best of a few coordinate orders (measured on the pattern),
-                                      // 2 + k = forced: coordinate order k
+    int opt_node_order = 1;           // FEMCY_OPT_NODE_ORDER: 0 = rows sorted inside windows of the caller's numbering,
+                                      // 1 (default) = inside windows of the best of a few coordinate orders if it beats the
+                                      // caller's numbering by 10 % (measured on the pattern), 2 + k = forced: coordinate order k
     int node_order_used = 0;          // 0 natural, 1 + k = coordinate order k (femcy_pattern_info)
     double node_order_cost[8] = {0};  // mean 128-byte lines per wave gather, natural first (diagnostics)
     std::vector<double> h_nodes;      // host copy of the coordinates (femcy_set_mesh) for the ordering

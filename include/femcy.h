@@ -127,10 +127,13 @@ enum femcy_option {
                                    profiles/r04_ab_footprint_product.txt)                                          */
     FEMCY_OPT_NODE_ORDER = 14,  /* internal row order of the matrix, set before femcy_build_pattern; vectors handed
                                    to / from the caller always keep the caller's numbering.  0 = rows sorted by length
-                                   inside windows of the caller's numbering; 1 = inside windows of the best of the
+                                   inside windows of the caller's numbering; 1 (default) = inside windows of the best of the
                                    lexicographic coordinate orders (one per axis permutation) if its measured gather cost
                                    (cache lines per wavefront gather, femcy_get_node_order) beats the caller's numbering
-                                   by 10 %; 2 + k = coordinate order k forced (tests)                            */
+                                   by 10 % -- otherwise the caller's numbering; 2 + k = coordinate order k forced (tests).
+                                   Measured: persistent PCG on C3D10 plates of 37 k / 72 k elements 31.8 -> 28.8 / 40.7 ->
+                                   34.9 us per iteration; neutral for the three-launch PCG and the assemblies; the 1 M / 8 M
+                                   C3D4 plates keep their numbering (profiles/r04_persist_node_order_c3d10.txt)      */
     FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (up to ~7.8e5
                                    DOF on MI355X) and whose matrix, less the part the kernel keeps on chip, fits the
                                    Infinity Cache are solved by one persistent launch -- vectors and part of the matrix

@@ -172,6 +172,51 @@ def knobs(wl):
     ctx.close()
 
 
+def persist_order(cells="40,5,60"):
+    """the persistent PCG on a C3D10 plate small enough for it, rows in the caller's numbering / in the measured coordinate
+    order (its d is gathered in storage order: 27 against 14 cache lines per gather)"""
+    nx, ny, nz = (int(v) for v in cells.split(","))
+    m = meshgen.twist_plate(nx, ny, nz, quadratic=True)
+    u = np.zeros(m["nodes"].size)
+    cons = []
+    for bc in m["dirichlet_bc_info"]:
+        cons.append(np.asarray(bc["node_set"]) * 3 + bc["dof"])
+        if bc["user"]:
+            user_dirichletBC_values(u, bc["node_set"], 3, bc["dof"], m["nodes"], 0.05)
+    cons = np.unique(np.concatenate(cons)).astype(np.int32)
+    ref = None
+    for order in (0, 1, 0, 1):
+        ctx, info = make_ctx(m, True, [(be.OPT_NODE_ORDER, order)])
+        used, lines = ctx.node_order()
+        state(ctx, u, cons)
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=200)
+        res = []
+        for _ in range(4):
+            ctx.set_option(be.OPT_TIMING, 1)
+            ctx.timing_reset()
+            its = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=400)[0]
+            tm = ctx.timing()
+            ctx.set_option(be.OPT_TIMING, 0)
+            res.append(tm["persist_ms"] * 1e3 / max(its, 1) if tm["persist_launches"] else tm["pcg_ms"] * 1e3 / its)
+        r30 = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+        x30 = ctx.download(be.VEC_X)
+        if ref is None:
+            ref = x30.copy()
+        tm = ctx.timing()
+        asm = []
+        ctx.set_option(be.OPT_TIMING, 1)
+        ctx.timing_reset()
+        for _ in range(5):
+            ctx.assemble_K(be.VEC_DOF)
+        t2 = ctx.timing()
+        ctx.set_option(be.OPT_TIMING, 0)
+        print(f"  C3D10 {cells} ({ctx.ne} elements, {ctx.nn} nodes, {info.nslices} slices, streamed {ctx.persist_streamed_bytes() / 1e6:.0f} MB) node_order "
+              f"{order} (used {used}; lines " + " ".join(f"{v:.1f}" for v in lines if v) + "): persistent PCG " + " ".join(f"{v:6.2f}" for v in res) +
+              f" us/it | paths persist/three {tm['solves_persist']}/{tm['solves_three']} | assembly "
+              f"{(t2['geom_ms'] + t2['assemble_ms']) / t2['assemble_launches']:.3f} ms | |x-x0|/|x0| {np.linalg.norm(x30 - ref) / np.linalg.norm(ref):.1e}", flush=True)
+        ctx.close()
+
+
 def footprint(wl):
     """the storage-order product with gathers from global memory against the footprint product (FEMCY_OPT_SPMV_FOOTPRINT)"""
     m, quad, u, cons = problem(wl)
@@ -237,6 +282,8 @@ if __name__ == "__main__":
     what = sys.argv[1]
     if what == "persist":
         persist(*(sys.argv[2:3]))
+    elif what == "persist_order":
+        persist_order(*(sys.argv[2:3]))
     elif what == "footprint":
         footprint(sys.argv[2] if len(sys.argv) > 2 else "c3d10")
     elif what == "fused":
