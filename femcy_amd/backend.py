@@ -45,6 +45,7 @@ OPT_EXCHANGE = 8         # multi-rank: 0 = packed all-reduce (default), 1 = neig
 OPT_PCG_STORAGE_ORDER = 13   # 1 (default) = the single-rank three-launch PCG keeps its vectors in storage order
 OPT_PCG_FUSED_UPDATE = 15    # 1 = one vector kernel per iteration in the single-rank three-launch PCG (default 0: measured slower)
 OPT_SPMV_FOOTPRINT = 16      # 1 = storage-order product with the wave's x footprint staged in LDS
+OPT_DIRECT_MAX_BYTES = 17   # femcy_direct_solve: largest band it may allocate (bytes, default 48 GiB)
 OPT_NODE_ORDER = 14      # 0 = caller's numbering, 1 (default) = measured choice among coordinate orders, 2 + k = forced (before build_pattern)
 OPT_PCG_PERSIST = 11     # 1 (default) = persistent one-launch PCG (single rank, <= ~7e5 DOF, matrix <= Infinity Cache); 2 = any matrix size
 OPT_PCG_PERSIST_MULTI = 12   # 1 (default) = the persistent kernel across ranks once the mailboxes are exchanged and agreed
@@ -70,6 +71,7 @@ EXPORTS = [
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
     "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
     "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order", "femcy_probe_mailbox", "femcy_probe_spmv",
+    "femcy_direct_solve",
 ]
 
 
@@ -82,6 +84,13 @@ class FemcyError(RuntimeError):
 
 
 FEMCY_ENUMERIC = -4
+FEMCY_ENOMEM = -6
+
+
+class DirectInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("band_bytes", C.c_int64), ("bandwidth", C.c_int32), ("panels", C.c_int32),
+                ("singular_at", C.c_int32), ("negative_pivots", C.c_int32), ("refinements", C.c_int32),
+                ("reserved", C.c_int32), ("residual", C.c_double)]
 
 
 class PatternInfo(C.Structure):
@@ -165,6 +174,7 @@ def _bind(lib, kind):
         "femcy_get_node_order": [p, C.POINTER(i32), p], "femcy_probe_mailbox": [p, i32, C.POINTER(f64)],
         "femcy_probe_spmv": [p, i32, i32, C.POINTER(f64)],
         "femcy_comm_persist_agree": [p, C.POINTER(i32)],
+        "femcy_direct_solve": [p, cint, cint, C.POINTER(DirectInfo)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -403,6 +413,14 @@ class Context:
         it, r0, rm = C.c_int32(), C.c_double(), C.c_double()
         self._call("femcy_pcg", int(b_vec), int(x_vec), float(eps), int(maxit), C.byref(it), C.byref(r0), C.byref(rm))
         return it.value, r0.value, rm.value
+
+    def direct_solve(self, b_vec: int, x_vec: int = VEC_X) -> dict:
+        """vec[x] = K^-1 vec[b] by a band factorisation K = L S L^T (solve_by_scipy, stiffnessMtrx.py:219-251).
+        -> what was factored and how good the solution is.  FemcyError with status FEMCY_ENUMERIC when K is singular or
+        the residual stays large, FEMCY_ENOMEM when the band is too large."""
+        info = DirectInfo()
+        self._call("femcy_direct_solve", int(b_vec), int(x_vec), C.byref(info))
+        return {k: getattr(info, k) for k, _ in DirectInfo._fields_ if k != "reserved"}
 
     # -------------------------------------------------------------------------- post-processing
     def compute_strain_stress(self, u_vec: int = VEC_DOF, large: bool = False):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include "ctx.hpp"
+#include "direct.hpp"
 
 namespace femcy {
 
@@ -239,6 +240,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
     pcg_graph_reset(c);
+    direct_release(c);
     dev_free(&c->d_nodes); dev_free(&c->d_elems); dev_free(&c->d_dN); dev_free(&c->d_w); dev_free(&c->d_C);
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
@@ -296,6 +298,8 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS4, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
+        case FEMCY_OPT_DIRECT_MAX_BYTES:
+            return direct_set_max_bytes(c, value);
         case FEMCY_OPT_PCG_POLL:
             FEMCY_REQUIRE(value >= 1, "poll interval must be >= 1");
             c->opt_poll = (int)value;
@@ -986,6 +990,15 @@ int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, i
     // reference: at most n iterations -- n of the whole (un-partitioned) system, so that every rank stops at the same count
     if (maxit <= 0) maxit = (int32_t)std::min<int64_t>(c->comm ? c->n_global : c->n, INT32_MAX);
     return pcg_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], eps, maxit, iters, rmax0, rmax);
+}
+
+int femcy_direct_solve(femcy_ctx* ctx, int b_vec, int x_vec, femcy_direct_info* info) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "pattern not built");
+    VEC_OR_FAIL(b_vec);
+    VEC_OR_FAIL(x_vec);
+    FEMCY_REQUIRE(b_vec != x_vec, "direct solve: b and x must be different vectors");
+    return direct_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], info);
 }
 
 // ------------------------------------------------------------------------------ post-processing

@@ -1,0 +1,528 @@
+// Direct solve of small systems on the device: band Cholesky.
+//
+//   solve_by_scipy   stiffnessMtrx.py:219-251   -> direct_solve (femcy_direct_solve)
+//
+// The reference hands systems below 1e5 DOF to scipy's sparse direct solver on the host.  Here the factorisation runs
+// on the GPU, on a matrix that never leaves it:
+//   * the nodes are renumbered by reverse Cuthill-McKee (band_order.hpp, once per pattern): K becomes a band of
+//     bw = (max rank distance + 1) * dm - 1 sub-diagonals -- a few hundred DOF for the 2-D decks, a few thousand for a
+//     3-D mesh of 3e4 nodes;
+//   * the lower band is stored as TILES of 32 x 32 doubles (8 KB, row-major), column panel after column panel:
+//     tile (p, t) = rows of block row p + t, columns of panel p, t = 0 .. T with T = ceil(bw / 32) -- a tile is what
+//     one workgroup reads or writes with full 128-byte lines, and fill-in stays inside the band;
+//   * K = L S L^T with L lower triangular (positive diagonal) and S = diag(+-1): Cholesky when K is positive definite,
+//     and still a factorisation when a diverging Newton iterate has inverted elements and K is indefinite -- the
+//     reference's LU returns a solution there too and the increment driver's path depends on it.  No pivoting (it
+//     would leave the band); instead the residual b - K x is formed with K itself (the SpMV of the PCG) and the
+//     solution refined while that pays, and a result is returned only if the residual ends small (band_order.hpp);
+//   * right-looking factorisation, two launches per panel: k_band_panel (every workgroup factors the 32 x 32 diagonal
+//     tile in the registers of its wave -- redundantly: 6 kflop against a grid-wide hand-over -- and solves ITS tile of
+//     the panel against it in the same instruction stream),
+//     k_band_update (one workgroup per pair of panel tiles: a 32 x 32 x 32 product subtracted from the tile it meets);
+//   * forward and backward substitution, one launch per panel each, column-oriented so that the T tiles of a panel are
+//     independent workgroups: the 32 unknowns of the panel are solved in registers of one wave (lane = row, its row of
+//     the factor in registers, v_readlane broadcast of the solved unknown), then every tile subtracts its share from
+//     the rows it couples to.
+// All launches sit on the context's stream in order; what returns to the host is the pivot flag and two residual norms.
+// The arithmetic is f64 VALU: at T tiles per panel the update moves 16 KB per 65 kflop tile product, which is bound by
+// the tile traffic (L2 / Infinity Cache at these sizes), not by the FMA rate -- no MFMA reshaping.
+//
+// State lives beside the context (a table keyed by the context's address), created on first use and dropped by
+// femcy_ctx_destroy / a new pattern.
+#include <mutex>
+#include <unordered_map>
+#include "band_order.hpp"
+#include "ctx.hpp"
+
+namespace femcy {
+
+namespace {
+
+constexpr int NB = 32;          // panel width = tile edge (DOF)
+constexpr int TS = NB * NB;     // doubles per tile
+
+struct DirectState {
+    int64_t pattern_serial = -1;
+    int64_t max_bytes = (int64_t)48 << 30;
+    int32_t half_band_nodes = 0, bw = 0, T = 0, P = 0;
+    int64_t band_tiles = 0;
+    int32_t* d_rank = nullptr;
+    int32_t* d_node_at = nullptr;
+    double* d_band = nullptr;
+    double* d_dfac = nullptr;
+    double* d_sgn = nullptr;      // [P * 32] the signs S
+    double* d_invd = nullptr;     // [P * 32] 1 / l_kk
+    double *d_wb = nullptr, *d_wy = nullptr, *d_wx = nullptr;
+    double *d_res = nullptr, *d_Kx = nullptr;   // [n] caller's numbering: residual, K x
+    double* d_norms = nullptr;    // max|res| (NaN if any entry is), max|b|
+    int32_t* d_flag = nullptr;    // [0] 1 + first pivot that is zero / NaN, [1] negative pivots
+    char* h_back = nullptr;       // pinned: 2 int32 + 2 doubles
+    void release() {
+        for (void* q : {(void*)d_rank, (void*)d_node_at, (void*)d_band, (void*)d_dfac, (void*)d_sgn, (void*)d_invd, (void*)d_wb, (void*)d_wy,
+                        (void*)d_wx, (void*)d_res, (void*)d_Kx, (void*)d_norms, (void*)d_flag})
+            if (q) (void)hipFree(q);
+        if (h_back) (void)hipHostFree(h_back);
+        d_rank = d_node_at = d_flag = nullptr;
+        d_band = d_dfac = d_sgn = d_invd = d_wb = d_wy = d_wx = d_res = d_Kx = d_norms = nullptr;
+        h_back = nullptr;
+        pattern_serial = -1;
+    }
+};
+
+std::mutex g_mu;
+std::unordered_map<const Ctx*, DirectState> g_states;
+
+DirectState& state_of(const Ctx* c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_states[c];   // references into an unordered_map stay valid across insertions
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K (blocked SELL, caller's numbering) -> lower band tiles (band order).  Thread = (slice, slot j, lane).
+template <int DM>
+__global__ void __launch_bounds__(256) k_band_fill(int32_t nslices, int32_t maxL, const int32_t* __restrict__ slice_len,
+                                                   const int64_t* __restrict__ slice_off,
+                                                   const int32_t* __restrict__ node_of, const int32_t* __restrict__ rowlen,
+                                                   const int32_t* __restrict__ bcol, const double* __restrict__ Kvals,
+                                                   const int32_t* __restrict__ rank, int32_t T, double* __restrict__ band) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(t & 63);
+    const int64_t q = t >> 6;
+    const int32_t j = (int32_t)(q % maxL), s = (int32_t)(q / maxL);
+    if (s >= nslices || j >= slice_len[s]) return;
+    const int32_t a = node_of[(int64_t)s * SLICE + lane];
+    if (a < 0 || j >= rowlen[a]) return;
+    const int64_t row = slice_off[s] + j;
+    const int32_t b = bcol[row * SLICE + lane];
+    const int32_t ra = rank[a], rb = rank[b];
+    if (ra < rb) return;                                          // the upper triangle is the mirror lane's
+#pragma unroll
+    for (int r = 0; r < DM; ++r)
+#pragma unroll
+        for (int cc = 0; cc < DM; ++cc) {
+            const int32_t i = ra * DM + r, jj = rb * DM + cc;
+            if (i < jj) continue;
+            const int32_t pn = jj / NB, tt = i / NB - pn;
+            band[((int64_t)pn * (T + 1) + tt) * TS + (i % NB) * NB + (jj % NB)] = Kvals[kv_index<DM>(row, r * DM + cc, lane)];
+        }
+}
+
+// right-hand side into band order; the rows that pad the last panel are unit rows
+__global__ void __launch_bounds__(256) k_band_gather(int64_t n, int32_t P, int32_t dm, int32_t T,
+                                                     const int32_t* __restrict__ node_at, const double* __restrict__ b,
+                                                     double* __restrict__ wb, double* __restrict__ band) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)P * NB) return;
+    if (i < n) {
+        wb[i] = b[(int64_t)node_at[i / dm] * dm + i % dm];
+    } else {
+        wb[i] = 0.0;
+        if (band) band[((int64_t)(i / NB) * (T + 1)) * TS + (i % NB) * NB + (i % NB)] = 1.0;   // (not when refining)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_band_scatter(int64_t n, int32_t dm, const int32_t* __restrict__ node_at,
+                                                      const double* __restrict__ wx, double* __restrict__ x, int add) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double* dst = x + (int64_t)node_at[i / dm] * dm + i % dm;
+    *dst = add ? *dst + wx[i] : wx[i];
+}
+
+// res = b - K x, norms[0] = max|res| (NaN as soon as one entry is), norms[1] = max|b|.  One workgroup: n < 1e5 here.
+__global__ void __launch_bounds__(1024) k_band_residual(int64_t n, const double* __restrict__ b, const double* __restrict__ Kx,
+                                                        double* __restrict__ res, double* __restrict__ norms) {
+    __shared__ double sr[1024], sb[1024];
+    __shared__ int snan;
+    if (threadIdx.x == 0) snan = 0;
+    __syncthreads();
+    double rm = 0.0, bm = 0.0;
+    bool nan = false;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double r = b[i] - Kx[i];
+        res[i] = r;
+        nan |= r != r;
+        rm = fmax(rm, fabs(r));
+        bm = fmax(bm, fabs(b[i]));
+    }
+    if (nan) snan = 1;
+    sr[threadIdx.x] = rm;
+    sb[threadIdx.x] = bm;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sr[threadIdx.x] = fmax(sr[threadIdx.x], sr[threadIdx.x + o]);
+            sb[threadIdx.x] = fmax(sb[threadIdx.x], sb[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        norms[0] = snan ? __builtin_nan("") : sr[0];
+        norms[1] = sb[0];
+    }
+}
+
+// value of lane `l` (uniform; a compile-time constant in the unrolled loops below) as a scalar
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// panel p: workgroup t = one wave.  Lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of tile t of
+// the panel (workgroup 0: copies of the diagonal rows, never stored) -- 32 doubles per lane, in registers.  The
+// right-looking elimination of the diagonal tile, A = L S L^T, IS the triangular solve of the rows below it: at step k
+// every row scales its entry of column k by s_k / l_kk and subtracts its multiple of column k from its later entries,
+// L(j, k) broadcast from lane j -- one instruction stream for both halves of the wave, no LDS, no barrier (the first
+// version, LDS tiles + three barriers per step, took 51 us per panel against 8: profiles/r04_direct_kernels.txt).
+// Workgroup 0 stores L to dfac[p], the signs to sgn, 1 / l_kk to invd; workgroup t > 0 replaces its tile by A (S L^T)^-1.
+// The right-hand side rides along as one more column: row i carries b_i, at step k z_k = b_k / l_kk goes to all and the
+// rows below subtract their multiple -- the forward sweep of the first solve costs two instructions per step instead of
+// a launch per panel (k_band_fwd serves the refinement solves).
+__global__ void __launch_bounds__(64) k_band_panel(int32_t p, int32_t T, double* __restrict__ band, double* __restrict__ dfac,
+                                                   double* __restrict__ sgn, double* __restrict__ invd,
+                                                   int32_t* __restrict__ flag, double* __restrict__ wb,
+                                                   double* __restrict__ wy) {
+    const int lane = threadIdx.x, t = blockIdx.x;
+    const int row = lane & (NB - 1);
+    const bool below = lane >= NB;                                // a row below the diagonal tile
+    double* Ap = band + (int64_t)p * (T + 1) * TS;
+    double* mine = (below && t > 0) ? Ap + (int64_t)t * TS + row * NB : Ap + row * NB;
+    double r[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(mine + c);
+        r[c] = v.x;
+        r[c + 1] = v.y;
+    }
+    double my_sign = 1.0, my_inv = 0.0;                           // lane k < 32: s_k, 1 / l_kk
+    int32_t bad_at = 0, negative = 0;
+    const int64_t brow = (int64_t)(p + ((below && t > 0) ? t : 0)) * NB + row;
+    double bi = wb[brow], zi = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double dkk = lane_bcast(r[k], k), a = fabs(dkk);
+        const bool bad = !(a > 0.0);                              // zero or NaN
+        const double sk = dkk < 0.0 ? -1.0 : 1.0;
+        const double piv = bad ? 1.0 : sqrt(a);
+        const double ipiv = 1.0 / piv;
+        if (bad && bad_at == 0) bad_at = p * NB + k + 1;
+        negative += dkk < 0.0 ? 1 : 0;
+        if (lane == k) {
+            my_sign = sk;
+            my_inv = ipiv;
+        }
+        const double scaled = r[k] * (sk * ipiv);
+        r[k] = (lane == k) ? piv : ((lane > k) ? scaled : r[k]);  // rows above k: the (unused) upper triangle stays
+        const double rks = r[k] * sk;
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) r[j] -= rks * lane_bcast(r[k], j);
+        const double zk = lane_bcast(bi, k) * ipiv;
+        zi = (lane == k) ? zk : zi;
+        bi = (lane > k) ? bi - r[k] * zk : bi;
+    }
+    if (t == 0) {
+        if (!below) {
+            double* out = dfac + (int64_t)p * TS + row * NB;
+#pragma unroll
+            for (int c = 0; c < NB; c += 2)
+                *reinterpret_cast<double2*>(out + c) = make_double2(c <= row ? r[c] : 0.0, c + 1 <= row ? r[c + 1] : 0.0);
+            sgn[(int64_t)p * NB + row] = my_sign;
+            invd[(int64_t)p * NB + row] = my_inv;
+            wy[brow] = zi * my_sign;                              // S z_p: the right-hand side of the backward sweep
+        }
+        if (lane == 0) {                                          // panels run in stream order: the first bad pivot stays
+            if (bad_at && flag[0] == 0) flag[0] = bad_at;
+            if (negative) flag[1] += negative;
+        }
+        return;
+    }
+    if (below) {
+#pragma unroll
+        for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(mine + c) = make_double2(r[c], r[c + 1]);
+        wb[brow] = bi;
+    }
+}
+
+// trailing update of panel p: workgroup (i, j), 1 <= j <= i <= Tp: tile (p + j, i - j) -= L(p, i) S_p L(p, j)^T
+__global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, double* __restrict__ band,
+                                                     const double* __restrict__ sgn) {
+    const int bi = blockIdx.x + 1, bj = blockIdx.y + 1;
+    if (bj > bi) return;
+    __shared__ double A[NB][NB + 1];
+    __shared__ double B[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const double* Lp = band + (int64_t)p * (T + 1) * TS;
+    for (int e = tid; e < TS; e += 256) {
+        A[e / NB][e % NB] = Lp[(int64_t)bi * TS + e] * sgn[(int64_t)p * NB + e % NB];   // the signs go into one operand
+        B[e / NB][e % NB] = Lp[(int64_t)bj * TS + e];
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+        const double a0 = A[ty][k], a1 = A[ty + 16][k], b0 = B[tx][k], b1 = B[tx + 16][k];
+        c00 += a0 * b0;
+        c01 += a0 * b1;
+        c10 += a1 * b0;
+        c11 += a1 * b1;
+    }
+    double* tgt = band + ((int64_t)(p + bj) * (T + 1) + (bi - bj)) * TS;
+    tgt[ty * NB + tx] -= c00;
+    tgt[ty * NB + tx + 16] -= c01;
+    tgt[(ty + 16) * NB + tx] -= c10;
+    tgt[(ty + 16) * NB + tx + 16] -= c11;
+}
+
+// forward substitution, panel p: z_p = L_pp^-1 b_p in the registers of the wave -- lane = row (both halves hold it), its
+// row of L_pp in 32 registers, column-oriented: z_c goes from lane c to all, every later row subtracts its multiple.
+// Workgroup 0 stores S z_p (the right-hand side of the backward sweep); workgroup g > 0 holds two tiles of the panel,
+// tile 2 g - 1 in lanes 0..31 and tile 2 g in lanes 32..63 (lane = row, the row in registers), and subtracts
+// L(p, t) z_p from the rows of block row p + t.
+__global__ void __launch_bounds__(64) k_band_fwd(int32_t p, int32_t T, int32_t Tp, const double* __restrict__ band,
+                                                 const double* __restrict__ dfac, const double* __restrict__ sgn,
+                                                 const double* __restrict__ invd, double* __restrict__ wb,
+                                                 double* __restrict__ wy) {
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const int row = lane & (NB - 1), half = lane >> 5;
+    const int tt = 2 * g - 1 + half;                              // my tile (g > 0)
+    const bool tile = g > 0 && tt <= Tp;
+    double d[NB], x[NB];
+    const double* Dp = dfac + (int64_t)p * TS + row * NB;
+    const double* Lt = band + ((int64_t)p * (T + 1) + (tile ? tt : 0)) * TS + row * NB;
+#pragma unroll
+    for (int c = 0; c < NB; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(Dp + c);
+        d[c] = v.x;
+        d[c + 1] = v.y;
+        const double2 w = tile ? *reinterpret_cast<const double2*>(Lt + c) : make_double2(0.0, 0.0);
+        x[c] = w.x;
+        x[c + 1] = w.y;
+    }
+    double bi = wb[(int64_t)p * NB + row];
+    const double iv = invd[(int64_t)p * NB + row];
+    double zi = 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const double zc = lane_bcast(bi, c) * lane_bcast(iv, c);
+        zi = (row == c) ? zc : zi;
+        bi = (row > c) ? bi - d[c] * zc : bi;
+    }
+    if (g == 0) {
+        if (half == 0) wy[(int64_t)p * NB + row] = zi * sgn[(int64_t)p * NB + row];
+        return;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) s += x[c] * lane_bcast(zi, c);
+    if (tile) wb[(int64_t)(p + tt) * NB + row] -= s;
+}
+
+// backward substitution, panel p: x_p = L_pp^-T y_p, lane = column (its column of L_pp in registers); workgroup g > 0:
+// tile t = 2 g - 1 / 2 g of panel p - t (the tiles whose rows are block row p), lane = column of the tile, subtracts
+// L(p - t, t)^T x_p from y of panel p - t
+__global__ void __launch_bounds__(64) k_band_bwd(int32_t p, int32_t T, int32_t Tq, const double* __restrict__ band,
+                                                 const double* __restrict__ dfac, const double* __restrict__ invd,
+                                                 double* __restrict__ wy, double* __restrict__ wx) {
+    const int lane = threadIdx.x, g = blockIdx.x;
+    const int col = lane & (NB - 1), half = lane >> 5;
+    const int tt = 2 * g - 1 + half;
+    const bool tile = g > 0 && tt <= Tq;
+    double d[NB], x[NB];
+    const double* Dp = dfac + (int64_t)p * TS + col;
+    const double* Lt = band + ((int64_t)(p - (tile ? tt : 0)) * (T + 1) + (tile ? tt : 0)) * TS + col;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        d[r] = Dp[r * NB];                                        // L_pp(r, col)
+        x[r] = tile ? Lt[r * NB] : 0.0;                           // L(p - t, t)(r, col)
+    }
+    double yi = wy[(int64_t)p * NB + col];
+    const double iv = invd[(int64_t)p * NB + col];
+    double xi = 0.0;
+#pragma unroll
+    for (int c = NB - 1; c >= 0; --c) {
+        const double xc = lane_bcast(yi, c) * lane_bcast(iv, c);
+        xi = (col == c) ? xc : xi;
+        yi = (col < c) ? yi - d[c] * xc : yi;
+    }
+    if (g == 0) {
+        if (half == 0) wx[(int64_t)p * NB + col] = xi;
+        return;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) s += x[r] * lane_bcast(xi, r);
+    if (tile) wy[(int64_t)(p - tt) * NB + col] -= s;
+}
+
+template <class Tp>
+int alloc(Tp** p, size_t count) {
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(Tp)) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        set_error("direct solve: out of device memory (%zu bytes)", count * sizeof(Tp));
+        return FEMCY_ENOMEM;
+    }
+    return FEMCY_OK;
+}
+
+// order + storage for the current pattern
+int prepare(Ctx* c, DirectState& st) {
+    if (st.pattern_serial == c->pattern_serial && st.d_band) return FEMCY_OK;
+    const int64_t keep_limit = st.max_bytes;
+    st.release();
+    st.max_bytes = keep_limit;
+    const BandOrder o = band_order_rcm(c->nn, c->ne, c->npe, c->h_elems.data());
+    st.half_band_nodes = o.half_band_nodes;
+    const int64_t bw = ((int64_t)o.half_band_nodes + 1) * c->dm - 1;
+    const int64_t T = (bw + NB - 1) / NB, P = (c->n + NB - 1) / NB;
+    const double bytes = (double)P * (double)(T + 1) * TS * 8.0;
+    if (bytes > (double)st.max_bytes) {
+        set_error("direct solve: the band of this system (%lld DOF, %lld sub-diagonals after reverse Cuthill-McKee) takes "
+                  "%.1f GB, more than the limit of %.1f GB (FEMCY_OPT_DIRECT_MAX_BYTES)",
+                  (long long)c->n, (long long)bw, bytes * 1e-9, (double)st.max_bytes * 1e-9);
+        return FEMCY_ENOMEM;
+    }
+    st.bw = (int32_t)bw;
+    st.T = (int32_t)T;
+    st.P = (int32_t)P;
+    st.band_tiles = P * (T + 1);
+    int rc;
+    if ((rc = alloc(&st.d_rank, (size_t)c->nn)) || (rc = alloc(&st.d_node_at, (size_t)c->nn)) ||
+        (rc = alloc(&st.d_band, (size_t)st.band_tiles * TS)) || (rc = alloc(&st.d_dfac, (size_t)P * TS)) ||
+        (rc = alloc(&st.d_sgn, (size_t)P * NB)) || (rc = alloc(&st.d_invd, (size_t)P * NB)) || (rc = alloc(&st.d_wb, (size_t)P * NB)) ||
+        (rc = alloc(&st.d_wy, (size_t)P * NB)) || (rc = alloc(&st.d_wx, (size_t)P * NB)) ||
+        (rc = alloc(&st.d_res, (size_t)c->n)) || (rc = alloc(&st.d_Kx, (size_t)c->n)) || (rc = alloc(&st.d_norms, 2)) ||
+        (rc = alloc(&st.d_flag, 2))) {
+        st.release();
+        st.max_bytes = keep_limit;
+        return rc;
+    }
+    FEMCY_HIP(hipHostMalloc((void**)&st.h_back, 32, hipHostMallocDefault));
+    FEMCY_HIP(hipMemcpy(st.d_rank, o.rank.data(), (size_t)c->nn * sizeof(int32_t), hipMemcpyHostToDevice));
+    FEMCY_HIP(hipMemcpy(st.d_node_at, o.node_at.data(), (size_t)c->nn * sizeof(int32_t), hipMemcpyHostToDevice));
+    st.pattern_serial = c->pattern_serial;
+    return FEMCY_OK;
+}
+
+}  // namespace
+
+void direct_release(Ctx* c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_states.find(c);
+    if (it != g_states.end()) {
+        it->second.release();
+        g_states.erase(it);
+    }
+}
+
+int direct_set_max_bytes(Ctx* c, int64_t bytes) {
+    FEMCY_REQUIRE(bytes >= (int64_t)1 << 20, "direct solve: the band limit must be at least 1 MiB");
+    state_of(c).max_bytes = bytes;
+    return FEMCY_OK;
+}
+
+int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info) {
+    if (c->comm) {
+        set_error("femcy_direct_solve: the factorisation is single-rank; a partitioned system is solved by femcy_pcg");
+        return FEMCY_ECOMM;
+    }
+    FEMCY_REQUIRE(c->dm == 2 || c->dm == 3, "direct solve: dm = %d", c->dm);
+    femcy_direct_info local{};
+    if (!info) info = &local;
+    *info = femcy_direct_info{};
+    info->n = c->n;
+    DirectState& st = state_of(c);
+    int rc = prepare(c, st);
+    if (rc) return rc;
+    info->band_bytes = st.band_tiles * TS * 8;
+    info->bandwidth = st.bw;
+    info->panels = st.P;
+    hipStream_t s = c->stream;
+    const int32_t T = st.T, P = st.P;
+    // ---- K -> band, factorisation
+    FEMCY_HIP(hipMemsetAsync(st.d_band, 0, (size_t)st.band_tiles * TS * sizeof(double), s));
+    FEMCY_HIP(hipMemsetAsync(st.d_flag, 0, 2 * sizeof(int32_t), s));
+    {
+        const int32_t maxL = *std::max_element(c->h_slice_len.begin(), c->h_slice_len.end());
+        const int64_t threads = (int64_t)c->nslices * maxL * SLICE;
+        const int grid = (int)((threads + 255) / 256);
+        if (c->dm == 3)
+            hipLaunchKernelGGL((k_band_fill<3>), dim3(grid), dim3(256), 0, s, c->nslices, maxL, c->d_slice_len, c->d_slice_off,
+                               c->d_node_of, c->d_rowlen, c->d_bcol, c->d_Kvals, st.d_rank, T, st.d_band);
+        else
+            hipLaunchKernelGGL((k_band_fill<2>), dim3(grid), dim3(256), 0, s, c->nslices, maxL, c->d_slice_len, c->d_slice_off,
+                               c->d_node_of, c->d_rowlen, c->d_bcol, c->d_Kvals, st.d_rank, T, st.d_band);
+    }
+    // band order of a right-hand side, the two sweeps, back to the caller's numbering (set or add)
+    auto solve_into = [&](const double* d_rhs, double* d_out, int add, double* d_band_pad) {
+        hipLaunchKernelGGL(k_band_gather, dim3((P * NB + 255) / 256), dim3(256), 0, s, c->n, P, c->dm, T, st.d_node_at, d_rhs,
+                           st.d_wb, d_band_pad);
+        if (d_band_pad)   // first call: the factorisation sits between the padding of the band and the sweeps
+            for (int32_t p = 0; p < P; ++p) {
+                const int32_t Tp = std::min(T, P - 1 - p);
+                hipLaunchKernelGGL(k_band_panel, dim3(Tp + 1), dim3(64), 0, s, p, T, st.d_band, st.d_dfac, st.d_sgn, st.d_invd,
+                                   st.d_flag, st.d_wb, st.d_wy);
+                if (Tp > 0) hipLaunchKernelGGL(k_band_update, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
+            }
+        for (int32_t p = 0; p < P && !d_band_pad; ++p) {       // (the first solve's forward sweep rode with the panels)
+            const int32_t Tp = std::min(T, P - 1 - p);
+            hipLaunchKernelGGL(k_band_fwd, dim3(1 + (Tp + 1) / 2), dim3(64), 0, s, p, T, Tp, st.d_band, st.d_dfac, st.d_sgn,
+                               st.d_invd, st.d_wb, st.d_wy);
+        }
+        for (int32_t p = P - 1; p >= 0; --p) {
+            const int32_t Tq = std::min(T, p);
+            hipLaunchKernelGGL(k_band_bwd, dim3(1 + (Tq + 1) / 2), dim3(64), 0, s, p, T, Tq, st.d_band, st.d_dfac, st.d_invd,
+                               st.d_wy, st.d_wx);
+        }
+        hipLaunchKernelGGL(k_band_scatter, dim3((int)((c->n + 255) / 256)), dim3(256), 0, s, c->n, c->dm, st.d_node_at,
+                           st.d_wx, d_out, add);
+    };
+    int32_t* h_flag = reinterpret_cast<int32_t*>(st.h_back);
+    double* h_norms = reinterpret_cast<double*>(st.h_back + 16);
+    // res = b - K x with the PCG's product; -> max|res| / max|b| (NaN stays NaN)
+    auto residual = [&](double* rel) -> int {
+        int rc2 = launch_spmv(c, d_x, st.d_Kx, nullptr, nullptr);
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(k_band_residual, dim3(1), dim3(1024), 0, s, c->n, d_b, st.d_Kx, st.d_res, st.d_norms);
+        FEMCY_HIP(hipMemcpyAsync(h_norms, st.d_norms, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FEMCY_HIP(hipStreamSynchronize(s));
+        *rel = (h_norms[0] != h_norms[0]) ? h_norms[0] : (h_norms[1] > 0.0 ? h_norms[0] / h_norms[1] : h_norms[0]);
+        return FEMCY_OK;
+    };
+    solve_into(d_b, d_x, 0, st.d_band);
+    FEMCY_HIP(hipMemcpyAsync(h_flag, st.d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FEMCY_HIP(hipStreamSynchronize(s));
+    FEMCY_HIP(hipGetLastError());
+    info->negative_pivots = h_flag[1];
+    if (h_flag[0]) {
+        info->singular_at = h_flag[0];
+        set_error("direct solve: pivot %d (band order) is zero or not a number -- the matrix is singular", h_flag[0] - 1);
+        return FEMCY_ENUMERIC;
+    }
+    double rel = 0.0;
+    if ((rc = residual(&rel))) return rc;
+    while (info->refinements < DIRECT_MAX_REFINE && rel > DIRECT_REFINE_ABOVE) {
+        solve_into(st.d_res, d_x, 1, nullptr);
+        ++info->refinements;
+        double rel2 = 0.0;
+        if ((rc = residual(&rel2))) return rc;
+        const bool stalled = !(rel2 < 0.5 * rel);
+        rel = rel2;
+        if (stalled) break;
+    }
+    FEMCY_HIP(hipGetLastError());
+    info->residual = rel;
+    if (!(rel <= DIRECT_ACCEPT)) {
+        set_error("direct solve: residual %.3e max|b| after %d refinement steps (%d negative pivots): elimination without "
+                  "pivoting lost this matrix", rel, info->refinements, info->negative_pivots);
+        return FEMCY_ENUMERIC;
+    }
+    return FEMCY_OK;
+}
+
+}  // namespace femcy

@@ -25,6 +25,7 @@
 #include <new>
 #include <vector>
 #include "../../include/femcy.h"
+#include "../csrc/band_order.hpp"
 #include "../csrc/element_math.hpp"
 
 using namespace femcy;
@@ -86,6 +87,10 @@ struct femcy_ctx {
     std::vector<LoadSet> loadsets;
     int opt_tangent = 0, opt_timing = 0;
     femcy_timing_t timing{};
+    // femcy_direct_solve: band order of the current pattern (built on first use), storage limit
+    BandOrder band_order;
+    bool have_band_order = false;
+    int64_t direct_max_bytes = (int64_t)48 << 30;
 };
 
 namespace {
@@ -406,6 +411,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
         case FEMCY_OPT_NODE_ORDER:
             REQUIRE(!c->have_pattern, "set the node order before femcy_build_pattern");
             return FEMCY_OK;
+        case FEMCY_OPT_DIRECT_MAX_BYTES:
+            REQUIRE(value >= (int64_t)1 << 20, "direct solve: the band limit must be at least 1 MiB");
+            c->direct_max_bytes = value;
+            return FEMCY_OK;
         default:
             if (option >= 100 && option <= 113) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
             set_error("unknown option %d", option);
@@ -562,6 +571,7 @@ int femcy_build_pattern(femcy_ctx* ctx) {
             }
         }
     c->have_pattern = true;
+    c->have_band_order = false;
     return FEMCY_OK;
 }
 
@@ -885,6 +895,103 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
     VEC_OR_FAIL(y_vec);
     REQUIRE(x_vec != y_vec, "spmv cannot run in place");
     spmv(c, c->vec[x_vec].data(), c->vec[y_vec].data(), nullptr);
+    return FEMCY_OK;
+}
+
+// solve_by_scipy (stiffnessMtrx.py:219-251): direct solve -- reverse Cuthill-McKee, lower band by columns, K = L S L^T,
+// residual check + refinement (csrc/band_order.hpp; the device library does the same on tiles, csrc/kernels_direct.hip)
+int femcy_direct_solve(femcy_ctx* ctx, int b_vec, int x_vec, femcy_direct_info* info) {
+    CTX_OR_FAIL(ctx);
+    REQUIRE(c->have_pattern, "pattern not built");
+    VEC_OR_FAIL(b_vec);
+    VEC_OR_FAIL(x_vec);
+    REQUIRE(b_vec != x_vec, "direct solve: b and x must be different vectors");
+    if (!c->have_band_order) {
+        c->band_order = band_order_rcm(c->nn, c->ne, c->npe, c->elems.data());
+        c->have_band_order = true;
+    }
+    const BandOrder& o = c->band_order;
+    const int dm = c->dm, dd = dm * dm;
+    const int64_t n = c->n, bw = ((int64_t)o.half_band_nodes + 1) * dm - 1, w = bw + 1;
+    const double bytes = (double)n * (double)w * 8.0;
+    femcy_direct_info local{};
+    if (!info) info = &local;
+    *info = femcy_direct_info{};
+    info->n = n;
+    info->band_bytes = (int64_t)bytes;
+    info->bandwidth = (int32_t)bw;
+    if (bytes > (double)c->direct_max_bytes) {
+        set_error("direct solve: the band of this system (%lld DOF, %lld sub-diagonals after reverse Cuthill-McKee) takes "
+                  "%.1f GB, more than the limit of %.1f GB (FEMCY_OPT_DIRECT_MAX_BYTES)",
+                  (long long)n, (long long)bw, bytes * 1e-9, (double)c->direct_max_bytes * 1e-9);
+        return FEMCY_ENOMEM;
+    }
+    std::vector<double> A, sgn((size_t)n);
+    try {
+        A.assign((size_t)n * (size_t)w, 0.0);
+    } catch (const std::bad_alloc&) {
+        set_error("direct solve: out of memory (%.1f GB)", bytes * 1e-9);
+        return FEMCY_ENOMEM;
+    }
+#pragma omp parallel for schedule(static)
+    for (int32_t a = 0; a < c->nn; ++a)
+        for (int64_t q = c->rowptr[a]; q < c->rowptr[a + 1]; ++q) {
+            const int32_t b = c->col[q];
+            const int64_t ra = o.rank[a], rb = o.rank[b];
+            if (ra < rb) continue;
+            for (int r = 0; r < dm; ++r)
+                for (int cc = 0; cc < dm; ++cc) {
+                    const int64_t i = ra * dm + r, j = rb * dm + cc;
+                    if (i >= j) A[(size_t)(j * w + (i - j))] = c->K[q * dd + r * dm + cc];
+                }
+        }
+    int64_t negative = 0;
+    const int64_t bad = band_factor_host(n, bw, A.data(), sgn.data(), &negative);
+    info->negative_pivots = (int32_t)std::min<int64_t>(negative, INT32_MAX);
+    if (bad) {
+        info->singular_at = (int32_t)bad;
+        set_error("direct solve: pivot %lld (band order) is zero or not a number -- the matrix is singular",
+                  (long long)(bad - 1));
+        return FEMCY_ENUMERIC;
+    }
+    const double* bvec = c->vec[b_vec].data();
+    double* x = c->vec[x_vec].data();
+    std::vector<double> y((size_t)n), res((size_t)n), Kx((size_t)n);
+    auto solve_into = [&](const double* rhs, double* out, bool add) {      // out (+)= K^-1 rhs
+        for (int64_t i = 0; i < n; ++i) y[(size_t)i] = rhs[(int64_t)o.node_at[i / dm] * dm + i % dm];
+        band_solve_host(n, bw, A.data(), sgn.data(), y.data());
+        for (int64_t i = 0; i < n; ++i) {
+            double& dst = out[(int64_t)o.node_at[i / dm] * dm + i % dm];
+            dst = add ? dst + y[(size_t)i] : y[(size_t)i];
+        }
+    };
+    auto residual = [&]() {                                                 // res = b - K x; -> max|res| / max|b|
+        spmv(c, x, Kx.data(), nullptr);
+        double rm = 0.0, bm = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            res[(size_t)i] = bvec[i] - Kx[(size_t)i];
+            rm = std::fmax(rm, std::fabs(res[(size_t)i]));
+            bm = std::fmax(bm, std::fabs(bvec[i]));
+        }
+        if (std::isnan(rm)) return rm;
+        return bm > 0.0 ? rm / bm : rm;
+    };
+    solve_into(bvec, x, false);
+    double rel = residual();
+    while (info->refinements < DIRECT_MAX_REFINE && rel > DIRECT_REFINE_ABOVE) {
+        solve_into(res.data(), x, true);
+        ++info->refinements;
+        const double rel2 = residual();
+        const bool stalled = !(rel2 < 0.5 * rel);
+        rel = rel2;
+        if (stalled) break;
+    }
+    info->residual = rel;
+    if (!(rel <= DIRECT_ACCEPT)) {
+        set_error("direct solve: residual %.3e max|b| after %d refinement steps (%d negative pivots): elimination without "
+                  "pivoting lost this matrix", rel, info->refinements, info->negative_pivots);
+        return FEMCY_ENUMERIC;
+    }
     return FEMCY_OK;
 }
 

@@ -10,10 +10,11 @@ loads (a per-facet loop in the reference too, stiffnessMtrx.py:369-411) and the 
 
 Deliberate deviations, all outside the arithmetic of the path:
   * `solve_dof`: the reference switches to scipy's direct `spsolve` below 1e5 DOF
-    (stiffnessMtrx.py:272-276).  There is no CPU solver in this package: small systems run the
-    same device PCG with a tight tolerance (`direct_eps`, default 1e-12 on max|r|/max|r0|), which
-    reproduces the direct-solve control flow of every shipped deck to ~1e-11; at >= 1e5 DOF the
-    reference's own CG settings (eps = 1e-3) apply.
+    (stiffnessMtrx.py:272-276).  Here that branch is a direct solve too, on the device: reverse Cuthill-McKee +
+    band Cholesky (`femcy_direct_solve`, csrc/kernels_direct.hip) -- no iteration, no tolerance.  A mesh split over
+    several ranks (`part`) keeps the device PCG with a tight tolerance instead (`direct_eps`, default 1e-12 on
+    max|r|/max|r0|; `direct="pcg"` selects it on one rank as well); at >= 1e5 DOF the reference's own CG settings
+    (eps = 1e-3) apply.
   * windows / PNG output are not produced (`show_newton_steps`, `save2path` are accepted and ignored);
     `femcy_amd.vtk_out.write_vtk` writes the mesh, displacements and Mises stress for ParaView instead.
   * the reference raises UnboundLocalError when the very first residual is < 1e-9
@@ -39,7 +40,7 @@ class System_of_equations:
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
                  part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce",
-                 gather_blobs=None):
+                 gather_blobs=None, direct: str = "cholesky"):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -52,6 +53,9 @@ class System_of_equations:
         self.C = material.C
         self.verbose = verbose
         self.direct_eps, self.cg_eps = direct_eps, cg_eps
+        if direct not in ("cholesky", "pcg"):
+            raise ValueError("direct must be 'cholesky' (band factorisation on the device) or 'pcg' (tight PCG)")
+        self.direct = direct
 
         # ---- device state: mesh, element tables, material, sparsity pattern
         self.ctx = ctx if ctx is not None else be.Context(device)
@@ -122,7 +126,8 @@ class System_of_equations:
         self.compiled = False
         self._dofsets = {}
         self._loadsets = {}
-        self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0}
+        self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0, "direct_solves": 0,
+                      "direct_rejected": 0}
 
     @property
     def n_system(self) -> int:
@@ -153,18 +158,14 @@ class System_of_equations:
         self.ctx.internal_force(be.VEC_DOF, be.VEC_TMP0)      # F and sigma are by-products of the element pass
 
     # ------------------------------------------------------------------------ linear solve
-    def solve_by_CG(self, eps=None, maxit=None):
+    def _linear_system(self):
         if not hasattr(self, "PCG"):
             b = self.rhs if not self.geometric_nonlinear else self.residual_nodal_force
             self.PCG = CG(spm=self.sparseMtrx_rowMajor, sparseIJ=self.sparseIJ, b=b, eps=self.cg_eps)
-        self.PCG.eps = self.cg_eps if eps is None else eps
-        self.PCG.re_init()
-        it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps,
-                                    maxit=self.PCG.maxit if maxit is None else maxit)
-        self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
-        self.PCG.converged = r0 == 0.0 or rmax < self.PCG.eps * r0
+        return self.PCG
+
+    def _take_solution(self):
         self.stats["linear_solves"] += 1
-        self.stats["cg_iterations"] += it
         self.du.copy_from(self.PCG.x)
         if not self.geometric_nonlinear:
             self.dof.copy_from(self.PCG.x)
@@ -172,18 +173,49 @@ class System_of_equations:
             tg.c_equals_a_minus_b(self.dof, self.dof, self.PCG.x)      # Newton: dof -= x
         return self.du
 
+    def solve_by_CG(self, eps=None, maxit=None):
+        self._linear_system()
+        self.PCG.eps = self.cg_eps if eps is None else eps
+        self.PCG.re_init()
+        it, r0, rmax = self.ctx.pcg(self.PCG.b.id, self.PCG.x.id, eps=self.PCG.eps,
+                                    maxit=self.PCG.maxit if maxit is None else maxit)
+        self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
+        self.PCG.converged = r0 == 0.0 or rmax < self.PCG.eps * r0
+        self.stats["cg_iterations"] += it
+        return self._take_solution()
+
     def solve_by_scipy(self):
-        """name kept for compatibility: the "direct" branch is a tight device PCG (module docstring)."""
-        # standing in for a direct solve: CG in floating point can need more than n iterations on an ill-conditioned
-        # K (nu -> 0.5), so the cap is 10 n here instead of the reference CG's n
+        """the reference's direct branch (`spsolve`, :219-251; the name is kept): band Cholesky on the device."""
+        if self.part is None and self.direct == "cholesky":
+            self._linear_system()
+            try:
+                self.direct_info = self.ctx.direct_solve(self.PCG.b.id, self.PCG.x.id)
+            except be.FemcyError as e:
+                if e.status == be.FEMCY_ENOMEM:
+                    print(f"femcy_amd: {e}; this system is solved by the tight PCG instead", flush=True)
+                    self.direct = "pcg"
+                elif e.status == be.FEMCY_ENUMERIC:
+                    # K singular, or so indefinite that elimination without pivoting lost it (a Newton iterate on its
+                    # way out: the increment is usually cut back a few solves later).  The reference's LU with
+                    # pivoting still returns something there and the driver's path depends on it, so THIS solve gets
+                    # the tight PCG; if that fails as well the breakdown goes to the caller
+                    self.stats["direct_rejected"] += 1
+                else:
+                    raise
+            else:
+                self.PCG.iterations, self.PCG.converged = 0, True
+                self.stats["direct_solves"] += 1
+                return self._take_solution()
+        # a mesh split over ranks (or direct="pcg"): CG in floating point can need more than n iterations on an
+        # ill-conditioned K (nu -> 0.5), so the cap is 10 n here instead of the reference CG's n
         du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
         if not self.PCG.converged:
             # a direct solver would have returned the solution (or failed loudly); an unconverged iterate must not be
             # used as if it were one: report it like a numerical breakdown, so that a Newton step is cut back
             # (advance_inc) and a linear deck fails instead of printing a wrong answer
-            raise be.FemcyError("direct-solve stand-in: PCG stopped at max|r| = {:.3e} > {:.1e} * {:.3e} after {} "
-                                "iterations".format(self.PCG.rmax, self.direct_eps, self.PCG.r0, self.PCG.iterations),
-                                status=be.FEMCY_ENUMERIC)
+            raise be.FemcyError("tight PCG in place of the direct solve: stopped at max|r| = {:.3e} > {:.1e} * {:.3e} "
+                                "after {} iterations".format(self.PCG.rmax, self.direct_eps, self.PCG.r0,
+                                                             self.PCG.iterations), status=be.FEMCY_ENUMERIC)
         return du
 
     def solve_dof(self):

@@ -125,6 +125,8 @@ enum femcy_option {
                                    coalesced loads and gathers from there through 16-bit local columns; 0 = gathers from
                                    global memory per block (default: measured 0 ... 6 % faster than the footprint form,
                                    profiles/r04_ab_footprint_product.txt)                                          */
+    FEMCY_OPT_DIRECT_MAX_BYTES = 17, /* femcy_direct_solve: largest band (bytes) it may allocate (default 48 GiB); a system
+                                   whose band after reverse Cuthill-McKee is larger is refused with FEMCY_ENOMEM    */
     FEMCY_OPT_NODE_ORDER = 14,  /* internal row order of the matrix, set before femcy_build_pattern; vectors handed
                                    to / from the caller always keep the caller's numbering.  0 = rows sorted by length
                                    inside windows of the caller's numbering; 1 (default) = inside windows of the best of the
@@ -311,6 +313,30 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec);
  * Jacobi-PCG, x0 = 0, stop when max|r| < eps*max|r0|, at most maxit iterations (reference: n). */
 int femcy_pcg(femcy_ctx* ctx, int b_vec, int x_vec, double eps, int32_t maxit, int32_t* iters,
               double* rmax0, double* rmax);
+/* solve_by_scipy (stiffnessMtrx.py:219-251: `spsolve` on the scipy matrix built from sparseIJ / sparseMtrx_rowMajor,
+ * the branch solve_dof takes below 1e5 DOF): vec[x] = K^-1 vec[b] by a direct factorisation on the device.
+ * The nodes are renumbered by reverse Cuthill-McKee (once per pattern), K is copied into lower band storage (tiles of
+ * 32 x 32, one column panel after the other) and factored K = L S L^T, S = diag(+-1), without pivoting: Cholesky for
+ * the positive definite K of a sound configuration (after the Dirichlet treatment, :279-341), and still a
+ * factorisation when a diverging Newton iterate has made K indefinite (the reference's LU returns a solution there
+ * too, and the increment driver's path depends on it).  Two triangular solves follow; then the residual b - K x is
+ * formed with K itself and the solution refined (at most twice) while that pays.  vec[b] is left untouched.
+ * FEMCY_ENUMERIC when a pivot is zero / not a number (info->singular_at) or the residual stays above 1e-8 max|b|
+ * (elimination without pivoting lost the indefinite matrix): the caller treats it like a solver breakdown.
+ * FEMCY_ENOMEM when the band does not fit the limit (FEMCY_OPT_DIRECT_MAX_BYTES).  FEMCY_ECOMM with a communicator
+ * attached (the factorisation is single-rank; a partitioned run of a small system keeps the tight PCG of femcy_pcg). */
+typedef struct femcy_direct_info {
+    int64_t n;               /* scalar unknowns */
+    int64_t band_bytes;      /* storage of the band */
+    int32_t bandwidth;       /* sub-diagonals kept, in DOF */
+    int32_t panels;          /* column panels of 32 DOF (0 on the host backend) */
+    int32_t singular_at;     /* 0, or 1 + the row (band order) whose pivot was zero / not a number */
+    int32_t negative_pivots; /* 0 = K was positive definite */
+    int32_t refinements;     /* refinement steps taken (0 .. 2) */
+    int32_t reserved;
+    double residual;         /* max|b - K x| / max|b| of the returned x */
+} femcy_direct_info;
+int femcy_direct_solve(femcy_ctx* ctx, int b_vec, int x_vec, femcy_direct_info* info /* nullable */);
 
 /* ------------------------------------------------------------------------ post-processing */
 /* compute_strain_stress (stiffnessMtrx.py:436-501): F at vec[u]; strain (infinitesimal, or Green when

@@ -5,7 +5,7 @@ The parity tests of the HIP path are written against `femcy_amd.backend.Context`
 files, unchanged, are run here in a child process with FEMCY_BACKEND=cpu: element matrices, forces, Dirichlet / Neumann
 treatment, PCG iterates, post-processing, golden vectors, first-principles pins, the consistent tangent, and whole
 decks through the reference's increment / Newton driver, all against the oracle.  (Device-only machinery is skipped by
-tests/conftest.py; the two C3D10 twist decks -- 14 minutes of host PCG -- are left to the GPU suite.)"""
+tests/conftest.py; the fine C3D10 twist deck -- minutes of host factorisations -- is left to the GPU suite.)"""
 import os
 import subprocess
 import sys
@@ -123,12 +123,15 @@ def test_cpu_context_in_process_solves_a_deck_system():
 
 
 def test_parity_suites_of_the_c_abi_on_the_cpu_backend():
-    tail = _run(["test_gpu_parity.py", "test_gpu_pins.py", "test_gpu_tangent.py", "test_gpu_neohooke2d.py"])
-    print("[cpu backend] parity / pins / tangent / neo-Hookean 2-D:", tail)
+    tail = _run(["test_gpu_parity.py", "test_gpu_pins.py", "test_gpu_tangent.py", "test_gpu_neohooke2d.py",
+                 "test_gpu_direct.py"])
+    print("[cpu backend] parity / pins / tangent / neo-Hookean 2-D / direct solve:", tail)
 
 
 def test_deck_parity_on_the_cpu_backend():
     """whole decks through System_of_equations.solve (increments, modified Newton, line searches, cut-backs) on the
-    host backend against the oracle's displacements: every deck of the reference but the two C3D10 twist decks"""
-    tail = _run(["test_gpu_e2e.py"], k="not C3D10")
+    host backend against the oracle's displacements: every deck of the reference but the fine C3D10 twist deck (2 923
+    factorisations of 9 558 unknowns: 6 minutes of host time; the coarse one is in since the direct branch is a
+    factorisation)"""
+    tail = _run(["test_gpu_e2e.py"], k="not twist_plate_C3D10")
     print("[cpu backend] decks:", tail)

@@ -1,0 +1,229 @@
+"""-m gpu: femcy_direct_solve, the device's answer to the reference's direct branch (`solve_by_scipy`,
+/root/reference/stiffnessMtrx.py:219-251: scipy `spsolve` below 1e5 DOF).  The checker is what the reference calls:
+scipy's sparse LU on the matrix exported from the device (`femcy_get_K_bsr`), with seeded right-hand sides -- on
+positive definite systems (every element family, nu -> 0.5), on the indefinite K of a configuration with inverted
+elements (the reference's LU solves those too and the increment driver's path depends on the answer), on singular
+systems (reported, never returned), and through the increment / Newton driver.  The same file runs against
+libfemcy_cpu.so in the CPU suite (tests/test_cpu_backend.py)."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spl
+
+from helpers import deck
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    et = list(inp.eSets)[0]
+    return inp, inp.eSets[et], list(inp.materials.values())[0]
+
+
+def make_ctx(factory, inp, el, mat):
+    ctx = factory()
+    ctx.set_mesh(inp.nodes, el)
+    ctx.set_element(inp.ELE)
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    return ctx
+
+
+def constrained(inp, dm):
+    return np.unique(np.concatenate([np.asarray(b["node_set"]) * dm + b["dof"] for b in inp.dirichlet_bc_info]))
+
+
+@pytest.mark.parametrize("name,tol", [
+    ("beam_CPS3_disp_meshSize1.inp", 1e-10),                       # tri3, one panel
+    ("ellip_CPS4.inp", 1e-10), ("ellip_CPS8.inp", 1e-10),          # quad4 / quad8
+    ("cookMembrane_CPE6_smallDef.inp", 1e-10),                     # tri6
+    ("ellip_dense_CPS6_0d04.inp", 1e-10),                          # 29 k DOF: ~900 column panels
+    ("cookMembrane_CPE6_smallDef_nu0d4999.inp", 1e-6),             # nu -> 0.5: condition ~1e8 (the tight PCG needs 4 n iterations)
+    ("twist_plate_C3D4.inp", 1e-10), ("twist_C3D10_coarse.inp", 1e-10), ("cook_3d_quadEl_smallDef.inp", 1e-10),
+])
+def test_direct_solve_equals_sparse_lu(gpu_ctx_factory, name, tol):
+    from femcy_amd import backend as be
+    inp, el, mat = load(name)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    dm = ctx.dm
+    ctx.assemble_K(-1)
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal(ctx.n)
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(constrained(inp, dm), be.VEC_RESIDUAL)
+    b = ctx.download(be.VEC_RESIDUAL)
+    K = ctx.get_K_bsr().tocsc()
+    info = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    x = ctx.download(be.VEC_X)
+    ref = spl.spsolve(K, b)
+    assert info["n"] == ctx.n and info["negative_pivots"] == 0 and info["singular_at"] == 0
+    assert 0 < info["bandwidth"] < ctx.n
+    assert np.array_equal(ctx.download(be.VEC_RESIDUAL), b)        # the right-hand side is left alone
+    res = np.abs(K @ x - b).max() / np.abs(b).max()
+    res_lu = np.abs(K @ ref - b).max() / np.abs(b).max()
+    err = np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    print(f"{name}: n = {ctx.n}, bandwidth {info['bandwidth']}, panels {info['panels']}, |x - x_lu| / |x_lu| = {err:.2e}, "
+          f"residual {res:.2e} (sparse LU: {res_lu:.2e}), refinements {info['refinements']}")
+    # the residual a backward-stable solver leaves scales with |K| |x| / |b|: 1e-11 on the ordinary systems, the LU's own
+    # level (x 10) on the nearly incompressible one
+    assert max(res, info["residual"]) <= max(1e-11, 10 * res_lu), (res, res_lu, info)
+    assert err <= tol
+    # a second solve on the same context (storage reused), another right-hand side
+    b2 = b[::-1].copy()
+    b2[constrained(inp, dm)] = 0.0
+    ctx.upload(be.VEC_TMP0, b2)
+    ctx.direct_solve(be.VEC_TMP0, be.VEC_TMP1)
+    x2 = ctx.download(be.VEC_TMP1)
+    assert np.abs(K @ x2 - b2).max() / np.abs(b2).max() <= max(1e-11, 10 * res_lu)
+
+
+def test_reverse_cuthill_mckee_makes_the_band_narrow(gpu_ctx_factory):
+    """the long beam in the caller's numbering couples nodes far apart; after the renumbering the band is a small
+    multiple of the cross-section"""
+    from femcy_amd import backend as be
+    inp, el, mat = load("ellip_dense_CPS6_0d04.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, np.ones(ctx.n))
+    ctx.dirichlet_newton(constrained(inp, ctx.dm), be.VEC_RESIDUAL)
+    info = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    natural = int(np.abs(el[:, :, None] - el[:, None, :]).max()) * ctx.dm
+    print(f"sub-diagonals: caller's numbering {natural}, reverse Cuthill-McKee {info['bandwidth']} of n = {ctx.n}")
+    assert info["bandwidth"] < 0.05 * ctx.n and info["bandwidth"] < natural
+
+
+def test_indefinite_matrix_of_inverted_elements_is_still_solved(gpu_ctx_factory):
+    """a Newton iterate on its way out: elements turned inside out, det J < 0 there, K = sum B^T C B det J w indefinite.
+    The reference's LU returns the solution of that system and the driver iterates on; so does L S L^T + refinement."""
+    from femcy_amd import backend as be
+    inp, el, mat = load("twist_plate_C3D4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    rng = np.random.default_rng(11)
+    h = np.linalg.norm(inp.nodes[el[:, 0]] - inp.nodes[el[:, 1]], axis=1).mean()     # a typical edge
+    u = np.zeros_like(inp.nodes)
+    pick = rng.choice(inp.nodes.shape[0], inp.nodes.shape[0] // 12, replace=False)
+    u[pick] = rng.standard_normal((pick.size, 3)) * 0.8 * h              # a few nodes pushed through their neighbours
+    ctx.upload(be.VEC_DOF, u.ravel())
+    ctx.assemble_K(be.VEC_DOF)
+    vol = ctx.gauss_field(be.GP_VOL).to_numpy()
+    assert (vol < 0).any() and (vol > 0).any()
+    b = rng.standard_normal(ctx.n)
+    ctx.upload(be.VEC_RESIDUAL, b)
+    ctx.dirichlet_newton(constrained(inp, 3), be.VEC_RESIDUAL)
+    b = ctx.download(be.VEC_RESIDUAL)
+    K = ctx.get_K_bsr().tocsc()
+    assert np.linalg.eigvalsh(K.toarray()).min() < 0.0
+    info = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    x = ctx.download(be.VEC_X)
+    ref = spl.spsolve(K, b)
+    err = np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    print(f"{info['negative_pivots']} negative pivots, {info['refinements']} refinements, residual {info['residual']:.2e}, "
+          f"|x - x_lu| / |x_lu| = {err:.2e}")
+    assert info["negative_pivots"] > 0 and info["residual"] <= 1e-8
+    assert err <= 1e-6
+
+
+def test_negative_definite_matrix_all_signs_flipped(gpu_ctx_factory):
+    """-K: every pivot negative, the same solution with the opposite sign (the signs S carry the whole difference)"""
+    from femcy_amd import backend as be
+    inp, el, mat = load("ellip_CPS4.inp")
+    import copy
+    neg = copy.copy(mat)
+    neg.C = -np.asarray(mat.C.to_numpy() if hasattr(mat.C, "to_numpy") else mat.C)
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx2 = make_ctx(gpu_ctx_factory, inp, el, neg)
+    cons = constrained(inp, 2)
+    free = np.setdiff1d(np.arange(ctx.n), cons)
+    b = np.zeros(ctx.n)
+    b[free] = np.random.default_rng(5).standard_normal(free.size)
+    xs = []
+    for c in (ctx, ctx2):
+        c.assemble_K(-1)
+        c.upload(be.VEC_RESIDUAL, b)
+        c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        info = c.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+        xs.append(c.download(be.VEC_X))
+    assert info["negative_pivots"] == free.size                          # the unit rows of the constrained DOFs stay +1
+    assert np.linalg.norm(xs[0] + xs[1]) <= 1e-12 * np.linalg.norm(xs[0])
+
+
+def test_singular_and_nan_matrices_are_reported(gpu_ctx_factory):
+    from femcy_amd import backend as be
+    inp, el, mat = load("ellip_CPS4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)                                                   # no Dirichlet treatment: three rigid-body modes
+    ctx.upload(be.VEC_RESIDUAL, np.random.default_rng(2).standard_normal(ctx.n))
+    with pytest.raises(be.FemcyError) as e:
+        ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    assert e.value.status == be.FEMCY_ENUMERIC
+    u = np.zeros(ctx.n)
+    u[5] = np.nan
+    ctx.upload(be.VEC_DOF, u)
+    ctx.assemble_K(be.VEC_DOF)                                           # NaN coordinates -> NaN blocks
+    ctx.dirichlet_newton(constrained(inp, 2), be.VEC_RESIDUAL)
+    with pytest.raises(be.FemcyError) as e:
+        ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    assert e.value.status == be.FEMCY_ENUMERIC
+    # and the context recovers
+    ctx.assemble_K(-1)
+    ctx.dirichlet_newton(constrained(inp, 2), be.VEC_RESIDUAL)
+    assert ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)["residual"] <= 1e-9
+
+
+def test_argument_and_resource_errors(gpu_ctx_factory):
+    from femcy_amd import backend as be
+    inp, el, mat = load("ellip_dense_CPS6_0d04.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, np.ones(ctx.n))
+    ctx.dirichlet_newton(constrained(inp, 2), be.VEC_RESIDUAL)
+    with pytest.raises(be.FemcyError):
+        ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_RESIDUAL)               # in place
+    with pytest.raises(be.FemcyError):
+        ctx.set_option(be.OPT_DIRECT_MAX_BYTES, 1000)
+    ctx.set_option(be.OPT_DIRECT_MAX_BYTES, 1 << 20)                     # this band takes ~140 MB
+    with pytest.raises(be.FemcyError) as e:
+        ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    assert e.value.status == be.FEMCY_ENOMEM and "FEMCY_OPT_DIRECT_MAX_BYTES" in str(e.value)
+    ctx.set_option(be.OPT_DIRECT_MAX_BYTES, 1 << 30)
+    assert ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)["residual"] <= 1e-9
+
+
+def test_driver_takes_the_direct_branch_and_falls_back_loudly(capsys):
+    """solve_dof below 1e5 DOF = the factorisation (no CG iteration at all); a band over the limit switches the system
+    to the tight PCG with a printed notice, and the answers agree"""
+    from femcy_amd import backend as be
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    out = []
+    for limit in (None, 1 << 20):
+        inp = InpInfo(deck("cookMembrane_CPE6_smallDef_nu0d4999.inp"))
+        body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+        system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+        if limit:
+            system.ctx.set_option(be.OPT_DIRECT_MAX_BYTES, limit)
+        system.solve(inp)
+        out.append((system.dof.to_numpy(), dict(system.stats), system.direct))
+        system.ctx.close()
+    (u0, s0, d0), (u1, s1, d1) = out
+    assert d0 == "cholesky" and s0["direct_solves"] == s0["linear_solves"] == 1 and s0["cg_iterations"] == 0
+    assert d1 == "pcg" and s1["direct_solves"] == 0 and s1["cg_iterations"] > 3498     # more than n iterations at nu = 0.4999
+    assert "tight PCG instead" in capsys.readouterr().out
+    assert np.linalg.norm(u1 - u0) <= 1e-6 * np.linalg.norm(u0)
+
+
+def test_direct_solve_refuses_a_partitioned_system(gpu_ctx_factory):
+    from femcy_amd import backend as be
+    inp, el, mat = load("twist_plate_C3D4.inp")
+    ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, np.ones(ctx.n))
+    ctx.dirichlet_newton(constrained(inp, 3), be.VEC_RESIDUAL)
+    iface = np.arange(0, ctx.n, 7, dtype=np.int32)
+    ctx.comm_init(0, 1, be.Context.comm_unique_id(), iface, np.arange(iface.size, dtype=np.int32), iface.size,
+                  np.ones(ctx.n, dtype=np.uint8))
+    with pytest.raises(be.FemcyError) as e:
+        ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+    assert e.value.status == -5                                          # FEMCY_ECOMM
