@@ -35,6 +35,9 @@ The JSON line carries, besides the contract's keys:
   hbm_bound    (N = 1, default workload) the same invocation then runs the two HBM-bound configurations --
                BASELINE configs[3]'s 7 962 624-element plate on this one GPU and configs[4]'s C3D10 plate -- and
                reports SpMV and PCG-iteration rates against 8 TB/s and against the copy probe of this GPU.
+  direct_branch (N = 1, default workload) the reference's OTHER solver branch -- `solve_dof` below 1e5 DOF, scipy spsolve
+               there, femcy_direct_solve here (band factorisation on the device) -- on three deck-sized systems: ms per
+               solve beside the tight PCG (eps 1e-12) that served the branch before round 4.
   cpu_baseline the as-written C/OpenMP port of the reference on the host, in a child process pinned one thread per
                physical core (OMP_PLACES=cores, OMP_PROC_BIND=spread; arrays first-touched by the threads that use them).
 
@@ -303,6 +306,47 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
                "assembly_ms": asm_ms, "assemblies_per_s": ctx.ne / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
                "wall_s": time.time() - t0}
         return rec
+    finally:
+        ctx.close()
+
+
+def direct_branch_record(be, label, mesh, element, material, user_values, reps=5):
+    """one system of the size the reference's decks have, solved the way `solve_dof` solves it below 1e5 DOF: the
+    direct solve (factorisation redone on every call, as in a Newton iteration) and the tight PCG, ms per solve"""
+    ctx = be.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        nodes, el = mesh["nodes"], mesh["elements"]
+        ctx.set_mesh(nodes, el)
+        ctx.set_element(element)
+        ctx.set_material(material)
+        ctx.build_pattern()
+        u, cons = s1_state(nodes, mesh["dirichlet_bc_info"], user_values)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.vector(be.VEC_RHS).fill(0.0)
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.dofset_dirichlet_newton(ctx.dofset(cons), be.VEC_RESIDUAL)
+
+        def timed(fn):
+            out = fn()                                               # warm-up (allocations, the band order)
+            ts = []
+            for _ in range(reps):
+                ctx.sync()
+                t0 = time.perf_counter()
+                out = fn()
+                ctx.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts)), out
+        t_direct, info = timed(lambda: ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X))
+        xd = ctx.download(be.VEC_X)
+        t_pcg, res = timed(lambda: ctx.pcg(be.VEC_RESIDUAL, be.VEC_TMP0, eps=1e-12, maxit=10 * ctx.n))
+        xp = ctx.download(be.VEC_TMP0)
+        return {"system": label, "dof": int(ctx.n), "sub_diagonals": int(info["bandwidth"]), "panels": int(info["panels"]),
+                "band_mb": info["band_bytes"] / 1e6, "direct_ms": t_direct, "residual": info["residual"],
+                "refinements": int(info["refinements"]), "negative_pivots": int(info["negative_pivots"]),
+                "tight_pcg_ms": t_pcg, "tight_pcg_iterations": int(res[0]),
+                "rel_diff_direct_vs_pcg": float(np.linalg.norm(xd - xp) / max(np.linalg.norm(xd), 1e-300))}
     finally:
         ctx.close()
 
@@ -841,6 +885,26 @@ def main():
         if env.agree_max(1 if "error" in rec else 0) and "error" not in rec:
             rec = {"error": "failed on another rank"}
         result["strong_scaling"] = rec
+
+    # ------------------------------------------------- the reference's direct branch (deck-sized systems), same invocation
+    if rank == 0 and N == 1 and on_gpu and args.hbm_bound == "auto" and not args.cells and not quadratic \
+            and not args.force_comm and not args.force_dist:
+        recs = []
+        for label, gen, ele in (
+                ("twist plate C3D4 8x2x12 cells (the size of the reference's twist_plate_C3D4 deck)",
+                 lambda: meshgen.twist_plate(8, 2, 12), Element_linear_tetrahedral()),
+                ("twist plate C3D10 8x2x12 cells (the size of twist_plate_C3D10)",
+                 lambda: meshgen.twist_plate(8, 2, 12, quadratic=True), Element_quadratic_tetrahedral()),
+                ("twist plate C3D4 24x6x36 cells (19 k DOF)",
+                 lambda: meshgen.twist_plate(24, 6, 36), Element_linear_tetrahedral())):
+            try:
+                msh = gen()
+                recs.append(direct_branch_record(be, label, msh, ele, LinearIsotropic(*msh["elastic"]),
+                                                 user_dirichletBC_values))
+            except Exception as e:                               # noqa: BLE001  (never lose the headline line)
+                log(f"[bench] direct_branch record '{label[:40]}' failed: {e!r}")
+                recs.append({"system": label, "error": repr(e)})
+        result["direct_branch"] = recs
 
     # ------------------------------------------------------------------ the HBM-bound configurations, same invocation
     if rank == 0 and N == 1 and on_gpu and args.hbm_bound == "auto" and not args.cells and not quadratic \

@@ -96,3 +96,21 @@ def test_bench_headline_workload_runs_the_persistent_pcg():
     assert 10.0 < r["avg_launch_us"] / 100 < 60.0                                      # us per iteration inside the launch
     assert abs(d["pcg_us_per_iter"] - r["avg_launch_us"] / 100) < 5.0                  # the solve IS that launch (+ Jacobi, copy-back)
     assert "hbm_bound" not in d
+
+
+def test_direct_branch_record_of_the_bench_line():
+    """`direct_branch` of the default N = 1 line: the reference's spsolve branch on a deck-sized system, both solvers
+    timed, the same answer"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+    msh = meshgen.twist_plate(8, 2, 12)
+    rec = bench.direct_branch_record(be, "twist plate 8x2x12", msh, Element_linear_tetrahedral(),
+                                     LinearIsotropic(*msh["elastic"]), user_dirichletBC_values, reps=2)
+    assert rec["dof"] == msh["nodes"].size and 0 < rec["sub_diagonals"] < rec["dof"] and rec["panels"] == (rec["dof"] + 31) // 32
+    assert rec["direct_ms"] > 0 and rec["tight_pcg_ms"] > 0 and rec["tight_pcg_iterations"] > 10
+    assert rec["negative_pivots"] == 0 and rec["residual"] <= 1e-10 and rec["rel_diff_direct_vs_pcg"] <= 1e-8
+    json.dumps(rec)
