@@ -244,6 +244,10 @@ __global__ void __launch_bounds__(64) k_band_panel(int32_t p, int32_t T, double*
 }
 
 // trailing update of panel p: workgroup (i, j), 1 <= j <= i <= Tp: tile (p + j, i - j) -= L(p, i) S_p L(p, j)^T
+// (2 x 2 tile pairs per workgroup -- a 64 x 64 x 32 product, 4 x 4 results per thread, two FMAs per LDS read -- were
+// measured SLOWER at every size, 19.9 -> 24.8 ms at 915 panels of 18 tiles, 138 -> 146 ms at 2 793 panels of 91: the
+// launch is over when its slowest workgroup is, and four times the work per workgroup costs more than the LDS reads
+// saved; profiles/r04_direct_bench.txt)
 __global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, double* __restrict__ band,
                                                      const double* __restrict__ sgn) {
     const int bi = blockIdx.x + 1, bj = blockIdx.y + 1;
