@@ -78,19 +78,30 @@ def test_direct_solve_equals_sparse_lu(gpu_ctx_factory, name, tol):
     assert np.abs(K @ x2 - b2).max() / np.abs(b2).max() <= max(1e-11, 10 * res_lu)
 
 
-def test_reverse_cuthill_mckee_makes_the_band_narrow(gpu_ctx_factory):
-    """the long beam in the caller's numbering couples nodes far apart; after the renumbering the band is a small
-    multiple of the cross-section"""
+@pytest.mark.parametrize("name", ["ellip_dense_CPS6_0d04.inp", "twist_plate_C3D10.inp", "cookMembrane_CPE6_smallDef.inp"])
+def test_reverse_cuthill_mckee_makes_the_band_narrow(gpu_ctx_factory, name):
+    """the decks' numberings couple nodes far apart; after the library's renumbering the band is a small multiple of the
+    mesh's cross-section -- and no wider than what scipy's reverse Cuthill-McKee finds on the same graph (x 1.25)"""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
     from femcy_amd import backend as be
-    inp, el, mat = load("ellip_dense_CPS6_0d04.inp")
+    inp, el, mat = load(name)
     ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
     ctx.assemble_K(-1)
     ctx.upload(be.VEC_RESIDUAL, np.ones(ctx.n))
     ctx.dirichlet_newton(constrained(inp, ctx.dm), be.VEC_RESIDUAL)
     info = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
-    natural = int(np.abs(el[:, :, None] - el[:, None, :]).max()) * ctx.dm
-    print(f"sub-diagonals: caller's numbering {natural}, reverse Cuthill-McKee {info['bandwidth']} of n = {ctx.n}")
-    assert info["bandwidth"] < 0.05 * ctx.n and info["bandwidth"] < natural
+    natural = (int(np.abs(el[:, :, None] - el[:, None, :]).max()) + 1) * ctx.dm - 1
+    npe = el.shape[1]
+    G = sp.csr_matrix((np.ones(el.size * npe, dtype=np.int8), (np.repeat(el, npe, axis=1).ravel(), np.tile(el, (1, npe)).ravel())),
+                      shape=(ctx.nn, ctx.nn))
+    perm = reverse_cuthill_mckee(G, symmetric_mode=True)
+    rank = np.empty(ctx.nn, dtype=np.int64)
+    rank[perm] = np.arange(ctx.nn)
+    scipy_bw = (int(np.abs(rank[el][:, :, None] - rank[el][:, None, :]).max()) + 1) * ctx.dm - 1
+    print(f"{name}: sub-diagonals: caller's numbering {natural}, library {info['bandwidth']}, scipy's RCM {scipy_bw} (n = {ctx.n})")
+    assert info["bandwidth"] < natural and info["bandwidth"] <= 1.25 * scipy_bw
+    assert info["bandwidth"] < 0.2 * ctx.n
 
 
 def test_indefinite_matrix_of_inverted_elements_is_still_solved(gpu_ctx_factory):
