@@ -238,3 +238,28 @@ def test_direct_solve_refuses_a_partitioned_system(gpu_ctx_factory):
     with pytest.raises(be.FemcyError) as e:
         ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
     assert e.value.status == -5                                          # FEMCY_ECOMM
+
+
+def test_band_order_follows_a_new_pattern_on_the_same_context(gpu_ctx_factory):
+    """the renumbering and the band storage belong to a pattern: another mesh on the same context gets its own"""
+    from femcy_amd import backend as be
+    ctx = gpu_ctx_factory()
+    seen = []
+    for name in ("ellip_CPS8.inp", "cookMembrane_CPE6_smallDef.inp", "ellip_CPS8.inp"):
+        inp, el, mat = load(name)
+        ctx.set_mesh(inp.nodes, el)
+        ctx.set_element(inp.ELE)
+        ctx.set_material(mat)
+        ctx.build_pattern()
+        ctx.assemble_K(-1)
+        b = np.random.default_rng(3).standard_normal(ctx.n)
+        ctx.upload(be.VEC_RESIDUAL, b)
+        ctx.dirichlet_newton(constrained(inp, 2), be.VEC_RESIDUAL)
+        b = ctx.download(be.VEC_RESIDUAL)
+        info = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+        x = ctx.download(be.VEC_X)
+        K = ctx.get_K_bsr().tocsc()
+        assert info["n"] == ctx.n == b.size
+        assert np.abs(K @ x - b).max() <= 1e-11 * np.abs(b).max()
+        seen.append((info["n"], info["bandwidth"]))
+    assert seen[0] == seen[2] and seen[0] != seen[1]

@@ -147,6 +147,28 @@ def test_fullsize_properties(full):
     assert it2 == it and np.array_equal(ctx.download(be.VEC_X), xs)       # run-to-run bit reproducible
 
 
+def test_fullsize_force_is_the_gradient_of_the_energy(full):
+    """a size-independent property with no oracle in it: at the bench's state S1 (5 % of the twist, finite rotations)
+    the device's internal force (sigma(F), current gradients and volumes, node gather) is the derivative of the device's
+    strain energy (F, energy density, reference volumes) -- central differences along two random directions"""
+    be, ctx, u, m = full["be"], full["ctx"], full["u"], full["m"]
+    ctx.upload(be.VEC_DOF, u)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f = ctx.download(be.VEC_FORCE)
+    ctx.assemble_K(-1)                                   # geometry at u = 0: femcy_elastic_energy sums over vol_0
+    rng = np.random.default_rng(9)
+    h = 1e-7 * np.ptp(m["nodes"], axis=0).max()
+    for _ in range(2):
+        v = rng.standard_normal(ctx.n)
+        ctx.upload(be.VEC_TMP0, u + h * v)
+        wp = ctx.elastic_energy(be.VEC_TMP0)
+        ctx.upload(be.VEC_TMP0, u - h * v)
+        wm = ctx.elastic_energy(be.VEC_TMP0)
+        err = abs((wp - wm) / (2 * h) - f @ v) / abs(f @ v)
+        print(f"1 M C3D4: |dW/du.v - f.v| / |f.v| = {err:.2e}")
+        assert err < 1e-5
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: the ~8 M-element C3D4 plate (k = 24: 7 962 624 elements, 4 183 275 DOF).  (a) on one GPU
 # against the C oracle -- the matrix (1.55 GB) streams from HBM here, so this is the non-temporal / in-kernel-loop

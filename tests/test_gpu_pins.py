@@ -261,3 +261,44 @@ def test_one_2d_element_homogeneous_deformation(gpu_ctx_factory, etype, mkind):
     Fg = ctx.gauss_field(be.GP_F).to_numpy()
     Sg = ctx.gauss_field(be.GP_SIGMA).to_numpy()
     assert np.abs(Fg - F).max() < 1e-14 and np.abs(Sg - sig).max() < 1e-13 * np.abs(sig).max()
+
+
+@pytest.mark.parametrize("name,hyperelastic", [("twist_plate_C3D4.inp", True), ("twist_C3D10_coarse.inp", True),
+                                               ("cook_3d_linearEl_largeDef.inp", True),
+                                               ("cookMembrane_2d_linearEl_largeDef.inp", True),
+                                               ("gen_beam_CPE8_tip4.inp", True),
+                                               ("beamDeflec_quadPSE_largeD_load800.inp", False)])
+def test_device_force_is_the_gradient_of_the_device_energy(gpu_ctx_factory, name, hyperelastic):
+    """no oracle in this one: `femcy_internal_force` (sigma(F), current gradients and volumes, node gather) against the
+    central difference of `femcy_elastic_energy` (F, energy density, reference volumes) along random directions -- two
+    device paths that share only the deformation gradient.  Equal for the hyperelastic laws (St. Venant-Kirchhoff,
+    neo-Hookean, plane strain), and NOT for the reference's plane-stress class, whose F33 does not come from its energy
+    (tests/test_oracle_pins.py::test_internal_force_is_the_gradient_of_the_strain_energy says the same of the oracle)."""
+    from femcy_amd import backend as be
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck(name))
+    el = list(inp.eSets.values())[0]
+    ctx = _ctx(gpu_ctx_factory, inp.nodes, el, inp.ELE, list(inp.materials.values())[0])
+    L = np.ptp(inp.nodes, axis=0).max()
+    x = inp.nodes / L
+    u = (0.03 * L * np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]), 0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0],
+                              0.3 * np.sin(x.sum(axis=1))][:inp.nodes.shape[1]], axis=1)).ravel()
+    ctx.upload(be.VEC_DOF, u)
+    ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+    f = ctx.download(be.VEC_FORCE)
+    ctx.assemble_K(-1)                                   # a geometry pass at u = 0: femcy_elastic_energy sums over the
+    rng = np.random.default_rng(0)                       # volumes of the last pass (reference behaviour) = vol_0
+    h = 1e-7 * L                                         # truncation ~ h^2: 6e-8 at worst here, rounding below that
+    worst = 0.0
+    for _ in range(3):
+        v = rng.standard_normal(u.size)
+        ctx.upload(be.VEC_TMP0, u + h * v)
+        wp = ctx.elastic_energy(be.VEC_TMP0)
+        ctx.upload(be.VEC_TMP0, u - h * v)
+        wm = ctx.elastic_energy(be.VEC_TMP0)
+        worst = max(worst, abs((wp - wm) / (2 * h) - f @ v) / abs(f @ v))
+    print(f"{name}: |dW/du.v - f.v| / |f.v| = {worst:.2e}")
+    if hyperelastic:
+        assert worst < 1e-6
+    else:
+        assert 1e-3 < worst < 0.5

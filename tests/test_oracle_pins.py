@@ -468,3 +468,69 @@ def test_plane_stress_large_deformation_force_has_no_symmetric_tangent():
         K = K.toarray() if hasattr(K, "toarray") else np.asarray(K)
         asym[kind] = np.abs(K - K.T).max() / np.abs(K).max()
     assert asym["pstrain"] < 1e-12 and asym["pstress"] > 1e-3, asym
+
+
+# ---------------------------------------------------------------- (iv) cross-pins between functions of the reference
+def _smooth_disp(nodes, scale):
+    L = np.ptp(nodes, axis=0).max()
+    x = nodes / L
+    u = np.stack([np.sin(1.3 * x[:, 0] + 0.4) * np.cos(0.7 * x[:, -1]), 0.5 * np.cos(2.1 * x[:, 1] - 0.2) * x[:, 0],
+                  0.3 * np.sin(x.sum(axis=1))][:nodes.shape[1]], axis=1)
+    return (scale * L * u).ravel()
+
+
+@pytest.mark.parametrize("name,hyperelastic", [("twist_plate_C3D4.inp", True),                  # St. Venant-Kirchhoff, C3D4
+                                               ("twist_C3D10_coarse.inp", True),                # ... C3D10, 4 Gauss points
+                                               ("cook_3d_linearEl_largeDef.inp", True),         # neo-Hookean
+                                               ("cookMembrane_2d_linearEl_largeDef.inp", True),  # plane strain
+                                               ("beamDeflec_quadPSE_largeD_load800.inp", False)])   # plane stress
+def test_internal_force_is_the_gradient_of_the_strain_energy(name, hyperelastic):
+    """Three functions of the reference that share no code must agree if each is read right:
+    `assemble_nodal_force_GN` (stiffnessMtrx.py:609-644: Cauchy stress, current gradients, current volumes),
+    `elasticEnergyDensity` of the material classes and `get_deformation_gradient` -- for a hyperelastic law the nodal
+    force is the derivative of W(u) = sum_gp psi(F(u)) vol_0, here by complex-step differentiation (exact to rounding)
+    at 3 % strains.  The plane-stress class synthesises F33 instead of deriving it from its energy
+    (linear_isotropic_plane_stress.py:65-96): its force is NOT that gradient (6 % off) -- the same fact that rules out
+    a symmetric consistent tangent for it."""
+    inp = InpInfo(deck(name))
+    s = oracle_system_from_inp(inp)
+    topo, mat = s.topo, s.material
+    u = _smooth_disp(topo.nodes, 0.03)
+    f = orc.internal_force(topo, u, mat)[0]
+    _, vol0 = orc.dsdx_and_vol(topo.nodes, topo.elements, np.zeros_like(u), topo.ed)
+
+    def W(uc):
+        F = orc.deformation_gradient(topo.nodes, topo.elements, uc, topo.ed)
+        return np.sum(orc.energy_density(mat, F) * vol0)
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(4):
+        v = rng.standard_normal(u.size)
+        dW = W(u + 1e-30j * v).imag / 1e-30
+        worst = max(worst, abs(dW - f @ v) / abs(f @ v))
+    print(f"{name} ({mat.kind}): |dW/du.v - f.v| / |f.v| = {worst:.2e}")
+    if hyperelastic:
+        assert worst < 1e-12
+    else:
+        assert 1e-3 < worst < 0.5
+
+
+def test_pcg_iterates_equal_scipys_preconditioned_cg():
+    """`ConjugateGradientSolver_rowMajor.solve` (conjugateGradientSolver.py:103-127) as restated in the oracle is the
+    textbook Jacobi-preconditioned CG with x0 = 0: its k-th iterate equals the k-th iterate of scipy's `cg` with
+    M = diag(K)^-1 -- an implementation that shares nothing with it -- to rounding, for k = 1 .. 40"""
+    import scipy.sparse.linalg as sl
+    inp = InpInfo(deck("twist_plate_C3D4.inp"))
+    s = oracle_system_from_inp(inp)
+    u = _smooth_disp(s.topo.nodes, 0.01)
+    cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in inp.dirichlet_bc_info]))
+    K = orc._zero_rows_cols_unit_diag(orc.assemble_K(s.topo, u, s.C), cons)
+    b = np.random.default_rng(4).standard_normal(s.topo.n)
+    b[cons] = 0.0
+    M = sl.LinearOperator(K.shape, matvec=lambda r, d=1.0 / K.diagonal(): d * r)
+    iterates = []
+    sl.cg(K, b, x0=np.zeros_like(b), rtol=1e-300, atol=0.0, maxiter=40, M=M, callback=lambda xk: iterates.append(xk.copy()))
+    assert len(iterates) == 40
+    for k in (1, 2, 5, 10, 20, 40):
+        xo = orc.pcg_reference(K, b, eps=0.0, maxit=k)[0]
+        assert np.linalg.norm(xo - iterates[k - 1]) <= 1e-9 * np.linalg.norm(xo), k
