@@ -168,6 +168,21 @@ __device__ __forceinline__ double lane_bcast(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// sqrt(a) and 1 / sqrt(a) of a pivot, a > 0: the hardware's reciprocal-square-root estimate, two Newton steps, one
+// correction each (2 ulp; the elimination's step-to-step chain waits for exactly this, and the library sqrt + division
+// it replaces is twice as long -- the residual check downstream does not care about the last bit)
+__device__ __forceinline__ void pivot_roots(double a, double& root, double& inv_root) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    double g = a * y;
+    g = fma(fma(-g, g, a), 0.5 * y, g);                           // sqrt: g += (a - g^2) / (2 g)
+    y = fma(fma(-g, y, 1.0), y, y);                               // 1 / g: y += y (1 - g y)
+    root = g;
+    inv_root = y;
+}
+
 // panel p: workgroup t = one wave.  Lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of tile t of
 // the panel (workgroup 0: copies of the diagonal rows, never stored) -- 32 doubles per lane, in registers.  The
 // right-looking elimination of the diagonal tile, A = L S L^T, IS the triangular solve of the rows below it: at step k
@@ -203,8 +218,8 @@ __global__ void __launch_bounds__(64) k_band_panel(int32_t p, int32_t T, double*
         const double dkk = lane_bcast(r[k], k), a = fabs(dkk);
         const bool bad = !(a > 0.0);                              // zero or NaN
         const double sk = dkk < 0.0 ? -1.0 : 1.0;
-        const double piv = bad ? 1.0 : sqrt(a);
-        const double ipiv = 1.0 / piv;
+        double piv, ipiv;
+        pivot_roots(bad ? 1.0 : a, piv, ipiv);
         if (bad && bad_at == 0) bad_at = p * NB + k + 1;
         negative += dkk < 0.0 ? 1 : 0;
         if (lane == k) {
@@ -255,13 +270,18 @@ __global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, doubl
     __shared__ double A[NB][NB + 1];
     __shared__ double B[NB][NB + 1];
     const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
     const double* Lp = band + (int64_t)p * (T + 1) * TS;
+    // the four entries of the target tile this thread owns: requested before the operands are staged, so that their
+    // latency is not paid after the product (each target tile belongs to exactly one workgroup of the launch)
+    double* tgt = band + ((int64_t)(p + bj) * (T + 1) + (bi - bj)) * TS;
+    const double t00 = tgt[ty * NB + tx], t01 = tgt[ty * NB + tx + 16], t10 = tgt[(ty + 16) * NB + tx],
+                 t11 = tgt[(ty + 16) * NB + tx + 16];
     for (int e = tid; e < TS; e += 256) {
         A[e / NB][e % NB] = Lp[(int64_t)bi * TS + e] * sgn[(int64_t)p * NB + e % NB];   // the signs go into one operand
         B[e / NB][e % NB] = Lp[(int64_t)bj * TS + e];
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
     double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
 #pragma unroll 8
     for (int k = 0; k < NB; ++k) {
@@ -271,11 +291,10 @@ __global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, doubl
         c10 += a1 * b0;
         c11 += a1 * b1;
     }
-    double* tgt = band + ((int64_t)(p + bj) * (T + 1) + (bi - bj)) * TS;
-    tgt[ty * NB + tx] -= c00;
-    tgt[ty * NB + tx + 16] -= c01;
-    tgt[(ty + 16) * NB + tx] -= c10;
-    tgt[(ty + 16) * NB + tx + 16] -= c11;
+    tgt[ty * NB + tx] = t00 - c00;
+    tgt[ty * NB + tx + 16] = t01 - c01;
+    tgt[(ty + 16) * NB + tx] = t10 - c10;
+    tgt[(ty + 16) * NB + tx + 16] = t11 - c11;
 }
 
 // forward substitution, panel p: z_p = L_pp^-1 b_p in the registers of the wave -- lane = row (both halves hold it), its
