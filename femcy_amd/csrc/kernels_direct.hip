@@ -517,9 +517,12 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
         *rel = (h_norms[0] != h_norms[0]) ? h_norms[0] : (h_norms[1] > 0.0 ? h_norms[0] / h_norms[1] : h_norms[0]);
         return FEMCY_OK;
     };
+    // the pivot flags travel with the first residual: one host synchronisation per solve, not two (a singular matrix
+    // costs a product nobody looks at)
     solve_into(d_b, d_x, 0, st.d_band);
     FEMCY_HIP(hipMemcpyAsync(h_flag, st.d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    FEMCY_HIP(hipStreamSynchronize(s));
+    double rel = 0.0;
+    if ((rc = residual(&rel))) return rc;
     FEMCY_HIP(hipGetLastError());
     info->negative_pivots = h_flag[1];
     if (h_flag[0]) {
@@ -527,8 +530,6 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
         set_error("direct solve: pivot %d (band order) is zero or not a number -- the matrix is singular", h_flag[0] - 1);
         return FEMCY_ENUMERIC;
     }
-    double rel = 0.0;
-    if ((rc = residual(&rel))) return rc;
     while (info->refinements < DIRECT_MAX_REFINE && rel > DIRECT_REFINE_ABOVE) {
         solve_into(st.d_res, d_x, 1, nullptr);
         ++info->refinements;
