@@ -183,6 +183,90 @@ __device__ __forceinline__ void pivot_roots(double a, double& root, double& inv_
     inv_root = y;
 }
 
+// The elimination of k_band_panel, written as compile-time recursion over the step k and the column j so that every
+// register index and every broadcast lane is a constant AND the stages of the next pivot's root chain can be placed
+// between the updates of the current step.  The pivot of step k + 1 is final after the FIRST update of step k; its
+// roots are a dozen dependent operations, and a wave issues in order: cut into stages and interleaved with the
+// remaining updates (independent of them), the chain's latency passes in the shadow of work that is due anyway.
+struct PivotRoots {                                               // sqrt(a) -> g, 1 / sqrt(a) -> y (see pivot_roots)
+    double a, h, y, t, g, e;
+};
+constexpr int ROOT_STAGES = 12;
+template <int S>
+__device__ __forceinline__ void root_stage(PivotRoots& x) {
+    if constexpr (S == 0) {
+        x.y = __builtin_amdgcn_rsq(x.a);
+        x.h = -0.5 * x.a;
+    } else if constexpr (S == 1 || S == 4) {
+        x.t = x.h * x.y;
+    } else if constexpr (S == 2 || S == 5) {
+        x.t = fma(x.t, x.y, 1.5);
+    } else if constexpr (S == 3 || S == 6) {
+        x.y = x.y * x.t;
+    } else if constexpr (S == 7) {
+        x.g = x.a * x.y;
+    } else if constexpr (S == 8) {
+        x.e = fma(-x.g, x.g, x.a);
+        x.t = 0.5 * x.y;
+    } else if constexpr (S == 9) {
+        x.g = fma(x.e, x.t, x.g);
+    } else if constexpr (S == 10) {
+        x.e = fma(-x.g, x.y, 1.0);
+    } else if constexpr (S == 11) {
+        x.y = fma(x.e, x.y, x.y);
+    }
+}
+struct PanelRow {                                                 // what a lane carries besides its 32 entries
+    double sign, inv, bi, zi;
+    int32_t bad_at, negative;
+};
+template <int K, int J>
+__device__ __forceinline__ void panel_updates(double (&r)[NB], double rks, PivotRoots& nx) {
+    if constexpr (J < NB) {
+        if constexpr (J - (K + 2) < ROOT_STAGES) root_stage<J - (K + 2)>(nx);
+        r[J] -= rks * lane_bcast(r[K], J);
+        panel_updates<K, J + 1>(r, rks, nx);
+    }
+}
+template <int K, int Q>
+__device__ __forceinline__ void root_tail(PivotRoots& nx) {       // the late steps have fewer updates than stages
+    if constexpr (Q < ROOT_STAGES) {
+        if constexpr (Q >= NB - (K + 2)) root_stage<Q>(nx);
+        root_tail<K, Q + 1>(nx);
+    }
+}
+template <int K>
+__device__ __forceinline__ void panel_step(double (&r)[NB], PanelRow& st, int lane, int32_t p, double dkk, double piv,
+                                           double ipiv) {
+    if constexpr (K < NB) {
+        const bool bad = !(fabs(dkk) > 0.0);                      // zero or NaN
+        const double sk = dkk < 0.0 ? -1.0 : 1.0;
+        if (bad && st.bad_at == 0) st.bad_at = p * NB + K + 1;
+        st.negative += dkk < 0.0 ? 1 : 0;
+        if (lane == K) {
+            st.sign = sk;
+            st.inv = ipiv;
+        }
+        const double scaled = r[K] * (sk * ipiv);
+        r[K] = (lane == K) ? piv : ((lane > K) ? scaled : r[K]);  // rows above K: the (unused) upper triangle stays
+        const double rks = r[K] * sk;
+        const double zk = lane_bcast(st.bi, K) * ipiv;
+        double dnext = 0.0;
+        PivotRoots nx;
+        nx.a = 1.0;
+        if constexpr (K + 1 < NB) {
+            r[K + 1] -= rks * lane_bcast(r[K], K + 1);
+            dnext = lane_bcast(r[K + 1], K + 1);
+            nx.a = fabs(dnext) > 0.0 ? fabs(dnext) : 1.0;
+        }
+        panel_updates<K, K + 2>(r, rks, nx);
+        root_tail<K, 0>(nx);
+        st.zi = (lane == K) ? zk : st.zi;
+        st.bi = (lane > K) ? st.bi - r[K] * zk : st.bi;
+        panel_step<K + 1>(r, st, lane, p, dnext, nx.g, nx.y);
+    }
+}
+
 // panel p: workgroup t = one wave.  Lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of tile t of
 // the panel (workgroup 0: copies of the diagonal rows, never stored) -- 32 doubles per lane, in registers.  The
 // right-looking elimination of the diagonal tile, A = L S L^T, IS the triangular solve of the rows below it: at step k
@@ -213,28 +297,16 @@ __global__ void __launch_bounds__(64) k_band_panel(int32_t p, int32_t T, double*
     int32_t bad_at = 0, negative = 0;
     const int64_t brow = (int64_t)(p + ((below && t > 0) ? t : 0)) * NB + row;
     double bi = wb[brow], zi = 0.0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const double dkk = lane_bcast(r[k], k), a = fabs(dkk);
-        const bool bad = !(a > 0.0);                              // zero or NaN
-        const double sk = dkk < 0.0 ? -1.0 : 1.0;
-        double piv, ipiv;
-        pivot_roots(bad ? 1.0 : a, piv, ipiv);
-        if (bad && bad_at == 0) bad_at = p * NB + k + 1;
-        negative += dkk < 0.0 ? 1 : 0;
-        if (lane == k) {
-            my_sign = sk;
-            my_inv = ipiv;
-        }
-        const double scaled = r[k] * (sk * ipiv);
-        r[k] = (lane == k) ? piv : ((lane > k) ? scaled : r[k]);  // rows above k: the (unused) upper triangle stays
-        const double rks = r[k] * sk;
-#pragma unroll
-        for (int j = k + 1; j < NB; ++j) r[j] -= rks * lane_bcast(r[k], j);
-        const double zk = lane_bcast(bi, k) * ipiv;
-        zi = (lane == k) ? zk : zi;
-        bi = (lane > k) ? bi - r[k] * zk : bi;
-    }
+    double dkk = lane_bcast(r[0], 0), piv, ipiv;
+    pivot_roots(fabs(dkk) > 0.0 ? fabs(dkk) : 1.0, piv, ipiv);
+    PanelRow st{my_sign, my_inv, bi, zi, bad_at, negative};
+    panel_step<0>(r, st, lane, p, dkk, piv, ipiv);
+    my_sign = st.sign;
+    my_inv = st.inv;
+    zi = st.zi;
+    bi = st.bi;
+    bad_at = st.bad_at;
+    negative = st.negative;
     if (t == 0) {
         if (!below) {
             double* out = dfac + (int64_t)p * TS + row * NB;
