@@ -1,4 +1,4 @@
-// Direct solve of small systems on the device: band Cholesky.
+// Direct solve of small systems on the device: band factorisation K = L S L^T (Cholesky when K is positive definite).
 //
 //   solve_by_scipy   stiffnessMtrx.py:219-251   -> direct_solve (femcy_direct_solve)
 //
@@ -19,13 +19,14 @@
 //     tile in the registers of its wave -- redundantly: 6 kflop against a grid-wide hand-over -- and solves ITS tile of
 //     the panel against it in the same instruction stream),
 //     k_band_update (one workgroup per pair of panel tiles: a 32 x 32 x 32 product subtracted from the tile it meets);
-//   * forward and backward substitution, one launch per panel each, column-oriented so that the T tiles of a panel are
-//     independent workgroups: the 32 unknowns of the panel are solved in registers of one wave (lane = row, its row of
-//     the factor in registers, v_readlane broadcast of the solved unknown), then every tile subtracts its share from
-//     the rows it couples to.
-// All launches sit on the context's stream in order; what returns to the host is the pivot flag and two residual norms.
-// The arithmetic is f64 VALU: at T tiles per panel the update moves 16 KB per 65 kflop tile product, which is bound by
-// the tile traffic (L2 / Infinity Cache at these sizes), not by the FMA rate -- no MFMA reshaping.
+//   * the forward sweep of the first right-hand side rides inside k_band_panel (b as a 33rd column); the backward sweep
+//     (and both sweeps of a refinement solve) take one launch per panel, column-oriented so that the T tiles of a panel
+//     are independent workgroups: the 32 unknowns of the panel are solved in registers of one wave (lane = row, its row
+//     of the factor in registers, v_readlane broadcast of the solved unknown), then every tile subtracts its share
+//     from the rows it couples to.
+// All launches sit on the context's stream in order; what returns to the host, in one synchronisation, is the pivot
+// flags and two residual norms.  The arithmetic is f64 VALU: the decks' bands are a few tiles wide and what is waited for
+// is the chain of dependent one-wave launches (~20 us per panel of 32 unknowns), not bytes or flops -- no MFMA reshaping.
 //
 // State lives beside the context (a table keyed by the context's address), created on first use and dropped by
 // femcy_ctx_destroy / a new pattern.
