@@ -65,7 +65,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, HBM section); the D2D probe below reports what
                                 # a plain device copy reaches on the box the bench runs on
-ELEMS_PER_GPU = {"c3d4": 995328, "c3d10": 124416}
+ELEMS_PER_GPU = {"c3d4": 995328, "c3d10": 124416, "cpe8": 163840}
+CPE8_CELLS = (1280, 128)        # 163 840 CPE8 elements, 494 337 nodes, 988 674 DOF (~1 M DOF: the size of the 3-D headline system)
+CPE8_NAME = ("beam CPE8 1280x128 serendipity quadrilaterals, plane strain, nlgeom (BASELINE configs[1] stand-in, "
+             "163 840 elements, 988 674 DOF)")
 TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/kernels_pcg_persist.hip", "femcy_amd/csrc/granule.hpp",
                    "femcy_amd/csrc/wave_reduce.hpp", "femcy_amd/csrc/ctx.hpp", "femcy_amd/csrc/pattern.cpp")
 
@@ -189,16 +192,20 @@ def self_launch(n, argv, timeout):
     return proc.returncode
 
 
-def s1_state(nodes, bcs, user_dirichletBC_values):
-    """state S1: the prescribed values of the first increment (t = 0.05) written into dof, zero
-    elsewhere, and the sorted list of constrained DOFs"""
+def s1_state(nodes, bcs, user_dirichletBC_values, t1=0.05, load_ratio=None):
+    """state S1: the prescribed values of the first increment (end time t1: user blocks are evaluated at
+    t1, plain blocks hold val * load_ratio, stiffnessMtrx.py:679-690) written into dof, zero elsewhere, and the sorted
+    list of constrained DOFs"""
+    dm = nodes.shape[1]
     u = np.zeros(nodes.size)
     cons = []
     for bc in bcs:
         ids = np.asarray(bc["node_set"], dtype=np.int64)
-        cons.append(ids * 3 + bc["dof"])
+        cons.append(ids * dm + bc["dof"])
         if bc["user"] and ids.size:
-            user_dirichletBC_values(u, ids, 3, bc["dof"], nodes, 0.05)
+            user_dirichletBC_values(u, ids, dm, bc["dof"], nodes, t1)
+        elif ids.size and bc["val"] != 0.0:
+            u[ids * dm + bc["dof"]] = bc["val"] * (t1 if load_ratio is None else load_ratio)
     return u, np.unique(np.concatenate(cons)).astype(np.int32)
 
 
@@ -234,7 +241,10 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         ctx.set_element(element)
         ctx.set_material(material)
         info = ctx.build_pattern()
-        u, cons = s1_state(nodes, mesh["dirichlet_bc_info"], user_values)
+        ti = mesh.get("time_incs", {})
+        u, cons = s1_state(nodes, mesh["dirichlet_bc_info"], user_values, t1=ti.get("ini_inc", 0.05),
+                           load_ratio=ti.get("ini_inc", 0.05) / ti.get("max_time", 1.0))
+        block_bytes = ctx.dm * ctx.dm * 8 + 4
         ctx.upload(be.VEC_DOF, u)
         ctx.vector(be.VEC_RHS).fill(0.0)
         ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
@@ -290,8 +300,8 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         path = ("persistent" if tm["solves_persist"] else "three-kernel")
         spmv_gbs = spmv_b / (spmv_us * 1e-6) / 1e9
         iter_gbs = iter_b / (iter_us * 1e-6) / 1e9
-        rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
-        rec = {"workload": name, "elements": int(ctx.ne), "dof": int(ctx.n), "stored_matrix_mb": info.stored_blocks * 76 / 1e6,
+        rprobe = read_stream_probe(ctx, be, info.stored_blocks * block_bytes)
+        rec = {"workload": name, "elements": int(ctx.ne), "dof": int(ctx.n), "stored_matrix_mb": info.stored_blocks * block_bytes / 1e6,
                "pcg_path": path,
                "spmv": {"kernel": f"k_spmv<{ctx.dm}> inside the PCG solves (vectors in storage order)", "bound": "hbm",
                         "avg_launch_us": spmv_us, "launches_timed": spmv_n, "bytes_per_launch": int(spmv_b), "achieved": spmv_gbs,
@@ -647,8 +657,9 @@ def main():
                          "plate cut into N z-slabs.  A weak run on N > 1 GPUs appends a short strong-scaling record "
                          "(`strong_scaling`) unless --no-strong")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, --scaling weak: skip the appended strong-scaling record")
-    ap.add_argument("--workload", choices=("c3d4", "c3d10"), default="c3d4",
-                    help="c3d4 = BASELINE configs[2]/[3] (the metric's configuration); c3d10 = configs[4], single GPU")
+    ap.add_argument("--workload", choices=("c3d4", "c3d10", "cpe8"), default="c3d4",
+                    help="c3d4 = BASELINE configs[2]/[3] (the metric's configuration); c3d10 = configs[4], single GPU; "
+                         "cpe8 = configs[1] (2-D: generated plane-strain beam, ~1 M DOF), single GPU")
     ap.add_argument("--sample", type=int, default=16, help="time every k-th SpMV launch with HIP events (1 = all)")
     ap.add_argument("--prewarm", type=float, default=4.0, help="seconds of untimed steps before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -697,6 +708,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != N:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {N}")
+    if args.workload == "cpe8":
+        if N > 1 or args.force_comm or args.force_dist:
+            raise SystemExit("--workload cpe8 is BASELINE configs[1], a single-GPU configuration")
+        result = cpe8_line(args, be, meshgen, torch, user_dirichletBC_values)
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
+        return 0
     quadratic = args.workload == "c3d10"
     if quadratic and (N > 1 or args.force_comm):
         raise SystemExit("--workload c3d10 is BASELINE configs[4], a single-GPU configuration")
@@ -914,11 +932,19 @@ def main():
                 ("twist plate C3D4 192x24x288 cells (BASELINE configs[3]'s 7 962 624 elements on ONE GPU)",
                  lambda: meshgen.twist_plate(192, 24, 288), Element_linear_tetrahedral()),
                 ("twist plate C3D10 48x6x72 cells (BASELINE configs[4], 124 416 elements)",
-                 lambda: meshgen.twist_plate(48, 6, 72, quadratic=True), Element_quadratic_tetrahedral())):
+                 lambda: meshgen.twist_plate(48, 6, 72, quadratic=True), Element_quadratic_tetrahedral()),
+                # round 5: the 2-D configuration (BASELINE configs[1]; no CPE8 beam deck is shipped, SURVEY.md 8d: the
+                # 40 x 4 beam of tests/beam_deflection meshed with serendipity quadrilaterals, plane strain, nlgeom)
+                (CPE8_NAME, lambda: meshgen.beam_quad8(*CPE8_CELLS, plane="CPE8"), None)):
             try:
                 msh = gen()
-                recs.append(hbm_bound_record(be, name, msh, ele, LinearIsotropic(*msh["elastic"]),
-                                             user_dirichletBC_values, probe))
+                if ele is None:
+                    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+                    from femcy_amd.material_zoo import LinearIsotropicPlaneStrain
+                    ele, mat = Element_quadratic_quadrilateral(), LinearIsotropicPlaneStrain(*msh["elastic"])
+                else:
+                    mat = LinearIsotropic(*msh["elastic"])
+                recs.append(hbm_bound_record(be, name, msh, ele, mat, user_dirichletBC_values, probe))
                 del msh
             except Exception as e:                               # noqa: BLE001  (never lose the headline line)
                 log(f"[bench] hbm_bound record '{name[:40]}' failed: {e!r}")
@@ -930,6 +956,99 @@ def main():
         real_stdout.flush()
     if use_dist:
         dist.destroy_process_group()
+
+
+def cpe8_line(args, be, meshgen, torch, user_values):
+    """`--workload cpe8`: the contract's line on the 2-D configuration.  One step = femcy_assemble_K (k_geom<8,2> +
+    the CPE8 assembly) + Newton Dirichlet treatment + femcy_pcg(eps = 0, maxit = iters) on the generated plane-strain
+    beam at state S1 (prescribed values of the first increment), inputs resident in HBM.  The dominant kernel is
+    k_spmv<2> (2 x 2 blocks, 36 bytes per stored block): its roofline comes from `hbm_bound_record` of the same mesh
+    (launch to launch between one HIP event pair), PMC traffic from profiles/spmv_traffic.json when recorded."""
+    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+    from femcy_amd.material_zoo import LinearIsotropicPlaneStrain
+    nx, ny = (int(v) for v in args.cells.split(",")[:2]) if args.cells else CPE8_CELLS
+    mesh = meshgen.beam_quad8(nx, ny, plane="CPE8")
+    ele, mat = Element_quadratic_quadrilateral(), LinearIsotropicPlaneStrain(*mesh["elastic"])
+    nodes, el = mesh["nodes"], mesh["elements"]
+    ti = mesh["time_incs"]
+    ctx = be.Context(0)
+    try:
+        ctx.set_mesh(nodes, el)
+        ctx.set_element(ele)
+        ctx.set_material(mat)
+        info = ctx.build_pattern()
+        u, cons = s1_state(nodes, mesh["dirichlet_bc_info"], user_values, t1=ti["ini_inc"], load_ratio=ti["ini_inc"] / ti["max_time"])
+        ctx.upload(be.VEC_DOF, u)
+        ctx.vector(be.VEC_RHS).fill(0.0)
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+        cs = ctx.dofset(cons)
+
+        def step():
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.dofset_dirichlet_newton(cs, be.VEC_RESIDUAL)
+            return ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=args.iters)
+
+        t_warm = time.perf_counter()
+        while args.warmup > 0:
+            step()
+            ctx.sync()
+            if time.perf_counter() - t_warm >= args.prewarm:
+                break
+        ctx.set_option(be.OPT_TIMING, args.sample)
+        for _ in range(args.warmup):
+            step()
+        ctx.timing_reset()
+        on_gpu = os.environ.get("FEMCY_BENCH_DEVICE", "cuda") == "cuda"      # (test hook: the host backend on CPU)
+        if on_gpu:
+            torch.cuda.synchronize()
+        ctx.sync()
+        t0 = time.perf_counter()
+        total = 0
+        for _ in range(args.steps):
+            total += step()[0]
+        ctx.sync()
+        if on_gpu:
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tm = ctx.timing()
+        ctx.set_option(be.OPT_TIMING, 0)
+        spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
+        ne, n, dm = int(ctx.ne), int(ctx.n), int(ctx.dm)
+        nnz = int(info.nnz)
+    finally:
+        ctx.close()
+    probe = hbm_copy_probe(torch) if on_gpu else None
+    name = CPE8_NAME if not args.cells else f"beam CPE8 {nx}x{ny} serendipity quadrilaterals, plane strain, nlgeom"
+    rec = hbm_bound_record(be, name, mesh, ele, mat, user_values, probe)
+    roof = dict(rec["spmv"])
+    traffic, traffic_src = pmc_traffic("cpe8", "k_spmv") if not args.cells else (None, "non-standard --cells")
+    roof.update(traffic=traffic, traffic_source=traffic_src, copy_probe_gbs=probe,
+                pcg_iteration_gbs=rec["pcg_iteration"]["achieved"], pcg_iteration_frac_of_hbm_peak=rec["pcg_iteration"]["frac"],
+                pcg_iteration_us=rec["pcg_iteration"]["us"], pcg_path=rec["pcg_path"])
+    asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
+    # as-written flops of one CPE8 stiffness (B^T C B at 4 Gauss points, B 3 x 16: 2 * (3*3*16 + 16*3*16) * 4)
+    kflop = 2 * (3 * 3 * 16 + 16 * 3 * 16) * 4 / 1e3
+    return {
+        "metric": "CG iters/sec + element-stiffness assemblies/sec, 1M C3D4 elems, 1/2/4/8 GPU",
+        "value": total / elapsed * (ne / ELEMS_PER_GPU["cpe8"]),
+        "unit": f"CG iters/s x (global elements / {ELEMS_PER_GPU['cpe8']})",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{name} (BASELINE configs[1]: the 2-D configuration, not the one the metric is quoted on), "
+                               f"state S1 (first increment, load ratio {ti['ini_inc'] / ti['max_time']}), "
+                               f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
+                   "elements_per_gpu": ne, "dof": n, "cg_iters_per_step": args.iters, "parallelism": "single GPU",
+                   "launcher": "single process"},
+        "cg_iters_per_s": total / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0,
+        "assemblies_per_s": ne / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
+        "assembly_ms": asm_ms,
+        "pcg_us_per_iter": tm["pcg_ms"] * 1e3 / max(total, 1),
+        "spmv_tflops": 2 * nnz / (roof["avg_launch_us"] * 1e-6) / 1e12 if roof.get("avg_launch_us") else 0.0,
+        "assembly_tflops": kflop * 1e3 * ne / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
+        "roofline": roof,
+        "hbm_bound": [rec],
+    }
 
 
 def persist_roofline(ctx, be, tm, args, n, iter_bytes, probe, rank):

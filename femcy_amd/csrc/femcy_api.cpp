@@ -386,7 +386,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             break;
 #endif
         case FEMCY_TUNE_PERSIST_REG_ROWS:   /* test knob: block rows per slice of the persistent PCG kept in registers (0, 4 or 5) */
+#ifdef FEMCY_PERSIST_PIPE
+            FEMCY_REQUIRE(value == 0 || value == 2 || value == 4 || value == 5, "register-resident block rows: 0, 2, 4 or 5");
+#else
             FEMCY_REQUIRE(value == 0 || value == 4 || value == 5, "register-resident block rows: 0, 4 or 5");
+#endif
             c->opt_persist_rj = (int)value;
             break;
         case FEMCY_OPT_PCG_SMALL:

@@ -213,18 +213,21 @@ template <int NV>
 __device__ __forceinline__ bool xrank_reduce(const PersistPcg& a, int base, int parity, uint32_t tag, double (&val)[NV],
                                              const int (&op)[NV]) {
     const int lane = threadIdx.x & 63, R = a.nranks;
-    if (blockIdx.x == 0 && lane < R) {
+    // (round 5) a rank's own value does not travel through its mailbox: lane `rank` takes it from the register.  The
+    // store -> visible -> load round trip on the own fine-grained buffer cost ~1.3 us per exchange, 2.6 us per iteration
+    // (32.2 against 27.0 us with a 1-rank communicator); the values and their order of summation are unchanged
+    if (blockIdx.x == 0 && lane < R && lane != a.rank) {
         unsigned long long* dst = a.peer[lane] + base + (size_t)((parity * R + a.rank) * NV) * 2;
 #pragma unroll
         for (int v = 0; v < NV; ++v) mb_store(dst + 2 * v, val[v], tag);
     }
     double got[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) got[v] = 0.0;
+    for (int v = 0; v < NV; ++v) got[v] = lane == a.rank ? val[v] : 0.0;
     uint32_t spins = 0;
     for (;;) {
         bool ok = true;
-        if (lane < R) {
+        if (lane < R && lane != a.rank) {
             const unsigned long long* src = a.mbox + base + (size_t)((parity * R + lane) * NV) * 2;
 #pragma unroll
             for (int v = 0; v < NV; ++v) ok = mb_load(src + 2 * v, tag, got[v]) && ok;
@@ -486,6 +489,23 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             arm_d(dpos[t], 2 * a.npad * 8);
         }
     }
+    // across ranks: the lane's interface table entries (send entry, recv entry, neighbour | lower << 8, its nb_total) stay
+    // in registers for the whole solve (round 5: they were re-loaded twice per iteration and used at once -- two exposed
+    // L2 round trips on the critical path of every exchange); a wave without an interface lane skips both blocks
+    // (the four-slice shape has no registers to spare: it keeps the wave-uniform flag and re-loads the entries)
+    constexpr bool TABREG = SPW <= 3;
+    int4 mtab[SPW];
+    bool wave_has_if = false;
+#pragma unroll
+    for (int t = 0; t < SPW; ++t) {
+        mtab[t] = make_int4(-1, -1, 0, 0);
+        if (MULTI && sl[t] >= 0) mtab[t] = reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane];
+        if (MULTI) wave_has_if = wave_has_if || __any(mtab[t].x >= 0 || mtab[t].y >= 0);
+    }
+    auto iface_entry = [&](int t) -> int4 {
+        if (TABREG) return mtab[t];
+        return sl[t] >= 0 ? reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane] : make_int4(-1, -1, 0, 0);
+    };
     unsigned round = 0;
     // across ranks: the cross-rank stage of an exchange (wave 0 of every workgroup; the local result is in `val`),
     // result through LDS to every thread
@@ -676,6 +696,61 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                                 acc[t][r] += lvals[((q + u) * DD + r * DM + cc) * 64 + lane] * xg[u][cc];
                     }
             }
+#ifdef FEMCY_PERSIST_PIPE
+            // (round 5 experiment, not in the shipped build) software-pipelined stream: the loads of batch k + 1 are
+            // issued behind the gathers of batch k and travel while batch k is multiplied -- two batches of values in
+            // registers (A / B ping-pong), for matrices that stream from HBM rather than from the Infinity Cache
+            if (j < L && !PDBG(a, 1)) {
+                int32_t colA[CH], colB[CH];
+                double eA[CH][DD], eB[CH][DD];
+                int nbA = min(CH, L - j), nbB = 0;
+                load_rows(bcp, vp, vs, j, nbA, je[t] + a.l2_rows, colA, eA);
+                for (;;) {
+                    {
+                        double xg[CH][DM];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) gather_d(colA[u], poff, xg[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int32_t jn = j + nbA;
+                        nbB = max(0, min(CH, L - jn));
+                        load_rows(bcp, vp, vs, nbB > 0 ? jn : j, nbB, je[t] + a.l2_rows, colB, eB);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                            if (u < nbA) {
+#pragma unroll
+                                for (int r = 0; r < DM; ++r)
+#pragma unroll
+                                    for (int cc = 0; cc < DM; ++cc) acc[t][r] += eA[u][r * DM + cc] * xg[u][cc];
+                            }
+                        j = jn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (nbB == 0) break;
+                    {
+                        double xg[CH][DM];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) gather_d(colB[u], poff, xg[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int32_t jn = j + nbB;
+                        nbA = max(0, min(CH, L - jn));
+                        load_rows(bcp, vp, vs, nbA > 0 ? jn : j, nbA, je[t] + a.l2_rows, colA, eA);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                            if (u < nbB) {
+#pragma unroll
+                                for (int r = 0; r < DM; ++r)
+#pragma unroll
+                                    for (int cc = 0; cc < DM; ++cc) acc[t][r] += eB[u][r * DM + cc] * xg[u][cc];
+                            }
+                        j = jn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (nbA == 0) break;
+                }
+            }
+#endif
             // streamed block rows, CH at a time: columns, then the values, then the gathers, then the multiplies
             while (j < L && !PDBG(a, 1)) {
                 const int nb = min(CH, L - j);
@@ -718,10 +793,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             // interface rows: the partial sums of this rank go straight into the sharing rank's mailbox (system-scope
             // 8-byte words that validate themselves); they travel while the exchanges below run
             const uint32_t tag = mb_tag(a.tagbase, it);
+            if (wave_has_if) {
 #pragma unroll
-            for (int t = 0; t < SPW; ++t)
-                if (sl[t] >= 0) {
-                    const int4 tb = reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane];
+                for (int t = 0; t < SPW; ++t) {
+                    const int4 tb = iface_entry(t);
                     if (tb.x >= 0) {
                         unsigned long long* dst = a.peer[tb.z & 0xff] + mb_ad(a.nranks) +
                                                   ((size_t)(it & 1) * tb.w + tb.x) * 2;
@@ -729,6 +804,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                         for (int c = 0; c < DM; ++c) mb_store(dst + 2 * c, Ad[t][c], tag);
                     }
                 }
+            }
         }
         // the matrix does not change: slice 0's first streamed batch for the NEXT product is requested inside the first
         // exchange (after the arrival, so that it does not delay it) and arrives while the wave waits in the three
@@ -788,10 +864,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             // the neighbour's partial sums of the interface rows, added in ascending rank order on both sides
             const uint32_t tag = mb_tag(a.tagbase, it);
             bool okr = true;
+            if (wave_has_if) {
 #pragma unroll
-            for (int t = 0; t < SPW; ++t)
-                if (sl[t] >= 0) {
-                    const int4 tb = reinterpret_cast<const int4*>(a.mr_tab)[(int64_t)sl[t] * 64 + lane];
+                for (int t = 0; t < SPW; ++t) {
+                    const int4 tb = iface_entry(t);
                     if (tb.y >= 0) {
                         const unsigned long long* src = a.mbox + mb_ad(a.nranks) + ((size_t)(it & 1) * a.nb_total + tb.y) * 2;
 #pragma unroll
@@ -806,6 +882,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                         }
                     }
                 }
+            }
             if (__any(!okr)) s_fail = 1;
             __syncthreads();
             if (s_fail) { done = 3; return; }
@@ -1259,6 +1336,9 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
         if (c->dm == 3 && SPW == 3) {
             if (c->opt_persist_rj == 5) { FEMCY_PERSIST_V(3, 3, 5) }
             else if (c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) }
+#ifdef FEMCY_PERSIST_PIPE
+            else if (c->opt_persist_rj == 2) { FEMCY_PERSIST_V(3, 3, 2) }
+#endif
             else { FEMCY_PERSIST_V(3, 3, 0) }
         } else if (c->dm == 3) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }

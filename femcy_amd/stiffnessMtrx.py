@@ -126,6 +126,7 @@ class System_of_equations:
         self.compiled = False
         self._dofsets = {}
         self._loadsets = {}
+        self.cg_log = []          # one entry per CG solve: iterations, max|r0|, max|r|, increment end time
         self.stats = {"assemblies": 0, "force_evals": 0, "linear_solves": 0, "cg_iterations": 0, "direct_solves": 0,
                       "direct_rejected": 0}
 
@@ -182,6 +183,7 @@ class System_of_equations:
         self.PCG.iterations, self.PCG.r0, self.PCG.rmax = it, r0, rmax
         self.PCG.converged = r0 == 0.0 or rmax < self.PCG.eps * r0
         self.stats["cg_iterations"] += it
+        self.cg_log.append({"iters": it, "r0": r0, "rmax": rmax, "time1": self.time1, "converged": self.PCG.converged})
         return self._take_solution()
 
     def solve_by_scipy(self):

@@ -581,7 +581,13 @@ class OracleSystem:
     increment / modified-Newton / line-search drivers with the reference's control flow."""
 
     def __init__(self, nodes, elements, abaqus_type: str, material: Material, geometric_nonlinear: bool,
-                 linear_solver: str = "reference", cg_eps: float = 1.0e-3, verbose: bool = False):
+                 linear_solver: str = "reference", cg_eps: float = 1.0e-3, verbose: bool = False,
+                 cg_backend: str = "numpy"):
+        """cg_backend "c": the CG branch runs in oracle/femcy_oracle.c (`orc_cg_solve`: the reference's ELL arrays,
+        thread-per-row product, one pass per kernel) -- same recurrence as `pcg_reference`, fast enough for the
+        >= 1e5-DOF systems that take the reference's CG branch (a numpy run of 8e5 iterations would take hours).
+        linear_solver "spsolve": every solve is the sparse LU whatever the size (the limit eps -> 0 of the CG branch:
+        the yardstick for runs whose eps = 1e-3 iterates differ)."""
         self.ed = elem_def(abaqus_type)
         self.topo = Topology(nodes, elements, self.ed)
         self.dm = self.topo.dm
@@ -600,6 +606,8 @@ class OracleSystem:
         self.K = None
         self.linear_solver = linear_solver    # "reference": <1e5 spsolve else CG (stiffnessMtrx.py:272-276)
         self.cg_eps = cg_eps
+        self.cg_backend = cg_backend
+        self._co = None
         self.verbose = verbose
         self.log: List[dict] = []             # one entry per linear solve / residual evaluation
         self.n_solves = 0
@@ -618,9 +626,12 @@ class OracleSystem:
         """solve_dof/solve_by_scipy/solve_by_CG (stiffnessMtrx.py:219-276)."""
         b = self.rhs if not self.geometric_nonlinear else self.residual_nodal_force
         use_cg = (self.linear_solver == "cg") or (self.linear_solver == "reference" and self.dof.shape[0] >= 1e5)
+        assert self.linear_solver in ("cg", "reference", "spsolve")
         if use_cg:
-            x, it, r0, rmax = pcg_reference(self.K, b, eps=self.cg_eps)
-            self.log.append({"solve": "cg", "iters": it, "r0": r0, "rmax": rmax})
+            x, it, r0, rmax = self._cg(b)
+            self.log.append({"solve": "cg", "iters": it, "r0": r0, "rmax": rmax, "time1": self.time1})
+            if self.verbose:
+                print(f"    cg: {it} iterations, r0 = {r0:.6e}, rmax = {rmax:.6e}", flush=True)
         else:
             x = sl.spsolve(self.K.tocsc(), b)
             self.log.append({"solve": "spsolve"})
@@ -631,6 +642,27 @@ class OracleSystem:
         else:
             self.dof = self.dof - self.du
         return self.du
+
+    def _cg(self, b):
+        """ConjugateGradientSolver_rowMajor.solve (conjugateGradientSolver.py:103-127), maxit = n."""
+        if self.cg_backend != "c":
+            return pcg_reference(self.K, b, eps=self.cg_eps)
+        try:
+            from .c_oracle import COracle
+        except ImportError:  # pragma: no cover
+            from c_oracle import COracle
+        if self._co is None:
+            t = self.topo
+            self._co = COracle(t.nodes, t.elements, self.ed.dN_table(), self.ed.gauss_weights, self.C,
+                               t.adj_ptr, t.adj_idx)
+            self._co_mask = np.arange(self._co.W)[None, :] < self._co.ij[:, :1]
+        co = self._co
+        K = self.K
+        # assemble_K keeps the full node-adjacency pattern with sorted columns = the column order of sparseIJ, so the
+        # CSR values ARE the ELL rows (`sparseMtrx_rowMajor`, stiffnessMtrx.py:91-94)
+        assert K.nnz == int(co.ij[:, 0].sum()), "K lost its structural pattern"
+        co.A[self._co_mask] = K.data
+        return co.cg(b, eps=self.cg_eps)
 
     def impose_boundary_condition(self, bcs):
         """stiffnessMtrx.py:504-529."""

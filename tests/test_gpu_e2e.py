@@ -138,6 +138,49 @@ def test_readme_known_answer_end_to_end(tmp_path):
     system.ctx.close()
 
 
+def test_readme_digits_through_the_device_cg_branch():
+    """README.md:70 prints FEMcy's CPS6 sigma_yy at D as 93.32 / 84.40: the stop iterate (128) of the reference's own
+    CG at eps = 1e-3 (conjugateGradientSolver.py:103-127), not the exact solution (93.3125 -> "93.31"); see
+    tests/test_oracle_pins.py::test_readme_numbers_are_the_cg_branch_at_eps_1e3.  The same deck through the product
+    with the reference's CG settings on the device (`femcy_pcg`, eps = 1e-3) must print the same digits: a
+    reference-PRODUCED number for the PCG recurrence + stopping rule on the HIP path.  CPS3: iterate 105 prints the
+    README's 93.56 (the device stops where the oracle does, at 104: 93.635)."""
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    inp = InpInfo(deck("ellip_membrane_quadritic_trig_neumann.inp"))
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], False, verbose=False, direct="pcg", direct_eps=1e-3)
+    system.solve(inp)
+    assert system.PCG.iterations == 128 and system.stats["cg_iterations"] == 128
+    system.compute_strain_stress()
+    sig = system.cauchy_stress.to_numpy()
+    nodal = system.ELE.extrapolate(system.cauchy_stress, None, comp=3)
+    nD = int(np.argmin(np.linalg.norm(inp.nodes - np.array([2., 0.]), axis=1)))
+    e, a = np.where(body.np_elements == nD)
+    assert "%.2f" % nodal[e[0], a[0]] == "93.32" and "%.2f" % sig[e[0], :, 1, 1].max() == "84.40"
+    # (summation orders differ from the oracle's: 128 CG iterations amplify rounding to ~2e-5 relative)
+    assert abs(nodal[e[0], a[0]] - 93.3198) < 4e-3 and abs(sig[e[0], :, 1, 1].max() - 84.3969) < 2e-3
+    system.ctx.close()
+    inp = InpInfo(deck("ellip_membrane_linEle_localVeryFine.inp"))
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], False, verbose=False, direct="pcg", direct_eps=1e-3)
+    system.solve(inp)
+    assert system.PCG.iterations == 104
+    system.compute_strain_stress()
+    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - 93.635) < 5e-3
+    # iterate 105 = the published 93.56: one more loop body than the stop rule asks for
+    system.time1 = 1.0
+    system.dof.fill(0.0)             # K is assembled on nodes + dof (stiffnessMtrx.py:132-150), also for nlgeom = NO
+    system.assemble_stiffnessMtrx()
+    system.impose_boundary_condition({"neumannBCs": inp.neumann_bc_info,
+                                      "dirichletBCs": [dict(bc, node_set=np.asarray([*bc["node_set"]])) for bc in inp.dirichlet_bc_info]})
+    system.solve_by_CG(eps=0.0, maxit=105)
+    system.compute_strain_stress()
+    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - 93.5617) < 5e-3       # README.md:70 "93.56"
+    system.ctx.close()
+
+
 def test_nafems_le1_target_on_the_dense_deck():
     """a reference-independent known answer: the elliptic membrane is NAFEMS LE1, target sigma_yy at D = 92.7 MPa
     (README.md:46).  The reference's densest CPS6 deck, solved and post-processed on the device, gives 92.72."""
