@@ -54,6 +54,7 @@ TUNE_PERSIST_VARIANT = 109   # persistent PCG variant bits (-1 default; femcy.h)
 TUNE_SKIP_OCCUPANCY_CHECK = 111
 TUNE_BARRIER_SPIN_LIMIT = 112
 TUNE_PERSIST_L2_ROWS = 113
+TUNE_PERSIST_MAX_MB = 114   # persistent PCG: streamed-matrix limit in MiB (0 = none, the default since round 5; 240 = rounds 2-4)
 OPT_OVERLAP = 9          # multi-rank, neighbour exchange: 1 (default) = exchange overlapped with the interior product
 ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2, ASM_ROWS3, ASM_ROWS4 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -71,7 +72,7 @@ EXPORTS = [
     "femcy_probe_stream", "femcy_probe_exchange", "femcy_persist_streamed_bytes",
     "femcy_comm_mailbox_export", "femcy_comm_mailbox_import", "femcy_comm_persist_agree",
     "femcy_comm_shm_id", "femcy_comm_allgather_host", "femcy_get_node_order", "femcy_probe_mailbox", "femcy_probe_spmv",
-    "femcy_direct_solve",
+    "femcy_direct_solve", "femcy_direct_plan",
 ]
 
 
@@ -175,6 +176,7 @@ def _bind(lib, kind):
         "femcy_probe_spmv": [p, i32, i32, C.POINTER(f64)],
         "femcy_comm_persist_agree": [p, C.POINTER(i32)],
         "femcy_direct_solve": [p, cint, cint, C.POINTER(DirectInfo)],
+        "femcy_direct_plan": [p, C.POINTER(DirectInfo)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -421,6 +423,13 @@ class Context:
         info = DirectInfo()
         self._call("femcy_direct_solve", int(b_vec), int(x_vec), C.byref(info))
         return {k: getattr(info, k) for k, _ in DirectInfo._fields_ if k != "reserved"}
+
+    def direct_plan(self) -> dict:
+        """the band `direct_solve` would factor for the current pattern (n, bandwidth, panels, band_bytes), without
+        factoring anything"""
+        info = DirectInfo()
+        self._call("femcy_direct_plan", C.byref(info))
+        return {k: getattr(info, k) for k in ("n", "band_bytes", "bandwidth", "panels")}
 
     # -------------------------------------------------------------------------- post-processing
     def compute_strain_stress(self, u_vec: int = VEC_DOF, large: bool = False):

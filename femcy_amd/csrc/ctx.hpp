@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/femcy.h"
@@ -18,6 +19,21 @@ void set_error(const char* fmt, ...);
             return FEMCY_EHIP;                                                                  \
         }                                                                                       \
     } while (0)
+
+// FEMCY_DEBUG_POISON=1 (environment, read once): every device allocation of the library is filled with 0xFF bytes
+// (a NaN as f64, -1 as i32) before it is used.  A kernel that reads memory nobody wrote -- which a fresh process hides,
+// because fresh device memory is zero, and a long-lived one does not, because the allocator hands freed blocks back --
+// then fails deterministically: the race / uninitialised-read check of the -m gpu suite (tools/records/r05_gpu2.sh).
+inline hipError_t malloc_checked(void** p, size_t bytes) {
+    static const bool poison = [] {
+        const char* e = getenv("FEMCY_DEBUG_POISON");
+        return e && e[0] && e[0] != '0';
+    }();
+    const hipError_t rc = hipMalloc(p, bytes);
+    if (rc == hipSuccess && poison && bytes) (void)hipMemset(*p, 0xFF, bytes);
+    return rc;
+}
+#define hipMalloc(p, n) ::femcy::malloc_checked((void**)(p), (n))
 
 #define FEMCY_REQUIRE(cond, ...)                    \
     do {                                            \
@@ -160,8 +176,12 @@ struct Ctx {
     int opt_graph = 1;
     // ---- persistent one-launch PCG for systems of one wavefront-task per SIMD (k_pcg_persist)
     int opt_persist = 1;              // FEMCY_OPT_PCG_PERSIST
-    int64_t persist_max_bytes = (int64_t)240 << 20;   // limit on the STREAMED part of the matrix in the persistent PCG
-                                                      // (Infinity Cache size)
+    // limit on the STREAMED part of the matrix in the persistent PCG.  Rounds 2-4: 240 MiB (the Infinity Cache), from a
+    // round-2 measurement (124 k C3D10, 280 MB streamed: 99-103 us here against 93 with three launches).  Re-measured in
+    // round 5 with the round-4 kernel (nt stream, tagged granules, storage-order d, 16 + 8 byte gathers): 61.0 us
+    // against 78.0 (profiles/r05_persist_hbm_c3d10.txt) -- the rule was stale.  What bounds the kernel is the vector
+    // layout (<= 4 slices per wave), not the matrix: no byte limit by default any more (test knob: option 114)
+    int64_t persist_max_bytes = (int64_t)1 << 40;
     int opt_persist_rj = 4;           // block rows per slice kept in registers (test knob 105)
     int opt_persist_wgs = 0;          // test knob 107: workgroups of the launch (0 = one per CU; more than that cannot
                                       // be co-resident, the barrier times out and the solve falls back)
@@ -334,6 +354,8 @@ int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
 int64_t persist_streamed_bytes(Ctx* c);
 int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps
+int ensure_pos_vectors(Ctx* c);   // d_posb / d_posx (storage-order right-hand side / solution) + d_bcolp
+int spmv_public(Ctx* c, const double* d_x, double* d_y);   // femcy_spmv: node order in and out, storage-order product inside
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);

@@ -367,6 +367,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->opt_persist_multi = (int)value;
             c->persist_multi_failed = false;
             break;
+        case FEMCY_TUNE_PERSIST_MAX_MB:
+            FEMCY_REQUIRE(value >= 0 && value <= (1 << 20), "streamed-matrix limit of the persistent PCG: 0 (none) .. 2^20 MiB");
+            c->persist_max_bytes = value == 0 ? ((int64_t)1 << 40) : ((int64_t)value << 20);
+            break;
         case FEMCY_TUNE_PERSIST_L2_ROWS:
             FEMCY_REQUIRE(value >= 0 && value <= 64, "rows out of range");
             c->opt_persist_l2rows = (int)value;
@@ -978,7 +982,7 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
     VEC_OR_FAIL(x_vec);
     VEC_OR_FAIL(y_vec);
     FEMCY_REQUIRE(x_vec != y_vec, "spmv cannot run in place");
-    int rc = launch_spmv(c, c->d_vec[x_vec], c->d_vec[y_vec], nullptr, nullptr);
+    int rc = spmv_public(c, c->d_vec[x_vec], c->d_vec[y_vec]);
     if (rc) return rc;
     if (c->comm) return iface_sum(c, c->d_vec[y_vec]);
     return FEMCY_OK;
@@ -1003,6 +1007,12 @@ int femcy_direct_solve(femcy_ctx* ctx, int b_vec, int x_vec, femcy_direct_info* 
     VEC_OR_FAIL(x_vec);
     FEMCY_REQUIRE(b_vec != x_vec, "direct solve: b and x must be different vectors");
     return direct_solve(c, c->d_vec[b_vec], c->d_vec[x_vec], info);
+}
+
+int femcy_direct_plan(femcy_ctx* ctx, femcy_direct_info* info) {
+    CTX_OR_FAIL(ctx);
+    FEMCY_REQUIRE(c->have_pattern, "pattern not built");
+    return direct_plan(c, info);
 }
 
 // ------------------------------------------------------------------------------ post-processing

@@ -58,6 +58,8 @@ struct DirectState {
     double* d_norms = nullptr;    // max|res| (NaN if any entry is), max|b|
     int32_t* d_flag = nullptr;    // [0] 1 + first pivot that is zero / NaN, [1] negative pivots
     char* h_back = nullptr;       // pinned: 2 int32 + 2 doubles
+    BandOrder order;              // host copy of the band order of pattern `order_serial`
+    int64_t order_serial = -1;
     void release() {
         for (void* q : {(void*)d_rank, (void*)d_node_at, (void*)d_band, (void*)d_dfac, (void*)d_sgn, (void*)d_invd, (void*)d_wb, (void*)d_wy,
                         (void*)d_wx, (void*)d_res, (void*)d_Kx, (void*)d_norms, (void*)d_flag})
@@ -467,12 +469,22 @@ int alloc(Tp** p, size_t count) {
 }
 
 // order + storage for the current pattern
+// reverse Cuthill-McKee of the current pattern, computed once per pattern and kept on the host (femcy_direct_plan needs
+// only this; femcy_direct_solve uploads it with the band)
+const BandOrder& order_of(Ctx* c, DirectState& st) {
+    if (st.order_serial != c->pattern_serial) {
+        st.order = band_order_rcm(c->nn, c->ne, c->npe, c->h_elems.data());
+        st.order_serial = c->pattern_serial;
+    }
+    return st.order;
+}
+
 int prepare(Ctx* c, DirectState& st) {
     if (st.pattern_serial == c->pattern_serial && st.d_band) return FEMCY_OK;
     const int64_t keep_limit = st.max_bytes;
     st.release();
     st.max_bytes = keep_limit;
-    const BandOrder o = band_order_rcm(c->nn, c->ne, c->npe, c->h_elems.data());
+    const BandOrder& o = order_of(c, st);
     st.half_band_nodes = o.half_band_nodes;
     const int64_t bw = ((int64_t)o.half_band_nodes + 1) * c->dm - 1;
     const int64_t T = (bw + NB - 1) / NB, P = (c->n + NB - 1) / NB;
@@ -519,6 +531,22 @@ void direct_release(Ctx* c) {
 int direct_set_max_bytes(Ctx* c, int64_t bytes) {
     FEMCY_REQUIRE(bytes >= (int64_t)1 << 20, "direct solve: the band limit must be at least 1 MiB");
     state_of(c).max_bytes = bytes;
+    return FEMCY_OK;
+}
+
+int direct_plan(Ctx* c, femcy_direct_info* info) {
+    FEMCY_REQUIRE(info != nullptr, "femcy_direct_plan: info must not be null");
+    FEMCY_REQUIRE(c->dm == 2 || c->dm == 3, "direct solve: dm = %d", c->dm);
+    *info = femcy_direct_info{};
+    DirectState& st = state_of(c);
+    const BandOrder& o = order_of(c, st);
+    const int64_t bw = ((int64_t)o.half_band_nodes + 1) * c->dm - 1;
+    const int64_t T = (bw + NB - 1) / NB, P = (c->n + NB - 1) / NB;
+    info->n = c->n;
+    info->bandwidth = (int32_t)bw;
+    info->panels = (int32_t)P;
+    const double bytes = (double)P * (double)(T + 1) * TS * 8.0;
+    info->band_bytes = bytes < 9.0e18 ? (int64_t)bytes : INT64_MAX;
     return FEMCY_OK;
 }
 

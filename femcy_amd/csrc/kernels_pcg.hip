@@ -1055,6 +1055,45 @@ int launch_spmv(Ctx* c, const double* d_x, double* d_y, double* d_partials, int*
 // kernel + the ~1.5 us boundary between dependent launches.  (Dispatch-attached events on single launches inside a
 // solve read ~5 us high: the profiled packet drains the pipeline -- round 4: 71.1 us against 65.8 us in rocprofv3's
 // kernel trace of the same run.)
+// the two storage-order vectors of a single-rank solve (right-hand side in, solution out) and the block columns as
+// positions; padding lanes start as zeros and are only ever written with zeros
+int ensure_pos_vectors(Ctx* c) {
+    int rc = ensure_bcolp(c);
+    if (rc) return rc;
+    const int64_t need = (int64_t)c->nslices * SLICE * c->dm + 64;
+    if (c->pos_cap < need) {
+        if (c->d_posb) (void)hipFree(c->d_posb);
+        if (c->d_posx) (void)hipFree(c->d_posx);
+        c->d_posb = c->d_posx = nullptr;
+        c->pos_cap = 0;
+        FEMCY_HIP(hipMalloc((void**)&c->d_posb, sizeof(double) * need));
+        FEMCY_HIP(hipMalloc((void**)&c->d_posx, sizeof(double) * need));
+        FEMCY_HIP(hipMemsetAsync(c->d_posb, 0, sizeof(double) * need, c->stream));
+        FEMCY_HIP(hipMemsetAsync(c->d_posx, 0, sizeof(double) * need, c->stream));
+        c->pos_cap = need;
+        pcg_graph_reset(c);
+    }
+    return FEMCY_OK;
+}
+
+// femcy_spmv (round 5): the public product runs the PCG's own storage-order kernel between two permutations (8 n bytes
+// in and out each: 4 % of the C3D10 product's bytes) instead of the node-order kernel, which was 14 % slower on that
+// plate (through_femcy_spmv_frac 0.645 against 0.738, BENCH_r04); multi-rank contexts keep node order
+int spmv_public(Ctx* c, const double* d_x, double* d_y) {
+    if (c->comm || !c->opt_pos_space) return launch_spmv(c, d_x, d_y, nullptr, nullptr);
+    int rc = ensure_pos_vectors(c);
+    if (rc) return rc;
+    const int32_t npos = c->nslices * SLICE;
+    const int pg = (npos + BS - 1) / BS;
+    if (c->dm == 3) hipLaunchKernelGGL((k_to_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
+    else hipLaunchKernelGGL((k_to_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
+    if ((rc = launch_spmv(c, c->d_posb, c->d_posx, nullptr, nullptr, true))) return rc;
+    if (c->dm == 3) hipLaunchKernelGGL((k_from_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
+    else hipLaunchKernelGGL((k_from_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch) {
     FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
     FEMCY_REQUIRE(reps >= 1 && reps <= 100000 && us_per_launch, "probe_spmv: reps 1..1e5");
@@ -1568,21 +1607,8 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     const double* vb = d_b;
     double* vx = d_x;
     if (pos) {
-        int rc = ensure_bcolp(c);
+        int rc = ensure_pos_vectors(c);
         if (rc) return rc;
-        const int64_t need = (int64_t)npos * c->dm + 64;
-        if (c->pos_cap < need) {
-            if (c->d_posb) (void)hipFree(c->d_posb);
-            if (c->d_posx) (void)hipFree(c->d_posx);
-            c->d_posb = c->d_posx = nullptr;
-            c->pos_cap = 0;
-            FEMCY_HIP(hipMalloc((void**)&c->d_posb, sizeof(double) * need));
-            FEMCY_HIP(hipMalloc((void**)&c->d_posx, sizeof(double) * need));
-            FEMCY_HIP(hipMemsetAsync(c->d_posb, 0, sizeof(double) * need, c->stream));
-            FEMCY_HIP(hipMemsetAsync(c->d_posx, 0, sizeof(double) * need, c->stream));
-            c->pos_cap = need;
-            pcg_graph_reset(c);
-        }
         const int pg = (npos + BS - 1) / BS;
         if (c->dm == 3) {
             hipLaunchKernelGGL((k_jacobi_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, c->d_slice_off, c->d_Kvals, c->d_M);

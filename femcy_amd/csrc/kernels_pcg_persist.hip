@@ -1,6 +1,7 @@
 // Jacobi-PCG as ONE persistent launch for single-rank systems that fit one wavefront-task per SIMD (<= 4 slices of
-// 64 rows per wave: ~7e5 DOF on MI355X) and whose matrix streams from the Infinity Cache (<= 240 MiB stored): the
-// headline 1 M-element C3D4 configuration.  DESIGN.md section 3 has the measurements.
+// 64 rows per wave: ~7e5 DOF on MI355X): the headline 1 M-element C3D4 configuration (matrix from the Infinity Cache)
+// and, since round 5, the 124 k C3D10 plate whose 380 MB matrix streams from HBM (61 against 78 us per iteration with
+// three launches).  DESIGN.md section 3 has the measurements.
 //
 // Why: with three launches per iteration (kernels_pcg.hip) the product streams the whole matrix from the Infinity
 // Cache every iteration (198 MB, 31 us) and the two vector kernels are latency-bound launches of 5.6 us each.  Here
@@ -1208,10 +1209,10 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
     int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
     const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
     lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
-    // ... and the part of the matrix that is STREAMED every iteration has to come from the Infinity Cache (256 MiB):
-    // with one wave per SIMD there is little latency hiding for HBM.  Measured: 1.4 M C3D4 elements (277 MB stored,
-    // 100 MB of it resident) 41.7 us per iteration here against 63.1 with three launches; 124 k C3D10 (380 MB stored,
-    // 280 MB streamed) 99-103 us here against 93.
+    // ... the part of the matrix that is STREAMED every iteration may be limited (persist_max_bytes, ctx.hpp; no limit
+    // by default since round 5).  Measured: 1.4 M C3D4 elements (277 MB stored, 100 MB of it resident) 41.7 us per
+    // iteration here against 63.1 with three launches; 124 k C3D10 (380 MB stored, 287 MB streamed from HBM) 61.0 us
+    // here against 78.0 (round 2, before the nt stream / tagged granules / storage-order d: 99-103 against 93).
     const int rj = c->dm == 3 ? (SPW == 3 ? c->opt_persist_rj : (c->opt_persist_rj ? 3 : 0)) : (c->opt_persist_rj ? 5 : 0);
     const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
     const int64_t kbytes = c->stored_rows * row_bytes;

@@ -416,7 +416,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->direct_max_bytes = value;
             return FEMCY_OK;
         default:
-            if (option >= 100 && option <= 113) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
+            if (option >= 100 && option <= 114) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
             set_error("unknown option %d", option);
             return FEMCY_EINVAL;
     }
@@ -895,6 +895,22 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
     VEC_OR_FAIL(y_vec);
     REQUIRE(x_vec != y_vec, "spmv cannot run in place");
     spmv(c, c->vec[x_vec].data(), c->vec[y_vec].data(), nullptr);
+    return FEMCY_OK;
+}
+
+int femcy_direct_plan(femcy_ctx* ctx, femcy_direct_info* info) {
+    CTX_OR_FAIL(ctx);
+    REQUIRE(c->have_pattern, "pattern not built");
+    REQUIRE(info != nullptr, "femcy_direct_plan: info must not be null");
+    if (!c->have_band_order) {
+        c->band_order = band_order_rcm(c->nn, c->ne, c->npe, c->elems.data());
+        c->have_band_order = true;
+    }
+    *info = femcy_direct_info{};
+    const int64_t bw = ((int64_t)c->band_order.half_band_nodes + 1) * c->dm - 1;
+    info->n = c->n;
+    info->bandwidth = (int32_t)bw;
+    info->band_bytes = (int64_t)((double)c->n * (double)(bw + 1) * 8.0);
     return FEMCY_OK;
 }
 

@@ -40,7 +40,7 @@ class System_of_equations:
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
                  part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce",
-                 gather_blobs=None, direct: str = "cholesky"):
+                 gather_blobs=None, direct: str = "auto"):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -53,9 +53,18 @@ class System_of_equations:
         self.C = material.C
         self.verbose = verbose
         self.direct_eps, self.cg_eps = direct_eps, cg_eps
-        if direct not in ("cholesky", "pcg"):
-            raise ValueError("direct must be 'cholesky' (band factorisation on the device) or 'pcg' (tight PCG)")
+        if direct not in ("auto", "cholesky", "pcg"):
+            raise ValueError("direct must be 'auto' (default: whichever of the two is faster on this system), 'cholesky' "
+                             "(band factorisation on the device) or 'pcg' (tight PCG)")
         self.direct = direct
+        # direct = "auto": both stand-ins for the reference's spsolve return the solution to ~1e-12, so which one runs is
+        # a question of time only.  The band factorisation costs n * bandwidth^2 flops behind a chain of dependent
+        # launches (~20 us per panel of 32 unknowns + the tile updates), the tight PCG iterations * (matrix bytes /
+        # memory bandwidth); on 2-D decks and small 3-D ones the factorisation wins by 2 ... 20 x, on 3-D meshes of
+        # 3e4 ... 1e5 DOF (bands of 1 300 ... 2 900 sub-diagonals) the PCG is up to 2 x faster
+        # (profiles/r04_direct_limit.txt).  First solve: by the band (femcy_direct_plan); from then on by the measured
+        # times of both (the other one is tried once, on the second solve, if the first took more than 5 ms).
+        self._auto = {"first": None, "ms": {}, "tried": set(), "pcg_ok": True, "pick": None}
 
         # ---- device state: mesh, element tables, material, sparsity pattern
         self.ctx = ctx if ctx is not None else be.Context(device)
@@ -186,9 +195,65 @@ class System_of_equations:
         self.cg_log.append({"iters": it, "r0": r0, "rmax": rmax, "time1": self.time1, "converged": self.PCG.converged})
         return self._take_solution()
 
+    AUTO_WIDE_BAND = 1280        # sub-diagonals above which the FIRST solve of direct = "auto" goes to the tight PCG
+    AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
+
+    def _auto_method(self) -> str:
+        """direct = "auto": 'cholesky' or 'pcg' for the next solve of the reference's direct branch."""
+        a = self._auto
+        if a["pick"] is not None:
+            return a["pick"]
+        if a["first"] is None:
+            try:
+                plan = self.ctx.direct_plan()
+                wide = plan["bandwidth"] > self.AUTO_WIDE_BAND
+                a["plan"] = plan
+            except (be.FemcyError, AttributeError):
+                wide = False
+            a["first"] = "pcg" if wide else "cholesky"
+            return a["first"]
+        other = "pcg" if a["first"] == "cholesky" else "cholesky"
+        if other == "pcg" and not a["pcg_ok"]:
+            a["pick"] = "cholesky"
+        elif other not in a["tried"] and a["ms"].get(a["first"], 0.0) > self.AUTO_TRY_OTHER_MS:
+            return other
+        elif other in a["ms"] and a["first"] in a["ms"]:
+            a["pick"] = min(a["ms"], key=a["ms"].get)
+        else:
+            a["pick"] = a["first"]
+        return a["pick"]
+
     def solve_by_scipy(self):
-        """the reference's direct branch (`spsolve`, :219-251; the name is kept): band Cholesky on the device."""
-        if self.part is None and self.direct == "cholesky":
+        """the reference's direct branch (`spsolve`, :219-251; the name is kept): band Cholesky on the device, or the
+        tight PCG where that is faster (direct = "auto")."""
+        if self.part is None and self.direct == "auto":
+            method = self._auto_method()
+            a = self._auto
+            self.ctx.sync()
+            t0 = time.perf_counter()
+            if method == "pcg":
+                a["tried"].add("pcg")
+                du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
+                if self.PCG.converged:
+                    a["ms"]["pcg"] = min(a["ms"].get("pcg", 1e30), (time.perf_counter() - t0) * 1e3)
+                    return du
+                # not converged within 10 n iterations (nu -> 0.5, an indefinite Newton iterate): this solve is redone
+                # by the factorisation, and the PCG is out of the race for this system
+                a["pcg_ok"], a["pick"] = False, "cholesky"
+                self.stats["linear_solves"] -= 1
+                if self.geometric_nonlinear:
+                    tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, 1.0, self.PCG.x)       # undo dof -= x
+                t0 = time.perf_counter()
+            a["tried"].add("cholesky")
+            du = self._solve_direct()
+            if self.direct_info is not None:
+                a["ms"]["cholesky"] = min(a["ms"].get("cholesky", 1e30), (time.perf_counter() - t0) * 1e3)
+            return du
+        return self._solve_direct()
+
+    def _solve_direct(self):
+        self.direct_info = None
+        if self.part is None and self.direct in ("cholesky", "auto"):
             self._linear_system()
             try:
                 self.direct_info = self.ctx.direct_solve(self.PCG.b.id, self.PCG.x.id)

@@ -193,6 +193,10 @@ enum femcy_option {
                                         of the barrier time-out and its fallback)                                   */
     FEMCY_TUNE_PERSIST_L2_ROWS = 113,/* persistent PCG with non-temporal matrix stream (variant bit 1): streamed block rows
                                         per slice that keep the default cache policy (they stay in the XCD's L2)     */
+    FEMCY_TUNE_PERSIST_MAX_MB = 114, /* persistent PCG: largest STREAMED part of the matrix (MiB) it takes; 0 = no limit
+                                        (default since round 5: 61 against 78 us per iteration on the 124 k C3D10 plate
+                                        whose 287 MB stream comes from HBM); rounds 2-4 used 240 (tests, comparison
+                                        records)                                                                     */
     FEMCY_TUNE_BARRIER_SPIN_LIMIT = 112 /* polls (each ~0.3-1 us) before a grid barrier of the one-launch solvers gives
                                         up, poisons the exchange and the solve is redone by the three-kernel loop
                                         (default 2^20, about half a second; 0 provokes the fallback: tests)         */
@@ -337,6 +341,13 @@ typedef struct femcy_direct_info {
     double residual;         /* max|b - K x| / max|b| of the returned x */
 } femcy_direct_info;
 int femcy_direct_solve(femcy_ctx* ctx, int b_vec, int x_vec, femcy_direct_info* info /* nullable */);
+/* What femcy_direct_solve WOULD factor for the current pattern, without factoring: n, bandwidth (after reverse
+ * Cuthill-McKee), panels and band_bytes are filled, everything else is zero.  The reference's switch between its two
+ * solvers is a fixed DOF count (`solve_dof`, stiffnessMtrx.py:272-276); the host driver here also looks at the band --
+ * n * bandwidth^2 flops against iterations * (matrix bytes / bandwidth of the memory) -- before it takes the direct
+ * branch (femcy_amd/stiffnessMtrx.py, direct = "auto").  Never FEMCY_ENOMEM: a band beyond the limit is reported, not
+ * refused. */
+int femcy_direct_plan(femcy_ctx* ctx, femcy_direct_info* info);
 
 /* ------------------------------------------------------------------------ post-processing */
 /* compute_strain_stress (stiffnessMtrx.py:436-501): F at vec[u]; strain (infinitesimal, or Green when

@@ -219,10 +219,56 @@ def test_driver_takes_the_direct_branch_and_falls_back_loudly(capsys):
         out.append((system.dof.to_numpy(), dict(system.stats), system.direct))
         system.ctx.close()
     (u0, s0, d0), (u1, s1, d1) = out
-    assert d0 == "cholesky" and s0["direct_solves"] == s0["linear_solves"] == 1 and s0["cg_iterations"] == 0
+    assert d0 == "auto" and s0["direct_solves"] == s0["linear_solves"] == 1 and s0["cg_iterations"] == 0   # narrow band: the factorisation
     assert d1 == "pcg" and s1["direct_solves"] == 0 and s1["cg_iterations"] > 3498     # more than n iterations at nu = 0.4999
     assert "tight PCG instead" in capsys.readouterr().out
     assert np.linalg.norm(u1 - u0) <= 1e-6 * np.linalg.norm(u0)
+
+
+def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
+    """direct = "auto" (the default): the reference switches solvers on a DOF count alone (stiffnessMtrx.py:272-276); here
+    the stand-in for its spsolve is chosen by the band first (femcy_direct_plan) and by measured times afterwards.
+    A cube-like 3-D mesh (27.8 k DOF, 1 328 sub-diagonals: n * bw^2 = 4.9e10 flops behind 869 dependent panels) starts
+    with the tight PCG; the 2-D decks and the slender twist plates start -- and stay -- with the factorisation.  Either
+    way the answer is the factorisation's to 1e-9."""
+    from types import SimpleNamespace
+    from femcy_amd import meshgen
+    from femcy_amd.body import Body
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    m = meshgen.twist_plate(20, 20, 20)
+    ELE = Element_linear_tetrahedral()
+    ti = dict(m["time_incs"], ini_inc=0.002, max_inc=0.002, max_time=0.004)         # two small increments of twist
+    inp = SimpleNamespace(nodes=m["nodes"], eSets={"C3D4": m["elements"]}, ELE=ELE, dirichlet_bc_info=m["dirichlet_bc_info"],
+                          neumann_bc_info=[], time_incs=ti, geometric_nonlinear=True,
+                          materials={"Elastic": LinearIsotropic(*m["elastic"])})
+    res = {}
+    for mode in ("auto", "cholesky"):
+        s = System_of_equations(Body(inp.nodes, m["elements"], ELE), inp.materials["Elastic"], True, verbose=False, direct=mode)
+        plan = s.ctx.direct_plan()
+        assert plan["n"] == m["nodes"].size and plan["bandwidth"] > s.AUTO_WIDE_BAND and plan["panels"] in (0, (plan["n"] + 31) // 32)   # (0: the host backend has no panels)
+        s.solve(inp)
+        res[mode] = (s.dof.to_numpy(), dict(s.stats), dict(s._auto), [dict(i) for i in s.increments])
+        s.ctx.close()
+    (ua, sa, auto, inca), (uc, sc, _, incc) = res["auto"], res["cholesky"]
+    assert auto["first"] == "pcg" and sa["cg_iterations"] > 0 and sa["linear_solves"] == sc["linear_solves"] >= 2
+    assert set(auto["ms"]) == {"pcg", "cholesky"} and auto["pick"] == min(auto["ms"], key=auto["ms"].get)   # both timed, the faster kept
+    assert sc["cg_iterations"] == 0 and sc["direct_solves"] == sc["linear_solves"]
+    assert [(i["time1"], i["converged"], i["newton_loop"]) for i in inca] == [(i["time1"], i["converged"], i["newton_loop"]) for i in incc]
+    assert np.linalg.norm(ua - uc) <= 1e-9 * np.linalg.norm(uc)
+    print(f"[auto] 20^3 cube: plan {plan}, first {auto['first']}, ms {auto['ms']}, pick {auto['pick']}")
+    # a deck with a narrow band: the factorisation from the first solve on, the PCG never runs
+    inp2, el2, mat2 = load("twist_plate_C3D4.inp")
+    s = System_of_equations(Body(inp2.nodes, el2, inp2.ELE), mat2, inp2.geometric_nonlinear, verbose=False)
+    assert s.direct == "auto" and s.ctx.direct_plan()["bandwidth"] < s.AUTO_WIDE_BAND
+    inp2.time_incs = dict(inp2.time_incs, max_time=0.05)                 # the first increment of the deck
+    s.solve(inp2)
+    assert s._auto["first"] == "cholesky" and s.stats["linear_solves"] > 0
+    # (the other method is timed once only if the first solve took more than 5 ms: 0.6 ms on the device, more on the host backend)
+    assert s.stats["cg_iterations"] == 0 or s._auto["ms"]["cholesky"] > s.AUTO_TRY_OTHER_MS
+    assert s.stats["cg_iterations"] > 0 or s.stats["direct_solves"] == s.stats["linear_solves"]
+    s.ctx.close()
 
 
 def test_direct_solve_refuses_a_partitioned_system(gpu_ctx_factory):

@@ -190,7 +190,8 @@ def test_persistent_pcg_two_dimensional_blocks(gpu_ctx_factory):
 def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
     """above 3 x 128 slices per XCD range a wave owns up to FOUR slices (SPW = 4 instantiation, 3 register rows per
     slice): a 1.09 M-element C3D4 plate (200 889 nodes = 3 139 slices, 217 MB of matrix: still Infinity-Cache size).
-    And the 124 k C3D10 plate (380 MB) is NOT taken by default -- its matrix streams from HBM -- but runs when forced."""
+    And the 124 k C3D10 plate (380 MB; 287 MB of it streamed from HBM every iteration) IS taken by default since round 5:
+    the 240 MiB rule of rounds 2-4 rested on a round-2 measurement and was stale (profiles/r05_persist_hbm_c3d10.txt)."""
     import time
     from femcy_amd import meshgen
     from femcy_amd.element_zoo import Element_linear_tetrahedral, Element_quadratic_tetrahedral
@@ -215,13 +216,23 @@ def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
     mq = meshgen.twist_plate(48, 6, 72, quadratic=True)
     be, ctx, info, b = _system(gpu_ctx_factory, mq, Element_quadratic_tetrahedral())
     before = _paths(ctx)
+    ctx.set_option(be.TUNE_PERSIST_MAX_MB, 240)            # the rule of rounds 2-4: streamed part within the Infinity Cache
     (it0, r00, rm0), x0 = _solve(ctx, be, 0.0, 20)
-    assert _paths(ctx)[0] - before[0] == 1                 # default: three launches (matrix beyond the Infinity Cache)
-    ctx.set_option(be.OPT_PCG_PERSIST, 2)
+    assert _paths(ctx)[0] - before[0] == 1                 # ... three launches for this matrix
+    ctx.set_option(be.TUNE_PERSIST_MAX_MB, 0)              # default since round 5: no byte limit (61 against 78 us / iteration)
     (it1, r01, rm1), x1 = _solve(ctx, be, 0.0, 20)
     assert _paths(ctx)[2] - before[2] == 1
     assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= 1e-11 * rm0
     assert np.linalg.norm(x1 - x0) <= 1e-11 * np.linalg.norm(x0)
+    us = {}
+    for mb in (240, 0):
+        ctx.set_option(be.TUNE_PERSIST_MAX_MB, mb)
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)
+        t = time.perf_counter()
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)
+        us[mb] = (time.perf_counter() - t) / 300 * 1e6
+    print(f"[124 k C3D10, matrix streamed from HBM] three launches {us[240]:.1f} us / iteration, persistent {us[0]:.1f}")
+    assert us[0] < us[240]                                 # the form that is chosen by default is the faster one
     ctx.close()
 
 
