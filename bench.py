@@ -255,13 +255,17 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)          # warm: clocks, caches, lazy allocations
         spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
         # (a) the product through the public entry point femcy_spmv (vectors in the caller's node order)
-        ctx.set_option(be.OPT_TIMING, 1)
-        ctx.timing_reset()
+        # (round 5: femcy_spmv = permutation in + the storage-order product + permutation out; timed as whole calls
+        # between two synchronisations, so the permutations are in the figure)
+        for _ in range(3):
+            ctx.spmv(be.VEC_RESIDUAL, be.VEC_TMP0)
+        ctx.sync()
+        t_api = time.perf_counter()
         for _ in range(spmv_reps):
             ctx.spmv(be.VEC_RESIDUAL, be.VEC_TMP0)
-        tm = ctx.timing()
-        api_us = tm["spmv_ms"] * 1e3 / max(tm["spmv_launches"], 1)
-        api_n = int(tm["spmv_launches"])
+        ctx.sync()
+        api_us = (time.perf_counter() - t_api) / spmv_reps * 1e6
+        api_n = spmv_reps
         # (b) the product as the three-launch PCG runs it (round 4: vectors in storage order) -- dispatch-attached events
         # on every 4th launch inside whole solves.  (Round 5: a system that fits the persistent kernel's vector layout
         # takes ONE launch per solve whatever the size of its matrix -- the C3D10 plate -- so the product kernel is
@@ -894,7 +898,16 @@ def main():
                                    (" (strong scaling: the 1 M mesh cut into N)" if strong else "")) if N > 1 else "single GPU",
                    "launcher": "self-launched torch.distributed.run" if os.environ.get("FEMCY_BENCH_SELF_LAUNCHED") else
                                ("torch.distributed.run" if world_env is not None else "single process"),
-                   "interface_exchange": exchange, "persistent_pcg_across_ranks": pmulti},
+                   "interface_exchange": exchange, "persistent_pcg_across_ranks": pmulti,
+                   "transport": (None if not use_comm else
+                                 ("shared-memory TEST transport (N processes on one GPU, host-staged collectives with two "
+                                  "stream synchronisations each): exercises the host steps, its timings say nothing about RCCL"
+                                  if os.environ.get("FEMCY_BENCH_TRANSPORT") == "shm" else "RCCL"))},
+        # the step of rounds 1-3 held 500 PCG iterations (--iters 500 --steps 10): since round 4 the one assembly per step
+        # is amortised over 1000, so `value` is NOT comparable with BENCH_r03 and earlier; `cg_iters_per_s` (PCG time
+        # only) and `assemblies_per_s` are
+        "notes": f"step = 1 assembly + Dirichlet + {args.iters} PCG iterations (500 until round 3); compare rounds through "
+                 f"cg_iters_per_s / pcg_us_per_iter / assembly_ms, which do not depend on the step definition",
         "cg_iters_per_s": cg_only * scale,
         "assemblies_per_s": ne_global / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,
@@ -1039,16 +1052,26 @@ def cpe8_line(args, be, meshgen, torch, user_values):
         spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
         ne, n, dm = int(ctx.ne), int(ctx.n), int(ctx.dm)
         nnz = int(info.nnz)
+        probe = hbm_copy_probe(torch) if on_gpu else None
+        # the dominant kernel of the timed region: since round 5 a 2-D system of up to 8 192 slices takes the persistent
+        # kernel (k_pcg_persist<2, 8, 2>: eight slices per wave); otherwise the product of the three-launch loop
+        persist = tm["persist_launches"] > 0 and tm["spmv_launches"] == 0
+        roof = persist_roofline(ctx, be, tm, args, n, iter_b, probe, 0) if persist else None
     finally:
         ctx.close()
-    probe = hbm_copy_probe(torch) if on_gpu else None
     name = CPE8_NAME if not args.cells else f"beam CPE8 {nx}x{ny} serendipity quadrilaterals, plane strain, nlgeom"
     rec = hbm_bound_record(be, name, mesh, ele, mat, user_values, probe)
-    roof = dict(rec["spmv"])
-    traffic, traffic_src = pmc_traffic("cpe8", "k_spmv") if not args.cells else (None, "non-standard --cells")
+    kernel = "k_pcg_persist" if persist else "k_spmv"
+    if roof is None:
+        roof = dict(rec["spmv"])
+    traffic, traffic_src = pmc_traffic("cpe8", kernel) if not args.cells else (None, "non-standard --cells")
     roof.update(traffic=traffic, traffic_source=traffic_src, copy_probe_gbs=probe,
                 pcg_iteration_gbs=rec["pcg_iteration"]["achieved"], pcg_iteration_frac_of_hbm_peak=rec["pcg_iteration"]["frac"],
-                pcg_iteration_us=rec["pcg_iteration"]["us"], pcg_path=rec["pcg_path"])
+                pcg_iteration_us=rec["pcg_iteration"]["us"], pcg_path=rec["pcg_path"],
+                spmv_launch_to_launch_us=rec["spmv"]["avg_launch_us"], spmv_frac_of_hbm_peak=rec["spmv"]["frac"])
+    if traffic is not None and roof.get("avg_launch_us", 0) > 0:
+        roof["traffic_gbs"] = traffic / (roof["avg_launch_us"] * 1e-6) / 1e9
+        roof["traffic_over_moved"] = traffic / roof["bytes_per_launch"] if roof.get("bytes_per_launch") else None
     asm_ms = (tm["geom_ms"] + tm["assemble_ms"]) / max(tm["assemble_launches"], 1)
     # as-written flops of one CPE8 stiffness (B^T C B at 4 Gauss points, B 3 x 16: 2 * (3*3*16 + 16*3*16) * 4)
     kflop = 2 * (3 * 3 * 16 + 16 * 3 * 16) * 4 / 1e3
@@ -1067,7 +1090,7 @@ def cpe8_line(args, be, meshgen, torch, user_values):
         "assemblies_per_s": ne / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,
         "pcg_us_per_iter": tm["pcg_ms"] * 1e3 / max(total, 1),
-        "spmv_tflops": 2 * nnz / (roof["avg_launch_us"] * 1e-6) / 1e12 if roof.get("avg_launch_us") else 0.0,
+        "spmv_tflops": 2 * nnz / (rec["spmv"]["avg_launch_us"] * 1e-6) / 1e12 if rec["spmv"].get("avg_launch_us") else 0.0,
         "assembly_tflops": kflop * 1e3 * ne / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
         "roofline": roof,
         "hbm_bound": [rec],

@@ -490,11 +490,12 @@ int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs) {
     // remote writes into a coarse-grained allocation are not guaranteed to become visible to a running kernel's polls:
     // without a fine-grained mailbox (here or on a peer) this rank votes for the RCCL loop instead of stalling in the
     // bounded spin of its first solve
+    for (int r = 0; r < R; ++r)                                   // nothing of a blob is believed before it is validated
+        FEMCY_REQUIRE(std::memcmp(B[r].magic, MBOX_MAGIC, 8) == 0 && B[r].rank == r && B[r].nranks == R,
+                      "blob %d is not the mailbox of rank %d of %d", r, r, R);
     bool ok = c->mbox_finegrained;
     for (int r = 0; r < R; ++r) ok = ok && (R == 1 || B[r].finegrained != 0);
     for (int r = 0; r < R; ++r) {
-        FEMCY_REQUIRE(std::memcmp(B[r].magic, MBOX_MAGIC, 8) == 0 && B[r].rank == r && B[r].nranks == R,
-                      "blob %d is not the mailbox of rank %d of %d", r, r, R);
         if (r == c->rank) {
             c->h_peer_mbox[r] = c->d_mbox;
             continue;

@@ -30,7 +30,13 @@ inline hipError_t malloc_checked(void** p, size_t bytes) {
         return e && e[0] && e[0] != '0';
     }();
     const hipError_t rc = hipMalloc(p, bytes);
-    if (rc == hipSuccess && poison && bytes) (void)hipMemset(*p, 0xFF, bytes);
+    if (rc == hipSuccess && poison && bytes) {
+        // the fill runs on the null stream, the library's work on its own (non-blocking) stream: without the device-wide
+        // synchronisation the fill can land AFTER the first copy into the new buffer (round 5, first poisoned run: index
+        // arrays of -1 and a memory fault that was the checker's own)
+        (void)hipMemset(*p, 0xFF, bytes);
+        (void)hipDeviceSynchronize();
+    }
     return rc;
 }
 #define hipMalloc(p, n) ::femcy::malloc_checked((void**)(p), (n))

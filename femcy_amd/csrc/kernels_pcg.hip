@@ -740,7 +740,9 @@ __global__ void __launch_bounds__(BS) k_update_fused(XcdRanges er, int np1, cons
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) st->done = 3;                     // every workgroup that gets here writes the same verdict
+        // the time-out verdict wins over whatever workgroup 0 concludes from a sweep that happened to complete for it
+        // (the granule reads of one sweep are not atomic: verdicts can be mixed inside one launch)
+        if (tid == 0) atomicMax(&st->done, 3);
         return;
     }
     const double rMr_new = bc[0], rmax = bc[1];
@@ -764,9 +766,9 @@ __global__ void __launch_bounds__(BS) k_update_fused(XcdRanges er, int np1, cons
         st->iters = it + 1;
         st->xround = tag;
         if (rmax != rmax || isinf(rmax) || rMr_new != rMr_new)
-            st->done = 2;
+            atomicMax(&st->done, 2);
         else if (rmax < st->eps * st->r0)
-            st->done = 1;
+            atomicMax(&st->done, 1);
     }
 }
 

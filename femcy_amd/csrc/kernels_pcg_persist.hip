@@ -1160,15 +1160,44 @@ int ensure_bcolp(Ctx* c) {
 constexpr int PERSIST_MULTI_RETRY = 16;   // RCCL-loop solves after a cross-rank time-out before the one-launch path is tried again
 
 int64_t persist_streamed_bytes(Ctx* c);
+
+// the launch shape of the persistent kernel for this pattern: slices per wave (SPW: the kernel's register arrays),
+// block rows per slice in registers (RJ) and per wave in LDS.  3 x 3 blocks: SPW 3 (RJ 4 / 5) or 4 (RJ 3) -- up to
+// 4 096 slices = 786 k DOF; 2 x 2 blocks (round 5): additionally SPW 6 (RJ 3) and 8 (RJ 2) -- a lane's vectors take
+// 20 registers per slice instead of 30, a block row 9 instead of 19 -- up to 8 192 slices = 1.05 M DOF in 2-D
+// (BASELINE configs[1] at the size of the 3-D headline system).  false = the pattern does not fit.
+struct PersistShape { int G, nwx, SPW, rj, lds_rows; int32_t maxrange; };
+bool persist_shape(const Ctx* c, PersistShape* out) {
+    PersistShape sh{};
+    sh.G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;   // one workgroup per CU
+    if (sh.G < PNX || !c->have_pattern) return false;
+    sh.nwx = (sh.G / PNX) * 4;
+    sh.maxrange = 0;
+    for (int k = 0; k < PNX; ++k) sh.maxrange = std::max(sh.maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
+    const int per_wave = (sh.maxrange + sh.nwx - 1) / sh.nwx;
+    const bool on = c->opt_persist_rj != 0;
+    if (c->dm == 3) {
+        if (per_wave > 4) return false;
+        sh.SPW = per_wave > 3 ? 4 : 3;
+        sh.rj = sh.SPW == 3 ? c->opt_persist_rj : (on ? 3 : 0);
+    } else {
+        if (per_wave > 8) return false;
+        sh.SPW = per_wave > 6 ? 8 : (per_wave > 4 ? 6 : (per_wave > 3 ? 4 : 3));
+        sh.rj = !on ? 0 : (sh.SPW == 8 ? 2 : (sh.SPW == 6 ? 3 : 5));
+    }
+    const int DD = c->dm * c->dm;
+    int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
+    sh.lds_rows = std::max(0, std::min(lds_rows, sh.SPW * (int)c->max_row_blocks));
+    *out = sh;
+    return true;
+}
+
 // does the system of this context take the persistent kernel?  (the multi-rank agreement)
 bool persist_pattern_fits(Ctx* c) {
     if (!c->opt_persist || !c->have_pattern) return false;
-    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;
-    if (G < PNX) return false;
-    const int nwx = (G / PNX) * 4;
-    int32_t maxrange = 0;
-    for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    if (maxrange > 4 * nwx || c->dm != 3) return false;          // (the multi-rank kernel is instantiated for 3 x 3 blocks)
+    PersistShape sh;
+    if (!persist_shape(c, &sh) || c->dm != 3) return false;      // (the multi-rank kernel is instantiated for 3 x 3 blocks)
+    const int G = sh.G;
     if (c->opt_persist >= 2) return true;
     // evaluated here once so that every rank applies the same verdict: the streamed part of the matrix fits the
     // Infinity Cache.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
@@ -1195,25 +1224,21 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
         }
     }
     if (multi && (!c->persist_multi || c->persist_multi_failed || !c->opt_persist_multi)) return FEMCY_OK;
-    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;   // one workgroup per CU
-    if (G < PNX) return FEMCY_OK;
-    const int nwx = (G / PNX) * 4;
-    int32_t maxrange = 0;
-    for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    // every wave gets its slices (<= 4), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
+    PersistShape sh;
+    if (!persist_shape(c, &sh)) return FEMCY_OK;
+    const int G = sh.G, nwx = sh.nwx;
+    // every wave gets its slices (<= 4; <= 8 in 2-D), and the chip is filled 1.5 times over: below ~380 slices the 13 us of
     // synchronisation per iteration exceed the (graph-replayed) three-launch iteration (size sweep in DESIGN.md)
     // (FEMCY_OPT_PCG_PERSIST = 2 takes any system whose slices fit; waves without a slice idle through the exchanges)
     // across ranks every rank must take the same path: only the rule the agreement checked applies there
-    if (maxrange > 4 * nwx || ((c->nslices < G + G / 2) && c->opt_persist < 2 && !multi)) return FEMCY_OK;
+    if ((c->nslices < G + G / 2) && c->opt_persist < 2 && !multi) return FEMCY_OK;
     const int DD = c->dm * c->dm;
-    int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
-    const int SPW = maxrange > 3 * nwx ? 4 : 3;                   // slices per wave (the kernel's register arrays)
-    lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
+    const int SPW = sh.SPW, lds_rows = sh.lds_rows;               // slices per wave (the kernel's register arrays)
     // ... the part of the matrix that is STREAMED every iteration may be limited (persist_max_bytes, ctx.hpp; no limit
     // by default since round 5).  Measured: 1.4 M C3D4 elements (277 MB stored, 100 MB of it resident) 41.7 us per
     // iteration here against 63.1 with three launches; 124 k C3D10 (380 MB stored, 287 MB streamed from HBM) 61.0 us
     // here against 78.0 (round 2, before the nt stream / tagged granules / storage-order d: 99-103 against 93).
-    const int rj = c->dm == 3 ? (SPW == 3 ? c->opt_persist_rj : (c->opt_persist_rj ? 3 : 0)) : (c->opt_persist_rj ? 5 : 0);
+    const int rj = sh.rj;
     const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
     const int64_t kbytes = c->stored_rows * row_bytes;
     const int64_t resident = (int64_t)G * 4 * (SPW * rj + lds_rows) * row_bytes;   // upper bound (short slices hold less)
@@ -1345,8 +1370,12 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
         } else if (SPW == 3) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }
-        } else {
+        } else if (SPW == 4) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 4, 5) } else { FEMCY_PERSIST_V(2, 4, 0) }
+        } else if (SPW == 6) {
+            if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 6, 3) } else { FEMCY_PERSIST_V(2, 6, 0) }
+        } else {
+            if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 8, 2) } else { FEMCY_PERSIST_V(2, 8, 0) }
         }
 #endif
 #undef FEMCY_PERSIST_V
@@ -1546,17 +1575,9 @@ int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round) {
 // bytes of the matrix the persistent kernel streams per iteration on this context (stored - register / LDS rows), 0
 // when the system would not take the persistent path
 int64_t persist_streamed_bytes(Ctx* c) {
-    const int G = ((c->opt_persist_wgs > 0 ? c->opt_persist_wgs : c->persist_cus) / PNX) * PNX;
-    if (G < PNX || !c->have_pattern) return 0;
-    const int nwx = (G / PNX) * 4;
-    int32_t maxrange = 0;
-    for (int k = 0; k < PNX; ++k) maxrange = std::max(maxrange, c->xcd.start[k + 1] - c->xcd.start[k]);
-    if (maxrange > 4 * nwx || c->nslices < G) return 0;
-    const int DD = c->dm * c->dm;
-    const int SPW = maxrange > 3 * nwx ? 4 : 3;
-    int lds_rows = c->opt_persist_lds < 0 ? (int)((c->small_max_lds - 2048) / (4 * 64 * (DD * 8 + 4))) : c->opt_persist_lds;
-    lds_rows = std::max(0, std::min(lds_rows, SPW * (int)c->max_row_blocks));
-    const int rj = c->dm == 3 ? (SPW == 3 ? c->opt_persist_rj : (c->opt_persist_rj ? 3 : 0)) : (c->opt_persist_rj ? 5 : 0);
+    PersistShape sh;
+    if (!persist_shape(c, &sh) || c->nslices < sh.G) return 0;
+    const int G = sh.G, DD = c->dm * c->dm, lds_rows = sh.lds_rows, rj = sh.rj;
     const int64_t row_bytes = (int64_t)(DD * 8 + 4) * 64;
     // every slice keeps min(L, rj) rows in registers, and the LDS rows of a wave are full whenever its slices have
     // more rows than rj (true for every mesh that takes this path)

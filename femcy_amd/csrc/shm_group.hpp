@@ -108,7 +108,7 @@ struct ShmGroup {
         }
     }
 
-    // join the group the id names (the first rank to arrive creates the segment)
+    // join the group the id names (rank 0 creates the segment)
     bool open(int32_t rank, int32_t nranks, const void* id128) {
         if (nranks < 1 || nranks > SHM_MAXR || rank < 0 || rank >= nranks) return fail("1 .. 16 ranks");
         uint64_t token, cap;
@@ -117,10 +117,13 @@ struct ShmGroup {
         std::snprintf(name, sizeof(name), "/femcy_%016llx", (unsigned long long)token);
         const size_t head = (sizeof(ShmHeader) + 4095) & ~(size_t)4095;
         bytes = head + sizeof(double) * (size_t)cap * nranks;
-        bool creator = true;
-        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0) {
-            creator = false;
+        // rank 0 creates the segment, everybody else opens it without O_CREAT: a rank that arrives after the group has
+        // already failed and been unlinked (leave() below) must not found a second, split group under the same name and
+        // sit in it until the rendezvous times out -- it fails here with "the segment did not appear"
+        const bool creator = rank == 0;
+        int fd = creator ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : -1;
+        if (creator && fd < 0) return fail("the segment exists already (a stale /dev/shm entry, or two ranks 0)");
+        if (!creator) {
             const double t0 = now_s();
             for (unsigned spins = 0; (fd = shm_open(name, O_RDWR, 0600)) < 0; ++spins) {
                 if (now_s() - t0 > timeout_s) return fail("the segment did not appear");
@@ -179,8 +182,13 @@ struct ShmGroup {
 
     void leave() {
         if (!h) return;
-        // a rank that leaves before everybody joined removes the name itself (the last joiner would have)
-        if (h->joined.load(std::memory_order_acquire) < h->nranks) shm_unlink(name);
+        // a rank that leaves before everybody joined (an error during set-up) removes the name itself -- the last joiner
+        // would have -- and marks the group broken first, so that the ranks already inside fail at their next rendezvous
+        // at once instead of after the time-out
+        if (h->joined.load(std::memory_order_acquire) < h->nranks) {
+            h->broken.store(1, std::memory_order_release);
+            shm_unlink(name);
+        }
         h->left.fetch_add(1, std::memory_order_acq_rel);
         munmap((void*)h, bytes);
         h = nullptr;

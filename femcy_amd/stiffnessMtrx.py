@@ -60,9 +60,9 @@ class System_of_equations:
         # direct = "auto": both stand-ins for the reference's spsolve return the solution to ~1e-12, so which one runs is
         # a question of time only.  The band factorisation costs n * bandwidth^2 flops behind a chain of dependent
         # launches (~20 us per panel of 32 unknowns + the tile updates), the tight PCG iterations * (matrix bytes /
-        # memory bandwidth); on 2-D decks and small 3-D ones the factorisation wins by 2 ... 20 x, on 3-D meshes of
-        # 3e4 ... 1e5 DOF (bands of 1 300 ... 2 900 sub-diagonals) the PCG is up to 2 x faster
-        # (profiles/r04_direct_limit.txt).  First solve: by the band (femcy_direct_plan); from then on by the measured
+        # memory bandwidth); on 2-D decks and 3-D ones up to ~4e4 DOF the factorisation wins by 1.5 ... 20 x, on 3-D
+        # meshes towards 1e5 DOF (bands of 2 000 ... 2 900 sub-diagonals) the PCG is up to 2 x faster
+        # (profiles/r05_direct_limit.txt).  First solve: by the band (femcy_direct_plan); from then on by the measured
         # times of both (the other one is tried once, on the second solve, if the first took more than 5 ms).
         self._auto = {"first": None, "ms": {}, "tried": set(), "pcg_ok": True, "pick": None}
 
@@ -195,7 +195,10 @@ class System_of_equations:
         self.cg_log.append({"iters": it, "r0": r0, "rmax": rmax, "time1": self.time1, "converged": self.PCG.converged})
         return self._take_solution()
 
-    AUTO_WIDE_BAND = 1280        # sub-diagonals above which the FIRST solve of direct = "auto" goes to the tight PCG
+    # sub-diagonals above which the FIRST solve of direct = "auto" goes to the tight PCG.  Cube-like C3D4 meshes, medians of
+    # five (profiles/r05_direct_limit.txt): 512 sub-diagonals 5.4 ms against 14.6 (PCG), 1 328: 29.1 against 45.3,
+    # 2 888: 128.5 against 69.0 -- the crossover lies near 2 000
+    AUTO_WIDE_BAND = 2048
     AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
 
     def _auto_method(self) -> str:

@@ -114,3 +114,50 @@ def test_direct_branch_record_of_the_bench_line():
     assert rec["direct_ms"] > 0 and rec["tight_pcg_ms"] > 0 and rec["tight_pcg_iterations"] > 10
     assert rec["negative_pivots"] == 0 and rec["residual"] <= 1e-10 and rec["rel_diff_direct_vs_pcg"] <= 1e-8
     json.dumps(rec)
+
+
+def test_bench_cpe8_workload_line():
+    """`--workload cpe8` (BASELINE configs[1], round 5): the contract's line on a generated plane-strain CPE8 beam; the
+    roofline object prices the dominant kernel of the timed region, `hbm_bound[0]` carries the k_spmv<2> product launch
+    to launch, the PCG iteration on both paths and the assembly rate"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cpe8", "--cells", "600,60", "--steps", "2",
+                          "--warmup", "1", "--iters", "50", "--prewarm", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("CG iters/sec") and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "CPE8 600x60" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"] and d["config"]["cg_iters_per_step"] == 50
+    assert d["value"] > 0 and d["assemblies_per_s"] > 0 and d["pcg_us_per_iter"] > 0 and d["steps"] == 2
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "infinity-cache") and r["unit"] == "GB/s" and r["achieved"] > 0 and r["traffic"] is None
+    assert r["kernel"].startswith("k_pcg_persist<2>") or r["kernel"].startswith("k_spmv<2>")
+    assert r["spmv_launch_to_launch_us"] > 0 and 0 < r["spmv_frac_of_hbm_peak"] < 1.5
+    h = d["hbm_bound"][0]
+    assert h["dof"] == 2 * ((2 * 600 + 1) * (2 * 60 + 1) - 600 * 60) and h["elements"] == 36000
+    assert h["spmv"]["kernel"].startswith("k_spmv<2>") and h["spmv"]["bound"] == "hbm" and h["spmv"]["peak"] == 8000.0
+    assert abs(h["spmv"]["frac"] - h["spmv"]["achieved"] / 8000.0) < 1e-12 and h["spmv"]["launches_timed"] > 0
+    p = h["pcg_iteration"]
+    assert p["path"] in ("persistent", "three-kernel") and p["us"] > 0 and p["three_launch_us"] > 0
+    assert (p["path"] == "persistent") == (p["persistent_streamed_bytes"] is not None)
+    assert h["assembly_ms"] > 0 and h["assemblies_per_s"] > 0
+
+
+def test_hbm_bound_records_of_the_default_line_have_the_2d_configuration():
+    """the default N = 1 line carries three HBM-bound configurations since round 5: 8 M C3D4, 124 k C3D10 and the CPE8
+    beam of ~1 M DOF (`hbm_bound[2]`); here the record builder on a small beam"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+    from femcy_amd.material_zoo import LinearIsotropicPlaneStrain
+    from femcy_amd.user_defined import user_dirichletBC_values
+    assert bench.CPE8_CELLS == (1280, 128) and "configs[1]" in bench.CPE8_NAME
+    msh = meshgen.beam_quad8(360, 60, plane="CPE8")
+    rec = bench.hbm_bound_record(be, "beam CPE8 360x60", msh, Element_quadratic_quadrilateral(),
+                                 LinearIsotropicPlaneStrain(*msh["elastic"]), user_dirichletBC_values, None, iters=40, spmv_reps=10)
+    assert rec["dof"] == msh["nodes"].size and rec["spmv"]["kernel"].startswith("k_spmv<2>")
+    assert rec["spmv"]["bytes_per_launch"] > 0 and rec["pcg_iteration"]["bytes"] == rec["spmv"]["bytes_per_launch"] + 88 * rec["dof"]
+    assert rec["stored_matrix_mb"] > 0 and rec["pcg_iteration"]["three_launch_us"] > 0
+    json.dumps(rec)

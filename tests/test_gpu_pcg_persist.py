@@ -187,6 +187,39 @@ def test_persistent_pcg_two_dimensional_blocks(gpu_ctx_factory):
     ctx.close()
 
 
+@pytest.mark.parametrize("cells,spw", [((1000, 100), 6), ((1280, 128), 8)])
+def test_persistent_pcg_2d_six_and_eight_slices_per_wave(gpu_ctx_factory, cells, spw):
+    """round 5: with 2 x 2 blocks a wave has the registers for up to EIGHT slices (vectors 20 registers per slice, a
+    block row 9), so 2-D systems of up to 8 192 slices = 1.05 M DOF take the one-launch path: the CPE8 beam of
+    `bench.py --workload cpe8` (BASELINE configs[1] at the size of the 3-D headline system, 7 725 slices, SPW = 8) and a
+    4 097 ... 6 144-slice one (SPW = 6).  Same recurrence: iterates equal the three-launch loop's to rounding."""
+    import time
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+    m = meshgen.beam_quad8(*cells)
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_quadratic_quadrilateral())
+    lo, hi = {6: (4096, 6144), 8: (6144, 8192)}[spw]
+    assert lo < info.nslices <= hi
+    out, us = {}, {}
+    for persist in (0, 1):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = _paths(ctx)
+        out[persist] = [_solve(ctx, be, 0.0, k) for k in (1, 9, 30)]
+        assert _paths(ctx)[2 if persist else 0] - before[2 if persist else 0] == 3
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)
+        t = time.perf_counter()
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)
+        us[persist] = (time.perf_counter() - t) / 300 * 1e6
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(out[0], out[1]), (1e-13, 1e-11, 1e-9)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    again = _solve(ctx, be, 0.0, 30)
+    assert np.array_equal(again[1], out[1][2][1])                      # a solve is bit-reproducible
+    print(f"[CPE8 {cells[0]}x{cells[1]}: {info.nslices} slices, {spw} per wave] three launches {us[0]:.1f} us / iteration, persistent {us[1]:.1f}")
+    assert us[1] < us[0]                                               # the default path is the faster one
+    ctx.close()
+
+
 def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
     """above 3 x 128 slices per XCD range a wave owns up to FOUR slices (SPW = 4 instantiation, 3 register rows per
     slice): a 1.09 M-element C3D4 plate (200 889 nodes = 3 139 slices, 217 MB of matrix: still Infinity-Cache size).
@@ -228,9 +261,12 @@ def test_persistent_pcg_four_slices_per_wave(gpu_ctx_factory):
     for mb in (240, 0):
         ctx.set_option(be.TUNE_PERSIST_MAX_MB, mb)
         ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=100)
-        t = time.perf_counter()
-        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)
-        us[mb] = (time.perf_counter() - t) / 300 * 1e6
+        best = 1e30
+        for _ in range(3):       # best of three: numpy's BLAS pool, still spinning after the norms above, stalls the host
+            t = time.perf_counter()                      # for 35-75 ms now and then (one such stall = +150 us / iteration)
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=300)
+            best = min(best, (time.perf_counter() - t) / 300 * 1e6)
+        us[mb] = best
     print(f"[124 k C3D10, matrix streamed from HBM] three launches {us[240]:.1f} us / iteration, persistent {us[0]:.1f}")
     assert us[0] < us[240]                                 # the form that is chosen by default is the faster one
     ctx.close()
