@@ -136,12 +136,13 @@ enum femcy_option {
                                    Measured: persistent PCG on C3D10 plates of 37 k / 72 k elements 31.8 -> 28.8 / 40.7 ->
                                    34.9 us per iteration; neutral for the three-launch PCG and the assemblies; the 1 M / 8 M
                                    C3D4 plates keep their numbering (profiles/r04_persist_node_order_c3d10.txt)      */
-    FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (up to ~7.8e5
-                                   DOF on MI355X) and whose matrix, less the part the kernel keeps on chip, fits the
-                                   Infinity Cache are solved by one persistent launch -- vectors and part of the matrix
-                                   in registers, another part in LDS, grid barriers at the three synchronisation points
-                                   of the recurrence; 2 = also when the streamed part is larger than the cache (slower
-                                   than three launches; tests); 0 = three launches per iteration */
+    FEMCY_OPT_PCG_PERSIST = 11, /* 1 (default): single-rank systems that fit one wavefront task per SIMD (3 x 3 blocks: up
+                                   to ~7.8e5 DOF on MI355X; 2 x 2 blocks: up to ~1.05e6) and fill the chip 1.5 times over
+                                   are solved by one persistent launch -- vectors and part of the matrix in registers,
+                                   another part in LDS, the rest streamed (from the Infinity Cache or, since round 5, from
+                                   HBM: FEMCY_TUNE_PERSIST_MAX_MB), grid-wide exchanges at the three synchronisation points
+                                   of the recurrence; 2 = any system whose slices fit (tests); 0 = three launches per
+                                   iteration */
     FEMCY_OPT_PCG_PERSIST_MULTI = 12, /* 1 (default): with a communicator attached, femcy_pcg keeps the one-launch
                                    persistent kernel on every rank and the ranks' kernels exchange the interface rows of
                                    Ad and the two scalar reductions through mailboxes in each other's HBM (written over

@@ -135,3 +135,13 @@ def test_deck_parity_on_the_cpu_backend():
     factorisation)"""
     tail = _run(["test_gpu_e2e.py"], k="not twist_plate_C3D10")
     print("[cpu backend] decks:", tail)
+
+
+def test_cg_branch_of_the_driver_on_the_cpu_backend():
+    """the reference's >= 1e5-DOF leg (`solve_by_CG`: eps = 1e-3, maxit = n) through the driver on the host backend: the
+    116 k-DOF twist plate in sound increments (12 CG solves, the oracle's iteration counts, displacements to 1e-6) and
+    the 108 k-DOF linear CPE8 cantilever (one solve).  (The deck's own first increment -- 820 k CG iterations, most of
+    them solves that run to the reference's cap on an indefinite K -- is the GPU suite's: 11 s there, 6 minutes here.)"""
+    tail = _run(["test_gpu_cg_branch.py"], k="beam_lin or fine_per_solve")
+    assert "2 passed" in tail
+    print("[cpu backend] CG branch:", tail)

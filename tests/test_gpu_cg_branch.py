@@ -9,9 +9,11 @@ values are the CPU oracle's (tests/golden/make_golden_cg.py -> oracle_cg_branch.
 What can be asked of such a run -- and what cannot -- follows from the algorithm, not from the implementation:
   * a CG solve that stops at max|r| < 1e-3 max|r0| pins the solution only up to its soft modes: two correct
     implementations that sum in different orders stop a few iterations apart and return x's that differ by far more
-    than 1e-3 (the oracle against ITSELF with another OpenMP thread count: DESIGN.md section 4).  So: iteration counts
-    per solve are compared on well-posed systems (twist_k7_fine: equal or within 3 %), and the final displacements are
-    compared with the distance between the eps = 1e-3 run and the exact-solve run of the same system as the yardstick;
+    than 1e-3 WHEN K IS INDEFINITE (the oracle against ITSELF with another OpenMP thread count: 540 / 513 / 503 / 502
+    iterations on the state-S1 system, solutions 1e-2 apart: profiles/r05_cg_reduction_order_sensitivity.txt).  On positive
+    definite systems the recurrence is stable: twist_k7_fine and beam_lin must match the oracle's iteration counts
+    (measured: all equal) and its displacements to north_star's 1e-6 (measured 5.9e-8 / 7.5e-14) -- although the
+    eps = 1e-3 answers themselves lie 2.6e-3 / 88 % away from the exact-solve flow of the same systems;
   * an increment that asks for too much twist inverts the boundary layer, K goes indefinite and the reference's CG runs
     to its cap n without converging (it has no breakdown test); the Newton iterates explode until a NaN cuts the
     increment back.  That IS the reference's behaviour (the oracle does the same: 5 of its 13 solves on twist_k7 end at
@@ -78,7 +80,7 @@ def test_twist_k7_control_flow_of_the_cg_branch(gold):
     assert np.array_equal(inc[ok, 3], ginc[ok, 3])             # Newton loops of every accepted increment
     assert (inc[~ok, 3] >= 1).all() and (~ok).sum() == 2       # (the loop a diverging sequence trips NaN in is chaotic)
     # the first solve is the same system on both sides (state S1: K indefinite already, CG "converges" erratically)
-    assert abs(cg[0, 1] - gcg[0, 1]) <= 1e-9 * gcg[0, 1] and abs(cg[0, 0] - gcg[0, 0]) <= 0.05 * gcg[0, 0]
+    assert abs(cg[0, 1] - gcg[0, 1]) <= 1e-9 * gcg[0, 1] and abs(cg[0, 0] - gcg[0, 0]) <= 0.10 * gcg[0, 0]   # (the oracle with 8 / 4 / 2 / 1 threads: 540 / 513 / 503 / 502)
     # reference behaviour, not a bug: inside the rejected increments CG runs to its cap n = 116 280 and does not converge
     n = s.n_system
     capped = cg[cg[:, 0] == n]
@@ -112,15 +114,15 @@ def test_twist_k7_fine_per_solve_iteration_counts(gold):
     print(f"device {cg[:, 0].astype(int).tolist()}\\noracle {gcg[:, 0].astype(int).tolist()}")
     assert np.array_equal(inc[:, 2:], ginc[:, 2:]) and np.allclose(inc[:, :2], ginc[:, :2], rtol=0, atol=1e-15)
     assert len(cg) == len(gcg) == s.stats["linear_solves"] and s.stats["direct_solves"] == 0
-    assert (np.abs(cg[:, 0] - gcg[:, 0]) <= np.maximum(2, 0.03 * gcg[:, 0])).all()
+    assert (np.abs(cg[:, 0] - gcg[:, 0]) <= 2).all()           # measured: all 12 counts equal
     assert np.array_equal(cg[:3, 0], gcg[:3, 0])               # first increment: the same systems to rounding
     assert (np.abs(cg[:, 1] - gcg[:, 1]) <= 0.02 * gcg[:, 1]).all() and (cg[:, 2] < 1e-3 * cg[:, 1]).all()
     u, gu, gt = s.dof.to_numpy(), gold["twist_k7_fine/dof"], gold["twist_k7_fine/dof_tight"]
     err, yard = np.linalg.norm(u - gu) / np.linalg.norm(gu), np.linalg.norm(gu - gt) / np.linalg.norm(gt)
     print(f"|u - u_oracle| / |u_oracle| = {err:.3e}; oracle eps = 1e-3 vs exact solves: {yard:.3e}; "
           f"device vs exact solves: {np.linalg.norm(u - gt) / np.linalg.norm(gt):.3e}")
-    assert err <= max(yard, 1e-6)                              # as close to the oracle as eps = 1e-3 is to the exact flow
-    assert np.linalg.norm(u - gt) / np.linalg.norm(gt) <= 2.0 * yard + 1e-6
+    assert err <= 1e-6                                         # north_star's tolerance, on the CG branch (measured 5.9e-8)
+    assert np.linalg.norm(u - gt) / np.linalg.norm(gt) <= 1.01 * yard + 1e-6   # ... and no further from the exact-solve flow than the oracle
     s.ctx.close()
 
 
@@ -142,8 +144,8 @@ def test_beam_lin_one_cg_solve(gold):
     u, gu, gt = s.dof.to_numpy(), gold["beam_lin/dof"], gold["beam_lin/dof_tight"]
     err, yard = np.linalg.norm(u - gu) / np.linalg.norm(gu), np.linalg.norm(gu - gt) / np.linalg.norm(gt)
     print(f"|u - u_oracle| / |u_oracle| = {err:.3e}; oracle eps = 1e-3 vs exact: {yard:.3e}")
-    assert err <= max(yard, 1e-6)
-    s.ctx.close()
+    assert err <= 1e-9 and yard > 0.5      # (the reference's CG stops 88 % away from the exact solution of this cantilever:
+    s.ctx.close()                           # 380 Jacobi-CG iterations do not carry the tip displacement along 420 elements)
 
 
 def test_main_on_a_written_deck_takes_the_cg_branch(tmp_path, gold):
@@ -151,6 +153,7 @@ def test_main_on_a_written_deck_takes_the_cg_branch(tmp_path, gold):
     from femcy_amd import meshgen
     m, _, _, ti = _twist({"ini_inc": 0.003125, "max_inc": 0.003125, "max_time": 0.0125})
     m["time_incs"] = ti
+    gu = gold["twist_k7_fine/dof"]
     deck = str(tmp_path / "twist_k7_fine.inp")
     meshgen.write_inp(deck, m)
     out = subprocess.run([sys.executable, "-m", "femcy_amd.main", deck, "--save", str(tmp_path / "out.npz")],
@@ -158,6 +161,5 @@ def test_main_on_a_written_deck_takes_the_cg_branch(tmp_path, gold):
     assert out.returncode == 0, out.stderr[-2000:]
     stats = [l for l in out.stdout.splitlines() if "solver statistics" in l][-1]
     assert "'direct_solves': 0" in stats and f"'linear_solves': {len(gold['twist_k7_fine/cg'])}" in stats
-    u, gu, gt = np.load(tmp_path / "out.npz")["dof"], gold["twist_k7_fine/dof"], gold["twist_k7_fine/dof_tight"]
-    yard = np.linalg.norm(gu - gt) / np.linalg.norm(gt)
-    assert np.linalg.norm(u - gu) / np.linalg.norm(gu) <= max(yard, 1e-6)
+    u = np.load(tmp_path / "out.npz")["dof"]
+    assert np.linalg.norm(u - gu) / np.linalg.norm(gu) <= 1e-6
