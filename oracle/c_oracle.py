@@ -140,3 +140,7 @@ class COracle:
 
     def threads(self):
         return self.L.orc_num_threads()
+
+    def set_threads(self, n: int):
+        """OpenMP threads of every later call (process-wide): 1 = serial sums, the reductions exactly as written"""
+        self.L.orc_set_num_threads(int(n))

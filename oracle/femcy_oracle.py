@@ -7,9 +7,11 @@ it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
 the checker.
 
 PARITY STATUS: "parity unpinned" against a real Taichi run (none can be produced).  The
-restatement is pinned instead by the reference's own published known answers
-(README.md:66-71: CPS6 sigma_yy at D = 93.32 node / 84.40 Gauss point; CPS3 Abaqus
-93.45) and by analytic properties (tests/test_oracle_*.py).
+restatement is pinned instead by the reference's own published known answers -- README.md:66-71,
+FEMcy row: sigma_yy at D = 93.56 (CPS3), 93.32 node / 84.40 Gauss point (CPS6), all three
+reproduced to the printed digit through the reference's own CG at eps = 1e-3 (round 5:
+tests/test_oracle_c.py::test_as_written_cg_reproduces_all_three_published_numbers,
+tests/test_oracle_pins.py::test_readme_*) -- and by analytic properties (tests/test_oracle_*.py).
 
 All `file:line` citations are relative to /root/reference.
 

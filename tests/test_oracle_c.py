@@ -67,3 +67,72 @@ def test_c_oracle_cg_is_the_reference_recurrence():
         assert np.abs(K @ x - b).max() < 2 * eps * r0
     x5, it5, _, _ = co.cg(b, eps=0.0, maxit=5)
     assert it5 == 5
+
+
+def _reference_adjacency(elements, nn):
+    """the column order of the reference's sparseIJ: Python sets filled and iterated exactly as body.py:165-194 does
+    (nodeEles -> coElement_nodes); CPython's set order of small ints is deterministic"""
+    nodeEles = [set() for _ in range(nn)]
+    for iele, ele in enumerate(elements):
+        for node in ele:
+            nodeEles[node].add(iele)
+    nodeEles = [list(s) for s in nodeEles]
+    co = []
+    for node0 in range(nn):
+        others = set()
+        for ele in nodeEles[node0]:
+            for node1 in elements[ele, :]:
+                others.add(node1)
+        co.append([int(v) for v in others])
+    ptr = np.zeros(nn + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum([len(c) for c in co])
+    return ptr, np.array([v for c in co for v in c], dtype=np.int64)
+
+
+@pytest.mark.parametrize("order", ["sorted", "reference-set-order"])
+def test_as_written_cg_reproduces_all_three_published_numbers(order):
+    """README.md:66-71, FEMcy row: sigma_yy at D = 93.56 (CPS3 deck), 93.32 / 84.40 (CPS6 deck, node / Gauss point).
+    The as-written restatement -- ELL rows multiplied in sparseIJ order, every kernel its own pass, the four reductions
+    as serial sums (one thread) -- driven by the reference's own CG settings (eps = 1e-3 on max|r| / max|r0|,
+    conjugateGradientSolver.py:103-127) stops the CPS3 solve after 105 iterations at max sigma_yy = 93.5617 and the CPS6
+    solve after 128 at 93.32 / 84.40: ALL THREE published digits, with the columns in sorted order and in the order the
+    reference's Python sets produce (body.py:165-194).  The exact solutions are 93.4514 and 93.3125 / 84.3960; the numpy
+    oracle (pairwise sums) stops the CPS3 solve one iteration earlier (104: 93.635) -- the stop test there passes by 1 %.
+    This pins assembly, consistent loads, Dirichlet elimination, the PCG recurrence with its stopping rule, stress
+    recovery and nodal extrapolation of the restatement to numbers the REFERENCE produced."""
+    from helpers import oracle_system_from_inp
+    want = {"ellip_membrane_linEle_localVeryFine.inp": (105, "93.56", None),
+            "ellip_membrane_quadritic_trig_neumann.inp": (128, "93.32", "84.40")}
+    for name, (stop, s_node, s_gp) in want.items():
+        inp = InpInfo(deck(name))
+        et = list(inp.eSets)[0]
+        el = np.asarray(inp.eSets[et])
+        ed = elem_def(et)
+        s = oracle_system_from_inp(inp)
+        s.time1 = 1.0
+        s.assemble_stiffnessMtrx()
+        s.impose_boundary_condition({"neumannBCs": inp.neumann_bc_info, "dirichletBCs": inp.dirichlet_bc_info})
+        K, b = s.K.tocsr(), s.rhs
+        topo = orc.Topology(inp.nodes, el, ed)
+        ptr, idx = (topo.adj_ptr, topo.adj_idx) if order == "sorted" else _reference_adjacency(el, inp.nodes.shape[0])
+        assert (order == "sorted") == np.array_equal(idx, topo.adj_idx)          # the set order really is another order
+        co = COracle(inp.nodes, el, ed.dN_table(), ed.gauss_weights, s.C, ptr, idx)
+        threads = co.threads()
+        co.set_threads(1)
+        try:
+            for i in range(co.n):                                                # K (with loads and Dirichlet applied) -> ELL rows
+                cols = co.ij[i, 1:co.ij[i, 0] + 1]
+                co.A[i, :cols.size] = np.asarray(K[i, cols].todense()).ravel()
+            x, it, r0, rmax = co.cg(b, eps=1e-3)
+        finally:
+            co.set_threads(threads)
+        assert it == stop and rmax < 1e-3 * r0
+        s.dof = x.copy()
+        sig = s.compute_strain_stress()
+        nodal = s.extrapolate(sig[:, :, 1, 1])
+        nD = int(np.argmin(np.linalg.norm(inp.nodes - np.array([2., 0.]), axis=1)))
+        e, a = np.where(el == nD)
+        if s_gp is None:
+            assert "%.2f" % sig[:, :, 1, 1].max() == s_node                      # CPS3: the largest sigma_yy of the mesh
+        else:
+            assert "%.2f" % nodal[e[0], a[0]] == s_node and "%.2f" % sig[e[0], :, 1, 1].max() == s_gp
