@@ -255,8 +255,8 @@ def hbm_bound_record(be, name, mesh, element, material, user_values, probe, iter
         ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=iters)          # warm: clocks, caches, lazy allocations
         spmv_b, iter_b = algorithmic_bytes(info, ctx.nn, ctx.n)
         # (a) the product through the public entry point femcy_spmv (vectors in the caller's node order)
-        # (round 5: femcy_spmv = permutation in + the storage-order product + permutation out; timed as whole calls
-        # between two synchronisations, so the permutations are in the figure)
+        # (round 5: timed as whole calls between two synchronisations -- what a caller of the public entry point sees,
+        # launch overhead included -- instead of HIP events around the kernel alone)
         for _ in range(3):
             ctx.spmv(be.VEC_RESIDUAL, be.VEC_TMP0)
         ctx.sync()

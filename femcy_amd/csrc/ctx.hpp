@@ -31,11 +31,17 @@ inline hipError_t malloc_checked(void** p, size_t bytes) {
     }();
     const hipError_t rc = hipMalloc(p, bytes);
     if (rc == hipSuccess && poison && bytes) {
-        // the fill runs on the null stream, the library's work on its own (non-blocking) stream: without the device-wide
-        // synchronisation the fill can land AFTER the first copy into the new buffer (round 5, first poisoned run: index
-        // arrays of -1 and a memory fault that was the checker's own)
-        (void)hipMemset(*p, 0xFF, bytes);
-        (void)hipDeviceSynchronize();
+        // the fill must have LANDED before the caller's first copy into the new buffer (on the null stream it could land
+        // after it: index arrays of -1 and a memory fault that was the checker's own), and it must not wait for other
+        // streams (a device-wide synchronisation deadlocks against the co-dependent persistent kernels of several ranks
+        // in one process until their spin limit): its own non-blocking stream, synchronised here
+        static hipStream_t fill_stream = [] {
+            hipStream_t st = nullptr;
+            (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            return st;
+        }();
+        (void)hipMemsetAsync(*p, 0xFF, bytes, fill_stream);
+        (void)hipStreamSynchronize(fill_stream);
     }
     return rc;
 }
@@ -361,7 +367,6 @@ int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launc
 int64_t persist_streamed_bytes(Ctx* c);
 int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps
 int ensure_pos_vectors(Ctx* c);   // d_posb / d_posx (storage-order right-hand side / solution) + d_bcolp
-int spmv_public(Ctx* c, const double* d_x, double* d_y);   // femcy_spmv: node order in and out, storage-order product inside
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions
 int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit, bool* handled);
 int launch_dirichlet_zero(Ctx* c, const int32_t* d_dofs, int32_t k, double* d_resid_or_null);

@@ -982,7 +982,10 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
     VEC_OR_FAIL(x_vec);
     VEC_OR_FAIL(y_vec);
     FEMCY_REQUIRE(x_vec != y_vec, "spmv cannot run in place");
-    int rc = spmv_public(c, c->d_vec[x_vec], c->d_vec[y_vec]);
+    // (node-order product.  Round 5 tried the PCG's storage-order kernel between two permutations here: 78.0 -> 75.7 us
+    // per call on the C3D10 plate, 281 -> 329 us on the 8 M C3D4 plate, whose numbering gathers as well as storage order
+    // does -- not adopted; profiles/r05_bench_c3d4_n1_public_spmv_storage_order.json)
+    int rc = launch_spmv(c, c->d_vec[x_vec], c->d_vec[y_vec], nullptr, nullptr);
     if (rc) return rc;
     if (c->comm) return iface_sum(c, c->d_vec[y_vec]);
     return FEMCY_OK;

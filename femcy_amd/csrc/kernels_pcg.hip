@@ -1078,24 +1078,6 @@ int ensure_pos_vectors(Ctx* c) {
     return FEMCY_OK;
 }
 
-// femcy_spmv (round 5): the public product runs the PCG's own storage-order kernel between two permutations (8 n bytes
-// in and out each: 4 % of the C3D10 product's bytes) instead of the node-order kernel, which was 14 % slower on that
-// plate (through_femcy_spmv_frac 0.645 against 0.738, BENCH_r04); multi-rank contexts keep node order
-int spmv_public(Ctx* c, const double* d_x, double* d_y) {
-    if (c->comm || !c->opt_pos_space) return launch_spmv(c, d_x, d_y, nullptr, nullptr);
-    int rc = ensure_pos_vectors(c);
-    if (rc) return rc;
-    const int32_t npos = c->nslices * SLICE;
-    const int pg = (npos + BS - 1) / BS;
-    if (c->dm == 3) hipLaunchKernelGGL((k_to_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
-    else hipLaunchKernelGGL((k_to_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
-    if ((rc = launch_spmv(c, c->d_posb, c->d_posx, nullptr, nullptr, true))) return rc;
-    if (c->dm == 3) hipLaunchKernelGGL((k_from_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
-    else hipLaunchKernelGGL((k_from_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
-    FEMCY_HIP(hipGetLastError());
-    return FEMCY_OK;
-}
-
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch) {
     FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
     FEMCY_REQUIRE(reps >= 1 && reps <= 100000 && us_per_launch, "probe_spmv: reps 1..1e5");
