@@ -13,6 +13,8 @@ Every shipped deck is below 1e5 DOF and takes the spsolve branch, so the systems
                 is cut back twice -- that IS the reference's behaviour on this system (its CG has no breakdown test)
   twist_k7_fine the same mesh with ini_inc = max_inc = 0.003125 (what the cut-backs arrive at), to max_time = 0.0125:
                 every solve converges -- the clean comparison of per-solve iteration counts
+  twist_c3d10_fine  BASELINE configs[4]'s element on the CG branch: 36 864 C3D10 (32 x 4 x 48 cells), 170 235 DOF, two
+                increments of 0.003125
   beam_lin      linear (nlgeom = NO) CPE8 cantilever 420 x 42 serendipity quadrilaterals, 107 690 DOF, tip displacement
                 1: ONE CG solve at eps = 1e-3
 
@@ -39,7 +41,10 @@ def cases():
     ti = dict(tw["time_incs"], max_time=0.05)
     fine = dict(tw["time_incs"], ini_inc=0.003125, max_inc=0.003125, max_time=0.0125)
     bm = beam_lin_mesh()
+    tq = meshgen.twist_plate(32, 4, 48, quadratic=True)
+    fineq = dict(tq["time_incs"], ini_inc=0.003125, max_inc=0.003125, max_time=0.00625)
     return {
+        "twist_c3d10_fine": (tq, "C3D10", Material("lin3d", tq["elastic"]), True, fineq),
         "twist_k7": (tw, "C3D4", Material("lin3d", tw["elastic"]), True, ti),
         "twist_k7_fine": (tw, "C3D4", Material("lin3d", tw["elastic"]), True, fine),
         "beam_lin": (bm, "CPE8", Material("pstrain", bm["elastic"]), False, bm["time_incs"]),
@@ -78,7 +83,9 @@ def main():
         u, cg, inc, s = run(name, mesh, etype, mat, nlgeom, ti, "reference")
         out[name + "/dof"], out[name + "/cg"], out[name + "/inc"] = u, cg, inc
         out[name + "/meta"] = np.array([s.n_solves, s.n_assemblies, getattr(s, "ini_residual", 0.0), s.time0], dtype=np.float64)
-        if "--no-tight" not in sys.argv and name != "twist_k7":       # (twist_k7: the exact-solve flow is twist_k7_fine's)
+        # (twist_k7: the exact-solve flow is twist_k7_fine's; twist_c3d10_fine: a sparse LU of 170 k C3D10 unknowns per
+        # solve is hours of SuperLU)
+        if "--no-tight" not in sys.argv and name not in ("twist_k7", "twist_c3d10_fine"):
             ut, _, inct, st = run(name, mesh, etype, mat, nlgeom, ti, "spsolve")
             out[name + "/dof_tight"], out[name + "/inc_tight"] = ut, inct
         np.savez_compressed(path, **out)

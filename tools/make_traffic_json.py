@@ -1,5 +1,5 @@
 """profiles/spmv_traffic.json from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, separate passes) of bench.py.
-usage: python tools/make_traffic_json.py <git_head> c3d4:<fetch.db>:<write.db> [c3d10:<fetch.db>:<write.db>]
+usage: python tools/make_traffic_json.py [--merge] <git_head> c3d4:<fetch.db>:<write.db> [c3d10:<fetch.db>:<write.db>] [cpe8:...]
 The file is stamped with a fingerprint of the SpMV kernel sources (bench.kernel_source_sha): bench.py refuses the
 numbers once those sources change."""
 import json
@@ -20,19 +20,33 @@ def avg_counter(db, counter):
                            "counter_name=? and kernel_name like ? group by kernel_name", (counter, like)).fetchall()
         if rows:
             rows.sort(key=lambda r: -r[1])
-            name, n, v, d = rows[0]
+            name = rows[0][0]
+            # the launches of the timed steps only: a run may also hold shorter solves of the same kernel (the 100-iteration
+            # solves of an `hbm_bound` record inside `--workload cpe8`), which must not dilute the per-launch average
+            dmax = cur.execute("select max(duration) from counters_collection where counter_name=? and kernel_name=?",
+                               (counter, name)).fetchone()[0]
+            n, v, d = cur.execute("select count(*), avg(value), avg(duration) from counters_collection where counter_name=? "
+                                  "and kernel_name=? and duration >= ?", (counter, name, 0.8 * dmax)).fetchone()
             return name, n, v, d / 1e3
     raise SystemExit(f"{db}: no k_pcg_persist / k_spmv dispatches with counter {counter}")
 
 
 def main():
     head = sys.argv[1]
+    path = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    keep = {}
+    if "--merge" in sys.argv:                  # re-take some workloads, keep the others (same kernel sources only)
+        sys.argv.remove("--merge")
+        old = json.load(open(path))
+        if old.get("kernel_source_sha") != bench.kernel_source_sha():
+            raise SystemExit("--merge: the kernel sources changed since profiles/spmv_traffic.json was taken")
+        keep = old.get("workloads", {})
     out = {"kernel_source_sha": bench.kernel_source_sha(), "git_head": head,
            "sources": list(bench.TRAFFIC_SOURCES),
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, "
                          "HBM section) -> x2; WRITE_SIZE taken as reported (uncalibrated)",
            "note": "counters are L2 <-> fabric requests, Infinity-Cache hits included",
-           "workloads": {}}
+           "workloads": dict(keep)}
     for spec in sys.argv[2:]:
         wl, fdb, wdb = spec.split(":")
         kname, nf, fetch_kb, us_f = avg_counter(fdb, "FETCH_SIZE")
@@ -40,7 +54,7 @@ def main():
         out["workloads"][wl] = {"kernel": kname, "dispatches": [nf, nw], "fetch_size_kb_reported": fetch_kb,
                                 "write_size_kb_reported": write_kb, "avg_us_under_pmc": [us_f, us_w],
                                 "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024))}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "spmv_traffic.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
