@@ -101,6 +101,23 @@ def test_readme_cps3_93_56_lies_in_the_cg_truncation_band():
     assert abs(vals[116] - 93.4514) < 5e-3                               # eps = 1e-4 would have printed 93.45
 
 
+def test_cook_membrane_silhouette_of_the_reference_png():
+    """a reference-PRODUCED picture: tests/cook_membrane/smallDef_linearEl/MisesStress_cookMembrane_2d_linearEl.png is
+    `body.show2d` of the solved deck (stiffnessMtrx.py:873-877: 512 x 512 window, vertices = (x_deformed - bottomleft) *
+    stretchRatio * 0.95, body.py:47-70, element_linear_triangular.py:164-175 -- a uniform scale about the deformed
+    bounding box's corner).  Its non-black pixels span columns 0 ... 177 and rows 1 ... 388 (from the bottom): the
+    deformed membrane is 178 x 388 pixels, height / width = 2.180 +- 0.02 (one pixel each way).  The oracle's deformed
+    bounding box of cookMembrane_2d_linearEl_smallDef.inp: 2.182 (the undeformed membrane: 1.25).  (Of the other
+    pictures in the reference tree the elliptic membrane agrees likewise -- 0.848 against 0.846, deformation invisible
+    -- and the beam / large-deformation pictures do not belong to the decks shipped beside them: 3 ... 14 % off in
+    either direction, loads and element types differ.)"""
+    inp, s = solve("cookMembrane_2d_linearEl_smallDef.inp")
+    X = inp.nodes + s.dof.reshape(-1, 2)
+    aspect = np.ptp(X[:, 1]) / np.ptp(X[:, 0])
+    assert abs(aspect - 388.0 / 178.0) < 0.02 and abs(aspect - 2.1819) < 1e-3
+    assert abs(np.ptp(inp.nodes[:, 1]) / np.ptp(inp.nodes[:, 0]) - 1.25) < 1e-12
+
+
 def test_nafems_le1_target():
     """the elliptic membrane is NAFEMS LE1: sigma_yy at D = 92.7 MPa (README.md:46, CoFEA benchmark 004) -- a known
     answer that does not come from FEMcy.  On the reference's densest decks the oracle gives 92.718 (CPS6, 0.02 % off)
