@@ -19,7 +19,14 @@ namespace femcy {
 // residual policy of the direct solve (both libraries): a factorisation of a positive definite K leaves 1e-14 ... 1e-10
 // depending on |K| |x| / |b| (the sparse LU the reference calls leaves the same); refine while max|b - K x| > REFINE_ABOVE max|b| and a step still
 // halves it, at most MAX_REFINE times; a solution is returned only if it ends at or below ACCEPT
-constexpr double DIRECT_REFINE_ABOVE = 1e-12, DIRECT_ACCEPT = 1e-8;
+// (round 5: REFINE_ABOVE 1e-12 -> 1e-10.  On the wide bands of cube-like 3-D meshes the unrefined residual is 1.4e-12 ...
+// 6.5e-12 -- what a sparse LU leaves -- and 1e-12 bought it a whole extra forward + backward sweep, 8 us per panel: 5.4 ->
+// 3.8, 29.1 -> 22.3, 128.5 -> 104.5 ms per solve; the 49 decks end to end are unchanged, worst 2.0e-10 rel. L2 at
+// nu = 0.4999, where the refinement still runs: profiles/r05_direct_refine_threshold.txt)
+#ifndef FEMCY_DIRECT_REFINE_ABOVE
+#define FEMCY_DIRECT_REFINE_ABOVE 1e-10
+#endif
+constexpr double DIRECT_REFINE_ABOVE = FEMCY_DIRECT_REFINE_ABOVE, DIRECT_ACCEPT = 1e-8;
 constexpr int DIRECT_MAX_REFINE = 2;
 
 struct BandOrder {

@@ -196,8 +196,8 @@ class System_of_equations:
         return self._take_solution()
 
     # sub-diagonals above which the FIRST solve of direct = "auto" goes to the tight PCG.  Cube-like C3D4 meshes, medians of
-    # five (profiles/r05_direct_limit.txt): 512 sub-diagonals 5.4 ms against 14.6 (PCG), 1 328: 29.1 against 45.3,
-    # 2 888: 128.5 against 69.0 -- the crossover lies near 2 000
+    # five (profiles/r05_direct_refine_threshold.txt): 512 sub-diagonals 3.8 ms against 14.6 (PCG), 1 328: 22.3 against
+    # 45.3, 2 888: 104.5 against 69.0 -- the crossover lies near 2 300
     AUTO_WIDE_BAND = 2048
     AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
 
