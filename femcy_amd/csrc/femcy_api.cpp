@@ -367,6 +367,8 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->opt_persist_multi = (int)value;
             c->persist_multi_failed = false;
             break;
+        case FEMCY_TUNE_DIRECT_UPDATE:
+            return direct_set_update_variant(c, value);
         case FEMCY_TUNE_PERSIST_MAX_MB:
             FEMCY_REQUIRE(value >= 0 && value <= (1 << 20), "streamed-matrix limit of the persistent PCG: 0 (none) .. 2^20 MiB");
             c->persist_max_bytes = value == 0 ? ((int64_t)1 << 40) : ((int64_t)value << 20);

@@ -25,8 +25,9 @@
 //     of the factor in registers, v_readlane broadcast of the solved unknown), then every tile subtracts its share
 //     from the rows it couples to.
 // All launches sit on the context's stream in order; what returns to the host, in one synchronisation, is the pivot
-// flags and two residual norms.  The arithmetic is f64 VALU: the decks' bands are a few tiles wide and what is waited for
-// is the chain of dependent one-wave launches (~20 us per panel of 32 unknowns), not bytes or flops -- no MFMA reshaping.
+// flags and two residual norms.  The arithmetic is f64 VALU in the panel and sweep kernels: what is waited for there is
+// the chain of dependent one-wave launches (~20 us per panel of 32 unknowns), not bytes or flops.  The trailing update
+// -- the one dense small GEMM of the repository -- runs on the f64 matrix cores from 8 tiles per panel on (round 5).
 //
 // State lives beside the context (a table keyed by the context's address), created on first use and dropped by
 // femcy_ctx_destroy / a new pattern.
@@ -40,6 +41,12 @@ namespace femcy {
 namespace {
 
 constexpr int NB = 32;          // panel width = tile edge (DOF)
+// the trailing update runs on the f64 matrix cores from this many tiles per panel on (k_band_update_mfma, variant 1: one
+// tile pair per workgroup).  Measured (profiles/r05_direct_mfma_update.txt): 89 k-DOF cube 104.2 -> 85.6 ms, 27.8 k 22.3 ->
+// 20.2, the C3D10 twist deck 3.90 -> 3.61, the dense CPS6 deck 17.80 -> 16.67; variant 2 (2 x 2 tile pairs per workgroup)
+// is no faster than the VALU product (105.3 ms: a quarter of the workgroups, the same chain of target load -> stage ->
+// barrier -> product -> store in each): the update is bound by that latency chain, not by tile traffic
+constexpr int DIRECT_MFMA_MIN_TILES = 8, DIRECT_MFMA_VARIANT = 1;
 constexpr int TS = NB * NB;     // doubles per tile
 
 struct DirectState {
@@ -58,6 +65,7 @@ struct DirectState {
     double* d_norms = nullptr;    // max|res| (NaN if any entry is), max|b|
     int32_t* d_flag = nullptr;    // [0] 1 + first pivot that is zero / NaN, [1] negative pivots
     char* h_back = nullptr;       // pinned: 2 int32 + 2 doubles
+    int update_variant = -1;      // FEMCY_TUNE_DIRECT_UPDATE: -1 auto, 0 VALU, 1 / 2 matrix cores (k_band_update_mfma / _mfma2)
     BandOrder order;              // host copy of the band order of pattern `order_serial`
     int64_t order_serial = -1;
     void release() {
@@ -372,6 +380,94 @@ __global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, doubl
     tgt[(ty + 16) * NB + tx + 16] = t11 - c11;
 }
 
+// ---- round 5: the same update on the f64 matrix cores.  v_mfma_f64_16x16x4_f64: D(16 x 16) += A(16 x 4) B(4 x 16), one f64
+// of A and of B per lane (A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15]), four results per lane
+// (D[row = (lane >> 4) + 4 reg][col = lane & 15]: cdna_hip_programming.md "f64 MFMA does NOT use these maps").  The f64
+// matrix peak of MI355X equals its vector peak, so this is not about flops: the VALU product reads LDS once per FMA
+// (4 ds_read_b64 per 4 v_fma_f64: the kernel is LDS-bound, 11 TFLOP/s at 91 tiles), an MFMA consumes 128 operand values
+// per 2 reads per lane -- 8 x fewer LDS reads per flop -- and what is left is the traffic of the tiles themselves.
+typedef double femcy_d4 __attribute__((ext_vector_type(4)));
+
+// variant 1: one pair of panel tiles per workgroup as above, wave w = quadrant (w >> 1, w & 1) of the 32 x 32 target
+__global__ void __launch_bounds__(256) k_band_update_mfma(int32_t p, int32_t T, double* __restrict__ band,
+                                                          const double* __restrict__ sgn) {
+    const int bi = blockIdx.x + 1, bj = blockIdx.y + 1;
+    if (bj > bi) return;
+    __shared__ double A[NB][NB + 1];
+    __shared__ double B[NB][NB + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qi = wave >> 1, qj = wave & 1, r16 = lane & 15, k4 = lane >> 4;
+    const double* Lp = band + (int64_t)p * (T + 1) * TS;
+    double* tgt = band + ((int64_t)(p + bj) * (T + 1) + (bi - bj)) * TS + (16 * qi + k4) * NB + 16 * qj + r16;
+    double t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = tgt[4 * i * NB];                   // requested before the operands are staged
+    for (int e = tid; e < TS; e += 256) {
+        A[e / NB][e % NB] = Lp[(int64_t)bi * TS + e] * sgn[(int64_t)p * NB + e % NB];
+        B[e / NB][e % NB] = Lp[(int64_t)bj * TS + e];
+    }
+    __syncthreads();
+    femcy_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * qi + r16][4 * kk + k4], B[16 * qj + r16][4 * kk + k4], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tgt[4 * i * NB] = t[i] - acc[i];
+}
+
+// variant 2: a 2 x 2 block of tile pairs per workgroup (a 64 x 64 x 32 product): four operand tiles staged once serve
+// four products -- 20 KB of tile traffic per product instead of 32 -- wave w owns target tile (w >> 1, w & 1) of the block:
+// 4 quadrants x 8 k-steps = 32 MFMAs.  (With VALU arithmetic this blocking lost in round 4: four times the LDS-bound
+// work per workgroup; with the matrix cores the work per workgroup is ~0.2 us.)
+__global__ void __launch_bounds__(256) k_band_update_mfma2(int32_t p, int32_t T, int32_t Tp, double* __restrict__ band,
+                                                           const double* __restrict__ sgn) {
+    const int I = blockIdx.x, J = blockIdx.y;
+    if (J > I) return;
+    __shared__ double A[2][NB][NB + 1];
+    __shared__ double B[2][NB][NB + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave >> 1, wj = wave & 1, r16 = lane & 15, k4 = lane >> 4;
+    const int bi = 2 * I + 1 + wi, bj = 2 * J + 1 + wj;                       // this wave's tile pair
+    const bool mine = bi <= Tp && bj <= bi;
+    const double* Lp = band + (int64_t)p * (T + 1) * TS;
+    double* tgt = band + ((int64_t)(p + bj) * (T + 1) + (bi - bj)) * TS + k4 * NB + r16;
+    double t[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[a][b][i] = mine ? tgt[(16 * a + 4 * i) * NB + 16 * b] : 0.0;
+    for (int e = tid; e < 2 * TS; e += 256) {
+        const int w = e / TS, o = e % TS;
+        const int ti = 2 * I + 1 + w, tj = 2 * J + 1 + w;
+        A[w][o / NB][o % NB] = ti <= Tp ? Lp[(int64_t)ti * TS + o] * sgn[(int64_t)p * NB + o % NB] : 0.0;
+        B[w][o / NB][o % NB] = tj <= Tp ? Lp[(int64_t)tj * TS + o] : 0.0;
+    }
+    __syncthreads();
+    if (!mine) return;
+    femcy_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = femcy_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a0 = A[wi][r16][4 * kk + k4], a1 = A[wi][16 + r16][4 * kk + k4];
+        const double b0 = B[wj][r16][4 * kk + k4], b1 = B[wj][16 + r16][4 * kk + k4];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tgt[(16 * a + 4 * i) * NB + 16 * b] = t[a][b][i] - acc[a][b][i];
+}
+
 // forward substitution, panel p: z_p = L_pp^-1 b_p in the registers of the wave -- lane = row (both halves hold it), its
 // row of L_pp in 32 registers, column-oriented: z_c goes from lane c to all, every later row subtracts its multiple.
 // Workgroup 0 stores S z_p (the right-hand side of the backward sweep); workgroup g > 0 holds two tiles of the panel,
@@ -528,6 +624,12 @@ void direct_release(Ctx* c) {
     }
 }
 
+int direct_set_update_variant(Ctx* c, int64_t v) {
+    FEMCY_REQUIRE(v >= -1 && v <= 2, "direct solve, tile update: -1 (auto), 0 (VALU), 1 or 2 (matrix cores)");
+    state_of(c).update_variant = (int)v;
+    return FEMCY_OK;
+}
+
 int direct_set_max_bytes(Ctx* c, int64_t bytes) {
     FEMCY_REQUIRE(bytes >= (int64_t)1 << 20, "direct solve: the band limit must be at least 1 MiB");
     state_of(c).max_bytes = bytes;
@@ -591,7 +693,17 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
                 const int32_t Tp = std::min(T, P - 1 - p);
                 hipLaunchKernelGGL(k_band_panel, dim3(Tp + 1), dim3(64), 0, s, p, T, st.d_band, st.d_dfac, st.d_sgn, st.d_invd,
                                    st.d_flag, st.d_wb, st.d_wy);
-                if (Tp > 0) hipLaunchKernelGGL(k_band_update, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
+                if (Tp > 0) {
+                    // 0 = VALU product (rounds 4-5 default below MFMA_MIN_TILES), 1 = matrix cores, one tile pair per
+                    // workgroup, 2 = matrix cores, 2 x 2 tile pairs per workgroup
+                    const int var = st.update_variant >= 0 ? st.update_variant : (Tp >= DIRECT_MFMA_MIN_TILES ? DIRECT_MFMA_VARIANT : 0);
+                    if (var == 2)
+                        hipLaunchKernelGGL(k_band_update_mfma2, dim3((Tp + 1) / 2, (Tp + 1) / 2), dim3(256), 0, s, p, T, Tp, st.d_band, st.d_sgn);
+                    else if (var == 1)
+                        hipLaunchKernelGGL(k_band_update_mfma, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
+                    else
+                        hipLaunchKernelGGL(k_band_update, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
+                }
             }
         for (int32_t p = 0; p < P && !d_band_pad; ++p) {       // (the first solve's forward sweep rode with the panels)
             const int32_t Tp = std::min(T, P - 1 - p);

@@ -271,6 +271,67 @@ def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
     s.ctx.close()
 
 
+@pytest.mark.parametrize("name,cube", [("twist_plate_C3D10.inp", 0), ("ellip_dense_CPS6_0d04.inp", 0), (None, 12), (None, 15)])
+def test_tile_update_on_the_matrix_cores_equals_the_valu_product(gpu_ctx_factory, name, cube):
+    """FEMCY_TUNE_DIRECT_UPDATE: the trailing update of the band factorisation as a VALU tile product (0), on the f64 matrix
+    cores with one tile pair per workgroup (1) and with 2 x 2 tile pairs per workgroup (2; an odd tile count leaves
+    half-empty blocks on the last block row / the diagonal: 15^3 cells) -- the same factor: solutions agree to rounding,
+    each solves K x = b, indefinite K included"""
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    if name:
+        inp, el, mat = load(name)
+        ctx = make_ctx(gpu_ctx_factory, inp, el, mat)
+        cons = constrained(inp, ctx.dm)
+    else:
+        m = meshgen.twist_plate(cube, cube, cube)
+        ctx = gpu_ctx_factory()
+        ctx.set_mesh(m["nodes"], m["elements"])
+        ctx.set_element(Element_linear_tetrahedral())
+        ctx.set_material(LinearIsotropic(*m["elastic"]))
+        ctx.build_pattern()
+        cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in m["dirichlet_bc_info"]]))
+    rng = np.random.default_rng(5)
+    for indefinite in (False, True):
+        if indefinite:                       # a displaced configuration with inverted elements: K = L S L^T with negative pivots
+            u = 0.3 * np.ptp(ctx_nodes(ctx, name, cube), axis=0).max() * rng.standard_normal(ctx.n) / 20.0
+            ctx.upload(be.VEC_DOF, u)
+            ctx.assemble_K(be.VEC_DOF)
+        else:
+            ctx.assemble_K(-1)
+        ctx.upload(be.VEC_RESIDUAL, rng.standard_normal(ctx.n))
+        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        b = ctx.download(be.VEC_RESIDUAL)
+        K = ctx.get_K_bsr().tocsr()
+        xs, infos = {}, {}
+        for var in (0, 1, 2):
+            ctx.set_option(be.TUNE_DIRECT_UPDATE, var)
+            try:
+                infos[var] = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
+                xs[var] = ctx.download(be.VEC_X)
+            except be.FemcyError as e:       # elimination without pivoting may lose an indefinite matrix: then every variant must
+                assert e.status == be.FEMCY_ENUMERIC and indefinite
+                infos[var] = None
+        ctx.set_option(be.TUNE_DIRECT_UPDATE, -1)
+        assert len({v is None for v in infos.values()}) == 1
+        if infos[0] is None:
+            continue
+        assert infos[0]["bandwidth"] // 32 >= 8                     # wide enough for the matrix-core path to be the one in use
+        assert infos[1]["negative_pivots"] == infos[2]["negative_pivots"] == infos[0]["negative_pivots"]
+        if indefinite:
+            assert infos[0]["negative_pivots"] > 0
+        for var in (0, 1, 2):
+            assert np.abs(K @ xs[var] - b).max() <= 1e-8 * np.abs(b).max()
+            assert np.linalg.norm(xs[var] - xs[0]) <= 1e-9 * np.linalg.norm(xs[0])
+    ctx.close() if not name else None
+
+
+def ctx_nodes(ctx, name, cube):
+    from femcy_amd import meshgen
+    return load(name)[0].nodes if name else meshgen.twist_plate(cube, cube, cube)["nodes"]
+
+
 def test_direct_solve_refuses_a_partitioned_system(gpu_ctx_factory):
     from femcy_amd import backend as be
     inp, el, mat = load("twist_plate_C3D4.inp")

@@ -22,6 +22,8 @@ def main():
         ctx.set_element(Element_linear_tetrahedral())
         ctx.set_material(LinearIsotropic(*m["elastic"]))
         ctx.build_pattern()
+        if os.environ.get("VARIANT"):                          # FEMCY_TUNE_DIRECT_UPDATE: 0 VALU, 1 / 2 matrix cores
+            ctx.set_option(be.TUNE_DIRECT_UPDATE, int(os.environ["VARIANT"]))
         ctx.assemble_K(-1)
         cons = np.unique(np.concatenate([np.asarray(b["node_set"]) * 3 + b["dof"] for b in m["dirichlet_bc_info"]]))
         ctx.upload(be.VEC_RESIDUAL, np.random.default_rng(0).standard_normal(ctx.n))
