@@ -47,6 +47,11 @@ constexpr int NB = 32;          // panel width = tile edge (DOF)
 // is no faster than the VALU product (105.3 ms: a quarter of the workgroups, the same chain of target load -> stage ->
 // barrier -> product -> store in each): the update is bound by that latency chain, not by tile traffic
 constexpr int DIRECT_MFMA_MIN_TILES = 8, DIRECT_MFMA_VARIANT = 1;
+// variant 3 (the update on two streams: the column the next panel needs first, the rest beside that panel) is NOT a default:
+// measured slower at every size -- 89 k-DOF cube 86.1 -> 100.2 ms, 27.8 k 20.3 -> 28.0, dense CPS6 deck 16.75 -> 28.44
+// (profiles/r05_direct_mfma_update.txt): two event hand-overs per panel between the streams cost more than the
+// overlap of a 15 us update with a 10 us panel returns.  Kept as a tested knob.
+constexpr int DIRECT_OVERLAP_MIN_TILES = 24, DIRECT_OVERLAP_VARIANT = -1;
 constexpr int TS = NB * NB;     // doubles per tile
 
 struct DirectState {
@@ -65,7 +70,11 @@ struct DirectState {
     double* d_norms = nullptr;    // max|res| (NaN if any entry is), max|b|
     int32_t* d_flag = nullptr;    // [0] 1 + first pivot that is zero / NaN, [1] negative pivots
     char* h_back = nullptr;       // pinned: 2 int32 + 2 doubles
-    int update_variant = -1;      // FEMCY_TUNE_DIRECT_UPDATE: -1 auto, 0 VALU, 1 / 2 matrix cores (k_band_update_mfma / _mfma2)
+    int update_variant = -1;      // FEMCY_TUNE_DIRECT_UPDATE: -1 auto, 0 VALU, 1 / 2 matrix cores (k_band_update_mfma / _mfma2),
+                                  // 3 = 1 on two streams (the update beside the next panel)
+    static constexpr int NEV = 16;
+    hipStream_t s2 = nullptr;     // second stream + event ring of the two-stream schedule (created on first use)
+    hipEvent_t ev[NEV] = {nullptr};
     BandOrder order;              // host copy of the band order of pattern `order_serial`
     int64_t order_serial = -1;
     void release() {
@@ -73,6 +82,15 @@ struct DirectState {
                         (void*)d_wx, (void*)d_res, (void*)d_Kx, (void*)d_norms, (void*)d_flag})
             if (q) (void)hipFree(q);
         if (h_back) (void)hipHostFree(h_back);
+        if (s2) {
+            (void)hipStreamSynchronize(s2);
+            (void)hipStreamDestroy(s2);
+            for (hipEvent_t& e : ev) {
+                if (e) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+            s2 = nullptr;
+        }
         d_rank = d_node_at = d_flag = nullptr;
         d_band = d_dfac = d_sgn = d_invd = d_wb = d_wy = d_wx = d_res = d_Kx = d_norms = nullptr;
         h_back = nullptr;
@@ -389,9 +407,11 @@ __global__ void __launch_bounds__(256) k_band_update(int32_t p, int32_t T, doubl
 typedef double femcy_d4 __attribute__((ext_vector_type(4)));
 
 // variant 1: one pair of panel tiles per workgroup as above, wave w = quadrant (w >> 1, w & 1) of the 32 x 32 target
-__global__ void __launch_bounds__(256) k_band_update_mfma(int32_t p, int32_t T, double* __restrict__ band,
+// (bj_off: the launch covers target columns bj_off + 1 ... of the panel's update -- the two-stream schedule below splits
+// the update into the column the next panel needs and the rest)
+__global__ void __launch_bounds__(256) k_band_update_mfma(int32_t p, int32_t T, int32_t bj_off, double* __restrict__ band,
                                                           const double* __restrict__ sgn) {
-    const int bi = blockIdx.x + 1, bj = blockIdx.y + 1;
+    const int bi = blockIdx.x + 1, bj = blockIdx.y + 1 + bj_off;
     if (bj > bi) return;
     __shared__ double A[NB][NB + 1];
     __shared__ double B[NB][NB + 1];
@@ -625,7 +645,7 @@ void direct_release(Ctx* c) {
 }
 
 int direct_set_update_variant(Ctx* c, int64_t v) {
-    FEMCY_REQUIRE(v >= -1 && v <= 2, "direct solve, tile update: -1 (auto), 0 (VALU), 1 or 2 (matrix cores)");
+    FEMCY_REQUIRE(v >= -1 && v <= 3, "direct solve, tile update: -1 (auto), 0 (VALU), 1 or 2 (matrix cores), 3 (1 on two streams)");
     state_of(c).update_variant = (int)v;
     return FEMCY_OK;
 }
@@ -685,9 +705,16 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
                                c->d_node_of, c->d_rowlen, c->d_bcol, c->d_Kvals, st.d_rank, T, st.d_band);
     }
     // band order of a right-hand side, the two sweeps, back to the caller's numbering (set or add)
-    auto solve_into = [&](const double* d_rhs, double* d_out, int add, double* d_band_pad) {
+    auto solve_into = [&](const double* d_rhs, double* d_out, int add, double* d_band_pad) -> int {
         hipLaunchKernelGGL(k_band_gather, dim3((P * NB + 255) / 256), dim3(256), 0, s, c->n, P, c->dm, T, st.d_node_at, d_rhs,
                            st.d_wb, d_band_pad);
+        hipEvent_t prev_rest = nullptr;
+        bool have_rest = false;
+        const int want = st.update_variant >= 0 ? st.update_variant : (T >= DIRECT_OVERLAP_MIN_TILES ? DIRECT_OVERLAP_VARIANT : -1);
+        if (want == 3 && !st.s2) {
+            FEMCY_HIP(hipStreamCreateWithFlags(&st.s2, hipStreamNonBlocking));
+            for (hipEvent_t& e : st.ev) FEMCY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         if (d_band_pad)   // first call: the factorisation sits between the padding of the band and the sweeps
             for (int32_t p = 0; p < P; ++p) {
                 const int32_t Tp = std::min(T, P - 1 - p);
@@ -696,15 +723,34 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
                 if (Tp > 0) {
                     // 0 = VALU product (rounds 4-5 default below MFMA_MIN_TILES), 1 = matrix cores, one tile pair per
                     // workgroup, 2 = matrix cores, 2 x 2 tile pairs per workgroup
-                    const int var = st.update_variant >= 0 ? st.update_variant : (Tp >= DIRECT_MFMA_MIN_TILES ? DIRECT_MFMA_VARIANT : 0);
+                    const int var = want >= 0 ? want : (Tp >= DIRECT_MFMA_MIN_TILES ? DIRECT_MFMA_VARIANT : 0);
                     if (var == 2)
                         hipLaunchKernelGGL(k_band_update_mfma2, dim3((Tp + 1) / 2, (Tp + 1) / 2), dim3(256), 0, s, p, T, Tp, st.d_band, st.d_sgn);
-                    else if (var == 1)
-                        hipLaunchKernelGGL(k_band_update_mfma, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
+                    else if (var == 3 && Tp >= 2) {
+                        // two-stream schedule (round 5): panel p + 1 needs only the tiles of column p + 1 updated, i.e. the
+                        // bj = 1 column of this update; that part stays on the main stream, the rest (bj >= 2) runs on a
+                        // second stream beside panel p + 1.  Orderings: rest(p) after panel(p) [its operands]; rest(p)
+                        // after rest(p - 1) [same stream: they meet in the same target tiles]; first(p) after rest(p - 1)
+                        // [both write column p + 1] -- rest(p) and first(p) write disjoint columns, rest(p) does not touch
+                        // column p + 1, which panel p + 1 factors meanwhile.
+                        hipEvent_t ep = st.ev[(2 * p) % DirectState::NEV], er = st.ev[(2 * p + 1) % DirectState::NEV];
+                        FEMCY_HIP(hipEventRecord(ep, s));                                   // panel(p) done
+                        if (have_rest) FEMCY_HIP(hipStreamWaitEvent(s, prev_rest, 0));      // rest(p - 1) done before first(p)
+                        hipLaunchKernelGGL(k_band_update_mfma, dim3(Tp, 1), dim3(256), 0, s, p, T, 0, st.d_band, st.d_sgn);
+                        FEMCY_HIP(hipStreamWaitEvent(st.s2, ep, 0));
+                        hipLaunchKernelGGL(k_band_update_mfma, dim3(Tp, Tp - 1), dim3(256), 0, st.s2, p, T, 1, st.d_band, st.d_sgn);
+                        FEMCY_HIP(hipEventRecord(er, st.s2));
+                        prev_rest = er;
+                        have_rest = true;
+                    } else if (var == 1 || var == 3) {
+                        if (have_rest) FEMCY_HIP(hipStreamWaitEvent(s, prev_rest, 0));      // (the last panels of a two-stream run)
+                        hipLaunchKernelGGL(k_band_update_mfma, dim3(Tp, Tp), dim3(256), 0, s, p, T, 0, st.d_band, st.d_sgn);
+                    }
                     else
                         hipLaunchKernelGGL(k_band_update, dim3(Tp, Tp), dim3(256), 0, s, p, T, st.d_band, st.d_sgn);
                 }
             }
+        if (have_rest) FEMCY_HIP(hipStreamWaitEvent(s, prev_rest, 0));   // the sweeps read what the second stream wrote last
         for (int32_t p = 0; p < P && !d_band_pad; ++p) {       // (the first solve's forward sweep rode with the panels)
             const int32_t Tp = std::min(T, P - 1 - p);
             hipLaunchKernelGGL(k_band_fwd, dim3(1 + (Tp + 1) / 2), dim3(64), 0, s, p, T, Tp, st.d_band, st.d_dfac, st.d_sgn,
@@ -717,6 +763,7 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
         }
         hipLaunchKernelGGL(k_band_scatter, dim3((int)((c->n + 255) / 256)), dim3(256), 0, s, c->n, c->dm, st.d_node_at,
                            st.d_wx, d_out, add);
+        return FEMCY_OK;
     };
     int32_t* h_flag = reinterpret_cast<int32_t*>(st.h_back);
     double* h_norms = reinterpret_cast<double*>(st.h_back + 16);
@@ -732,7 +779,7 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
     };
     // the pivot flags travel with the first residual: one host synchronisation per solve, not two (a singular matrix
     // costs a product nobody looks at)
-    solve_into(d_b, d_x, 0, st.d_band);
+    if ((rc = solve_into(d_b, d_x, 0, st.d_band))) return rc;
     FEMCY_HIP(hipMemcpyAsync(h_flag, st.d_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     double rel = 0.0;
     if ((rc = residual(&rel))) return rc;
@@ -744,7 +791,7 @@ int direct_solve(Ctx* c, const double* d_b, double* d_x, femcy_direct_info* info
         return FEMCY_ENUMERIC;
     }
     while (info->refinements < DIRECT_MAX_REFINE && rel > DIRECT_REFINE_ABOVE) {
-        solve_into(st.d_res, d_x, 1, nullptr);
+        if ((rc = solve_into(st.d_res, d_x, 1, nullptr))) return rc;
         ++info->refinements;
         double rel2 = 0.0;
         if ((rc = residual(&rel2))) return rc;

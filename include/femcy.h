@@ -196,7 +196,8 @@ enum femcy_option {
                                         per slice that keep the default cache policy (they stay in the XCD's L2)     */
     FEMCY_TUNE_DIRECT_UPDATE = 115,  /* femcy_direct_solve, trailing tile update: -1 auto (default), 0 = VALU product, 1 = f64
                                         matrix cores (v_mfma_f64_16x16x4_f64), one tile pair per workgroup, 2 = matrix
-                                        cores, 2 x 2 tile pairs per workgroup (tests, comparison records)             */
+                                        cores, 2 x 2 tile pairs per workgroup, 3 = 1 on two streams: the tiles the next panel
+                                        needs first, the rest beside that panel (tests, comparison records)          */
     FEMCY_TUNE_PERSIST_MAX_MB = 114, /* persistent PCG: largest STREAMED part of the matrix (MiB) it takes; 0 = no limit
                                         (default since round 5: 61 against 78 us per iteration on the 124 k C3D10 plate
                                         whose 287 MB stream comes from HBM); rounds 2-4 used 240 (tests, comparison

@@ -274,8 +274,9 @@ def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
 @pytest.mark.parametrize("name,cube", [("twist_plate_C3D10.inp", 0), ("ellip_dense_CPS6_0d04.inp", 0), (None, 12), (None, 15)])
 def test_tile_update_on_the_matrix_cores_equals_the_valu_product(gpu_ctx_factory, name, cube):
     """FEMCY_TUNE_DIRECT_UPDATE: the trailing update of the band factorisation as a VALU tile product (0), on the f64 matrix
-    cores with one tile pair per workgroup (1) and with 2 x 2 tile pairs per workgroup (2; an odd tile count leaves
-    half-empty blocks on the last block row / the diagonal: 15^3 cells) -- the same factor: solutions agree to rounding,
+    cores with one tile pair per workgroup (1), with 2 x 2 tile pairs per workgroup (2; an odd tile count leaves
+    half-empty blocks on the last block row / the diagonal: 15^3 cells) and as 1 on two streams (3: the column the next
+    panel needs first, the rest beside that panel) -- the same factor: solutions agree to rounding,
     each solves K x = b, indefinite K included"""
     from femcy_amd import backend as be, meshgen
     from femcy_amd.element_zoo import Element_linear_tetrahedral
@@ -305,7 +306,7 @@ def test_tile_update_on_the_matrix_cores_equals_the_valu_product(gpu_ctx_factory
         b = ctx.download(be.VEC_RESIDUAL)
         K = ctx.get_K_bsr().tocsr()
         xs, infos = {}, {}
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3):
             ctx.set_option(be.TUNE_DIRECT_UPDATE, var)
             try:
                 infos[var] = ctx.direct_solve(be.VEC_RESIDUAL, be.VEC_X)
@@ -318,10 +319,11 @@ def test_tile_update_on_the_matrix_cores_equals_the_valu_product(gpu_ctx_factory
         if infos[0] is None:
             continue
         assert infos[0]["bandwidth"] // 32 >= 8                     # wide enough for the matrix-core path to be the one in use
-        assert infos[1]["negative_pivots"] == infos[2]["negative_pivots"] == infos[0]["negative_pivots"]
+        assert infos[1]["negative_pivots"] == infos[2]["negative_pivots"] == infos[3]["negative_pivots"] == infos[0]["negative_pivots"]
         if indefinite:
             assert infos[0]["negative_pivots"] > 0
-        for var in (0, 1, 2):
+        assert np.array_equal(xs[3], xs[1])                         # the two-stream schedule runs the same kernels on the same data
+        for var in (0, 1, 2, 3):
             assert np.abs(K @ xs[var] - b).max() <= 1e-8 * np.abs(b).max()
             assert np.linalg.norm(xs[var] - xs[0]) <= 1e-9 * np.linalg.norm(xs[0])
     ctx.close() if not name else None
