@@ -40,7 +40,7 @@ class System_of_equations:
     def __init__(self, body: Body, material, geometric_nonlinear: bool, device: int = 0, verbose: bool = True,
                  direct_eps: float = 1.0e-12, cg_eps: float = 1.0e-3, ctx: "be.Context" = None,
                  part=None, comm_uid: bytes = None, tangent: str = "reference", exchange: str = "allreduce",
-                 gather_blobs=None, direct: str = "auto"):
+                 gather_blobs=None, direct: str = "auto", cg_branch_from: float = 1.0e5):
         """part / comm_uid: this process (or thread) holds one element partition of the mesh
         (`femcy_amd.partition.Part`, `body` built from its local nodes / elements) and joins the communicator
         `comm_uid` (RCCL unique id, or an in-process group id); every rank then runs the same `solve`."""
@@ -53,6 +53,9 @@ class System_of_equations:
         self.C = material.C
         self.verbose = verbose
         self.direct_eps, self.cg_eps = direct_eps, cg_eps
+        # `solve_dof` (reference :272-276) sends systems of at least 1e5 DOF to its CG (eps = 1e-3, maxit = n); the constant
+        # is a parameter here so that the CG leg can be driven on any deck (tests: cg_branch_from = 0)
+        self.cg_branch_from = cg_branch_from
         if direct not in ("auto", "cholesky", "pcg"):
             raise ValueError("direct must be 'auto' (default: whichever of the two is faster on this system), 'cholesky' "
                              "(band factorisation on the device) or 'pcg' (tight PCG)")
@@ -289,7 +292,7 @@ class System_of_equations:
         return du
 
     def solve_dof(self):
-        if self.n_system < 1e5:                        # DOFs of the whole system (all ranks take the same branch)
+        if self.n_system < self.cg_branch_from:        # DOFs of the whole system (all ranks take the same branch)
             return self.solve_by_scipy()
         return self.solve_by_CG()
 

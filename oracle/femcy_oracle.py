@@ -584,7 +584,7 @@ class OracleSystem:
 
     def __init__(self, nodes, elements, abaqus_type: str, material: Material, geometric_nonlinear: bool,
                  linear_solver: str = "reference", cg_eps: float = 1.0e-3, verbose: bool = False,
-                 cg_backend: str = "numpy"):
+                 cg_backend: str = "numpy", cg_threads: Optional[int] = None):
         """cg_backend "c": the CG branch runs in oracle/femcy_oracle.c (`orc_cg_solve`: the reference's ELL arrays,
         thread-per-row product, one pass per kernel) -- same recurrence as `pcg_reference`, fast enough for the
         >= 1e5-DOF systems that take the reference's CG branch (a numpy run of 8e5 iterations would take hours).
@@ -609,6 +609,7 @@ class OracleSystem:
         self.linear_solver = linear_solver    # "reference": <1e5 spsolve else CG (stiffnessMtrx.py:272-276)
         self.cg_eps = cg_eps
         self.cg_backend = cg_backend
+        self.cg_threads = cg_threads          # C backend: OpenMP threads of the CG (1 = serial sums, the reductions as written)
         self._co = None
         self.verbose = verbose
         self.log: List[dict] = []             # one entry per linear solve / residual evaluation
@@ -664,6 +665,13 @@ class OracleSystem:
         # CSR values ARE the ELL rows (`sparseMtrx_rowMajor`, stiffnessMtrx.py:91-94)
         assert K.nnz == int(co.ij[:, 0].sum()), "K lost its structural pattern"
         co.A[self._co_mask] = K.data
+        if self.cg_threads:
+            keep = co.threads()
+            co.set_threads(self.cg_threads)
+            try:
+                return co.cg(b, eps=self.cg_eps)
+            finally:
+                co.set_threads(keep)
         return co.cg(b, eps=self.cg_eps)
 
     def impose_boundary_condition(self, bcs):

@@ -145,3 +145,6 @@ def test_cg_branch_of_the_driver_on_the_cpu_backend():
     tail = _run(["test_gpu_cg_branch.py"], k="beam_lin or fine_per_solve")
     assert "2 passed" in tail
     print("[cpu backend] CG branch:", tail)
+    # ... and the reference's own decks on that leg (cg_branch_from = 0): the single-solve ones here, all 48 in the GPU suite
+    tail = _run(["test_gpu_cg_branch.py"], k="cg_leg and (ellip_ or cook_3d or smallD or smallDef)")
+    print("[cpu backend] CG leg on the decks:", tail)
