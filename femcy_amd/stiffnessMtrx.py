@@ -66,7 +66,7 @@ class System_of_equations:
         # memory bandwidth); on 2-D decks and 3-D ones up to ~4e4 DOF the factorisation wins by 1.5 ... 20 x, on 3-D
         # meshes towards 1e5 DOF (bands of 2 000 ... 2 900 sub-diagonals) the PCG is up to 2 x faster
         # (profiles/r05_direct_limit.txt).  First solve: by the band (femcy_direct_plan); from then on by the measured
-        # times of both (the other one is tried once, on the second solve, if the first took more than 5 ms).
+        # times of both (each timed twice, alternating, if the first solve took more than 5 ms: `_auto_method`).
         self._auto = {"first": None, "ms": {}, "tried": set(), "pcg_ok": True, "pick": None}
 
         # ---- device state: mesh, element tables, material, sparsity pattern
@@ -205,7 +205,10 @@ class System_of_equations:
     AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
 
     def _auto_method(self) -> str:
-        """direct = "auto": 'cholesky' or 'pcg' for the next solve of the reference's direct branch."""
+        """direct = "auto": 'cholesky' or 'pcg' for the next solve of the reference's direct branch.  First solve: by the
+        band; if it took more than AUTO_TRY_OTHER_MS the next three solves alternate other / first / other, so that each
+        method is timed twice (the first call of either carries one-off costs: band allocation, hipGraph capture), and the
+        faster one (minimum of its samples) serves the rest of the run."""
         a = self._auto
         if a["pick"] is not None:
             return a["pick"]
@@ -218,15 +221,19 @@ class System_of_equations:
                 wide = False
             a["first"] = "pcg" if wide else "cholesky"
             return a["first"]
-        other = "pcg" if a["first"] == "cholesky" else "cholesky"
-        if other == "pcg" and not a["pcg_ok"]:
+        first = a["first"]
+        other = "pcg" if first == "cholesky" else "cholesky"
+        if not a["pcg_ok"]:
             a["pick"] = "cholesky"
-        elif other not in a["tried"] and a["ms"].get(a["first"], 0.0) > self.AUTO_TRY_OTHER_MS:
-            return other
-        elif other in a["ms"] and a["first"] in a["ms"]:
-            a["pick"] = min(a["ms"], key=a["ms"].get)
+        elif first in a["ms"] and a["ms"][first] <= self.AUTO_TRY_OTHER_MS:
+            a["pick"] = first                                    # a millisecond-sized solve: nothing to gain by exploring
         else:
-            a["pick"] = a["first"]
+            cnt = a.setdefault("samples", {})
+            if cnt.get(other, 0) < cnt.get(first, 0) and cnt.get(other, 0) < 2:
+                return other
+            if cnt.get(first, 0) < 2:
+                return first
+            a["pick"] = min(a["ms"], key=a["ms"].get) if a["ms"] else first
         return a["pick"]
 
     def solve_by_scipy(self):
@@ -242,6 +249,7 @@ class System_of_equations:
                 du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
                 if self.PCG.converged:
                     a["ms"]["pcg"] = min(a["ms"].get("pcg", 1e30), (time.perf_counter() - t0) * 1e3)
+                    a.setdefault("samples", {})["pcg"] = a.get("samples", {}).get("pcg", 0) + 1
                     return du
                 # not converged within 10 n iterations (nu -> 0.5, an indefinite Newton iterate): this solve is redone
                 # by the factorisation, and the PCG is out of the race for this system
@@ -254,6 +262,9 @@ class System_of_equations:
             du = self._solve_direct()
             if self.direct_info is not None:
                 a["ms"]["cholesky"] = min(a["ms"].get("cholesky", 1e30), (time.perf_counter() - t0) * 1e3)
+            # (a rejected factorisation -- ENUMERIC, served by the tight PCG inside _solve_direct -- still counts as a sample:
+            # the exploration must end)
+            a.setdefault("samples", {})["cholesky"] = a.get("samples", {}).get("cholesky", 0) + 1
             return du
         return self._solve_direct()
 
