@@ -199,9 +199,9 @@ class System_of_equations:
         return self._take_solution()
 
     # sub-diagonals above which the FIRST solve of direct = "auto" goes to the tight PCG.  Cube-like C3D4 meshes, medians of
-    # five (profiles/r05_direct_refine_threshold.txt): 512 sub-diagonals 3.8 ms against 14.6 (PCG), 1 328: 22.3 against
-    # 45.3, 2 888: 104.5 against 69.0 -- the crossover lies near 2 300
-    AUTO_WIDE_BAND = 2048
+    # five (profiles/r05_direct_mfma_update.txt): 512 sub-diagonals 3.7 ms against 14.6 (PCG), 1 328: 20.3 against 45.3,
+    # 2 192: 51.0 against 59.1, 2 888: 86.4 against 69.0 -- the crossover lies near 2 500
+    AUTO_WIDE_BAND = 2560
     AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
 
     def _auto_method(self) -> str:

@@ -228,7 +228,7 @@ def test_driver_takes_the_direct_branch_and_falls_back_loudly(capsys):
 def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
     """direct = "auto" (the default): the reference switches solvers on a DOF count alone (stiffnessMtrx.py:272-276); here
     the stand-in for its spsolve is chosen by the band first (femcy_direct_plan) and by measured times afterwards.
-    A cube-like 3-D mesh (59 k DOF, 2 200 sub-diagonals: n * bw^2 = 2.9e11 flops behind 1 846 dependent panels) starts
+    A cube-like 3-D mesh (89 k DOF, 2 888 sub-diagonals: n * bw^2 = 7.5e11 flops behind 2 793 dependent panels) starts
     with the tight PCG; the 2-D decks and the slender twist plates start -- and stay -- with the factorisation.  Either
     way the answer is the factorisation's to 1e-9."""
     from types import SimpleNamespace
@@ -237,7 +237,7 @@ def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
     from femcy_amd.element_zoo import Element_linear_tetrahedral
     from femcy_amd.material_zoo import LinearIsotropic
     from femcy_amd.stiffnessMtrx import System_of_equations
-    m = meshgen.twist_plate(26, 26, 26)
+    m = meshgen.twist_plate(30, 30, 30)
     ELE = Element_linear_tetrahedral()
     ti = dict(m["time_incs"], ini_inc=0.002, max_inc=0.002, max_time=0.008)         # four small increments of twist: >= 4 solves
     inp = SimpleNamespace(nodes=m["nodes"], eSets={"C3D4": m["elements"]}, ELE=ELE, dirichlet_bc_info=m["dirichlet_bc_info"],
@@ -259,7 +259,7 @@ def test_auto_chooses_between_the_factorisation_and_the_tight_pcg():
     assert sc["cg_iterations"] == 0 and sc["direct_solves"] == sc["linear_solves"]
     assert [(i["time1"], i["converged"], i["newton_loop"]) for i in inca] == [(i["time1"], i["converged"], i["newton_loop"]) for i in incc]
     assert np.linalg.norm(ua - uc) <= 1e-9 * np.linalg.norm(uc)
-    print(f"[auto] 26^3 cube: plan {plan}, first {auto['first']}, ms {auto['ms']}, pick {auto['pick']}")
+    print(f"[auto] 30^3 cube: plan {plan}, first {auto['first']}, ms {auto['ms']}, pick {auto['pick']}")
     # a deck with a narrow band: the factorisation from the first solve on, the PCG never runs
     inp2, el2, mat2 = load("twist_plate_C3D4.inp")
     s = System_of_equations(Body(inp2.nodes, el2, inp2.ELE), mat2, inp2.geometric_nonlinear, verbose=False)
