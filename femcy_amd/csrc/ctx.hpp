@@ -194,6 +194,7 @@ struct Ctx {
     // against 78.0 (profiles/r05_persist_hbm_c3d10.txt) -- the rule was stale.  What bounds the kernel is the vector
     // layout (<= 4 slices per wave), not the matrix: no byte limit by default any more (test knob: option 114)
     int64_t persist_max_bytes = (int64_t)1 << 40;
+    int tune_rows4_tile = 0;          // FEMCY_TUNE_ROWS4_TILE: 1000 GP + LCUT, 0 = off (round-5 experiment, kernels_assembly.hip)
     int opt_persist_rj = 4;           // block rows per slice kept in registers (test knob 105)
     int opt_persist_wgs = 0;          // test knob 107: workgroups of the launch (0 = one per CU; more than that cannot
                                       // be co-resident, the barrier times out and the solve falls back)

@@ -369,6 +369,11 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             break;
         case FEMCY_TUNE_DIRECT_UPDATE:
             return direct_set_update_variant(c, value);
+        case FEMCY_TUNE_ROWS4_TILE:
+            FEMCY_REQUIRE(value == 0 || ((value / 1000 == 2 || value / 1000 == 4) && value % 1000 > 0),
+                          "ROWS4 tile write-out: 0 (off) or 1000 GP + LCUT with GP 2 or 4 and LCUT > 0 blocks");
+            c->tune_rows4_tile = (int)value;
+            break;
         case FEMCY_TUNE_PERSIST_MAX_MB:
             FEMCY_REQUIRE(value >= 0 && value <= (1 << 20), "streamed-matrix limit of the persistent PCG: 0 (none) .. 2^20 MiB");
             c->persist_max_bytes = value == 0 ? ((int64_t)1 << 40) : ((int64_t)value << 20);

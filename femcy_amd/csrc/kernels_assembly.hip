@@ -1001,8 +1001,15 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
 //   * at the end of a pair of rows each lane takes one stored block (32 per trip: one trip for most rows) out of LDS,
 //     leaves zeros, applies the material constants and stores its five pieces.
 // Deterministic for the same reason as rows2 (fixed step order, ds_add_f64 of one instruction applied in lane order).
-template <int NPE, int NGP, bool CUBIC>
-__global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax, const int32_t* __restrict__ order,
+//
+// GP > 0 (round 5, the verdict's "a wave owns adjacent rows and writes whole lines from its own LDS tile"; experiment,
+// FEMCY_TUNE_ROWS4_TILE = 1000 GP + LCUT): in slices no wider than `lcut` blocks a wave owns 16 CONSECUTIVE rows, keeps the finished
+// rows of GP pairs (2 GP adjacent rows) in a tile of its own LDS and writes them out together: a store instruction
+// then covers 32 GP contiguous bytes of 32 / GP slots instead of 32 bytes of 32 slots -- no workgroup barrier (rows3
+// lost 57 us to one).  Wider slices (the corner nodes' rows) run as before.
+template <int NPE, int NGP, bool CUBIC, int GP>
+__global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax, int32_t lcut, int32_t wstride,
+                                                        const int32_t* __restrict__ order,
                                                         const int32_t* __restrict__ ne_ptr,
                                                         const int32_t* __restrict__ ne_idx,
                                                         const uint16_t* __restrict__ slotj,
@@ -1023,10 +1030,9 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     const int grp = lane >> 5, gl = lane & 31, gbase = grp * G;
     const int q = gl / NPE, t = gl - q * NPE;                    // element of the step, column node
     const int accw = (Lmax * DD + 1) & ~1;
-    double* wbase = lds_rows4 + (size_t)wave * 2 * (EPG * RD + VOLW + accw + 2);
-    double* rec = wbase + (size_t)grp * (EPG * RD + VOLW + accw + 2);      // this half's records
-    double* vl = rec + EPG * RD;
-    double* acc = vl + VOLW;
+    constexpr int RG = GP ? 2 * GP : 2;                          // rows of a tile
+    const int accw_t = (lcut * DD) | 1;                          // an odd number of doubles: the rows of a tile start in different banks
+    double* wbase = lds_rows4 + (size_t)wave * wstride;
     // workgroup b takes the b-th slice in order of decreasing work (pattern.cpp: `asm_order`).  Workgroups are dispatched
     // in index order and run on XCD b % 8 (observed; speed only): longest first gives every XCD an even share of every
     // weight class and lets the short slices fill the tail.  Round 4: in plain slice order a row order whose long rows
@@ -1039,6 +1045,11 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     const int64_t off_v = slice_off[s];
     const int64_t off = ((int64_t)__builtin_amdgcn_readfirstlane((int32_t)(off_v >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)off_v);
+    const bool tile = GP > 0 && __builtin_amdgcn_readfirstlane((int32_t)(slice_off[s + 1] - off_v)) <= lcut;   // the slice's width
+    double* rec = wbase + (size_t)grp * (tile ? EPG * RD + VOLW + 2 : EPG * RD + VOLW + accw + 2);     // this half's records
+    double* vl = rec + EPG * RD;
+    double* acc = vl + VOLW;                                     // pair layout: this half's row
+    double* tbase = wbase + 2 * (EPG * RD + VOLW + 2);           // tile layout: RG rows of accw_t
 
     // ---- the wave's rows: pair b = slice lanes 8 b + 2 wave and + 1 -- ADJACENT rows, so that the two halves of a
     // store instruction write neighbouring 16-byte pieces of the same line (one request instead of two), and the eight
@@ -1048,7 +1059,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     int32_t m_L = 0, m_k0 = 0, m_cnt = 0;
     bool m_valid = false;
     if (lane < RPW) {
-        const int32_t a = node_of[(int64_t)s * SLICE + 8 * (lane >> 1) + 2 * wave + (lane & 1)];
+        const int32_t a = node_of[(int64_t)s * SLICE + (tile ? RPW * wave + lane : 8 * (lane >> 1) + 2 * wave + (lane & 1))];
         if (a >= 0) {
             m_valid = true;
             m_L = rowlen[a];
@@ -1131,9 +1142,13 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
             cnewB = load_codes(b3, c03);
     R4_LOAD_RECORDS(RA, VA, JA, code0, b0, c00)
     R4_LOAD_RECORDS(RB, VB, JB, code1, b1, c01)
-    for (int idx = gl; idx < accw; idx += G) acc[idx] = 0.0;     // every row leaves the slots it used zeroed
+    if (tile) {
+        for (int idx = lane; idx < RG * accw_t; idx += 64) tbase[idx] = 0.0;
+    } else {
+        for (int idx = gl; idx < accw; idx += G) acc[idx] = 0.0; // every row leaves the slots it used zeroed
+    }
 
-    auto compute = [&](int32_t nE, int32_t j, int32_t la) {
+    auto compute = [&](int32_t nE, int32_t j, int32_t la, double* __restrict__ acc) {
         if (gl < nE * NPE) {
             double blk[DD];
 #pragma unroll
@@ -1161,9 +1176,38 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
         }
     };
     auto pair_end = [&](int b) {                                // the pair is complete: constants, write-out, zeros
+        double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
+        if (GP > 0 && tile) {
+            constexpr int GPD = GP ? GP : 1;
+            if ((b % GPD) != GPD - 1 && b != npairs - 1) return; // the tile is not complete yet
+            const int g0 = (b / GPD) * GPD;                      // its first pair
+            int32_t Lg = 0;
+#pragma unroll
+            for (int i = 0; i < RG; ++i) Lg = max(Lg, __builtin_amdgcn_readlane(m_L, 2 * g0 + i));    // rows >= nrows: 0
+            const int rt = lane % RG, r = RPW * wave + 2 * g0 + rt;
+            double* trow = tbase + rt * accw_t;
+            wave_lds_sync();                                     // the atomics of the last step have landed
+            for (int32_t jb = lane / RG; jb < Lg; jb += 64 / RG) {      // shorter rows of the tile: zero blocks, as stored
+                double S[DD], Kb[DD];
+#pragma unroll
+                for (int k = 0; k < DD; ++k) S[k] = trow[jb * DD + k];
+#pragma unroll
+                for (int k = 0; k < DD; ++k) trow[jb * DD + k] = 0.0;
+                if (CUBIC) cubic_from_outer3(S, c11, c12, c44, Kb);
+                else {
+#pragma unroll
+                    for (int k = 0; k < DD; ++k) Kb[k] = S[k];
+                }
+                double* dst = Krow + (int64_t)jb * (DD * SLICE);
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                    reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
+                dst[4 * (2 * SLICE) + r] = Kb[8];
+            }
+            return;
+        }
         const int32_t L = R4_ROWVAL(m_L, b);                    // rows >= nrows: 0
         const int r = 8 * b + 2 * wave + grp;
-        double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
         int32_t ln = gl;
         asm volatile("" : "+v"(ln));    // addresses built on the lane are computed HERE, not hoisted into VGPRs for the
                                         // whole kernel
@@ -1219,7 +1263,7 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
         CN_ = load_codes(b4, c04);                                                                    \
         R4_LOAD_RECORDS(R_, V_, J_, code2, b2, c02)                                                   \
         wave_lds_sync();                                                                              \
-        compute(nE, j, la);                                                                           \
+        compute(nE, j, la, (GP > 0 && tile) ? tbase + ((b0 % (GP ? GP : 1)) * 2 + grp) * accw_t : acc); \
         if (b0 < npairs && c00 + 1 >= steps_of(b0) && !ROWS2_PROBE_BIT(32)) pair_end(b0);             \
         b0 = b1; c00 = c01; b1 = b2; c01 = c02; b2 = b3; c02 = c03; b3 = b4; c03 = c04;               \
         advance(b4, c04);                                                                             \
@@ -1637,22 +1681,30 @@ int launch_assemble(Ctx* c) {
         const int R4_LMAX = c->max_row_blocks;
 #endif
         const int volw = (EPG * c->nGP + 1) & ~1, accw = (R4_LMAX * 9 + 1) & ~1;
-        const size_t lds = (size_t)4 * 2 * (EPG * RD + volw + accw + 2) * sizeof(double);
+        // experiment (round 5): FEMCY_TUNE_ROWS4_TILE = 1000 GP + LCUT -- whole-line write-out from a wave's own LDS tile,
+        // see the kernel; 0 (default) = off
+        const int r4_gp = c->tune_rows4_tile / 1000, r4_lcut = c->tune_rows4_tile % 1000;
+        const int wpair = 2 * (EPG * RD + volw + accw + 2);
+        const int wtile = r4_gp ? 2 * (EPG * RD + volw + 2) + 2 * r4_gp * ((r4_lcut * 9) | 1) + 1 : 0;
+        const int wstride = (std::max(wpair, wtile) + 1) & ~1;
+        const size_t lds = (size_t)4 * wstride * sizeof(double);
         FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS4 assembly needs %zu B of LDS per workgroup (longest row: %d "
                       "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
         const int r4_grid = c->nslices;
-#define FEMCY_ROWS4(CUB_)                                                                                              \
+#define FEMCY_ROWS4(CUB_, GP_)                                                                                         \
     do {                                                                                                               \
         if (lds > 48 * 1024)                                                                                           \
-            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_>),               \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_, GP_>),          \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_>), dim3(r4_grid), dim3(bs), lds, c->stream, c->nslices,       \
-                           R4_LMAX, (const int32_t*)c->d_asm_order, c->d_ne_ptr, c->d_ne_idx, c->d_slotj, c->d_rowlen,  \
-                           c->d_node_of,                                                                               \
+        hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_, GP_>), dim3(r4_grid), dim3(bs), lds, c->stream, c->nslices,  \
+                           R4_LMAX, r4_lcut, wstride, (const int32_t*)c->d_asm_order, c->d_ne_ptr, c->d_ne_idx,        \
+                           c->d_slotj, c->d_rowlen, c->d_node_of,                                                      \
                            c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
                            c->d_Kvals);                                                                                \
     } while (0)
-        if (c->C_is_cubic) FEMCY_ROWS4(true); else FEMCY_ROWS4(false);
+        if (r4_gp == 2) { if (c->C_is_cubic) FEMCY_ROWS4(true, 2); else FEMCY_ROWS4(false, 2); }
+        else if (r4_gp == 4) { if (c->C_is_cubic) FEMCY_ROWS4(true, 4); else FEMCY_ROWS4(false, 4); }
+        else { if (c->C_is_cubic) FEMCY_ROWS4(true, 0); else FEMCY_ROWS4(false, 0); }
 #undef FEMCY_ROWS4
     } else if (mode == FEMCY_ASM_ROWS2 || mode == FEMCY_ASM_ROWS3) {
     } else if (mode == FEMCY_ASM_ROWS) {

@@ -198,6 +198,10 @@ enum femcy_option {
                                         matrix cores (v_mfma_f64_16x16x4_f64), one tile pair per workgroup, 2 = matrix
                                         cores, 2 x 2 tile pairs per workgroup, 3 = 1 on two streams: the tiles the next panel
                                         needs first, the rest beside that panel (tests, comparison records)          */
+    FEMCY_TUNE_ROWS4_TILE = 116,     /* FEMCY_ASM_ROWS4 (C3D10), experiment of round 5: 1000 GP + LCUT = in slices no wider than
+                                        LCUT blocks a wave owns 16 consecutive rows and writes 2 GP adjacent rows (GP 2 or 4)
+                                        at a time from a tile of its own LDS (64 / 128 contiguous bytes per slot instead
+                                        of 32); 0 = off (default: 288 - 295 us against 295, profiles/r05_pmc_rows4_tile.txt) */
     FEMCY_TUNE_PERSIST_MAX_MB = 114, /* persistent PCG: largest STREAMED part of the matrix (MiB) it takes; 0 = no limit
                                         (default since round 5: 61 against 78 us per iteration on the 124 k C3D10 plate
                                         whose 287 MB stream comes from HBM); rounds 2-4 used 240 (tests, comparison

@@ -91,6 +91,51 @@ def test_assemble_K(gpu_ctx_factory, name, mode):
     assert info.nnzb == topo.adj_idx.size and info.max_row_blocks == np.diff(topo.adj_ptr).max()
 
 
+@pytest.mark.parametrize("name", DECKS)
+def test_assemble_K_rows4_tile_writeout(gpu_ctx_factory, name):
+    """FEMCY_TUNE_ROWS4_TILE (round-5 experiment, off by default): in slices no wider than LCUT a wave owns 16 consecutive
+    rows and writes 4 or 8 adjacent rows at a time from a tile of its LDS.  Every row still sums its elements in the same
+    order, so K must be the SAME BITS as the shipped kernel's -- with every slice in the tile path (LCUT 200 where the
+    LDS holds it), with none, and with the cut in the middle of the deck's row lengths; cubic and general C."""
+    from types import SimpleNamespace
+    from femcy_amd import backend as be
+    inp, et, el, mat = load(name)
+    if et != "C3D10":
+        pytest.skip("the two-rows-per-wave assembly is instantiated for C3D10")
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((6, 6))
+    general = SimpleNamespace(kind=mat.kind, C=mat.C + 0.05 * np.abs(mat.C).max() * (A + A.T), params=mat.params)
+    for plugin in (mat, general):
+        ctx = gpu_ctx_factory()
+        ctx.set_mesh(inp.nodes, el)
+        ctx.set_element(inp.ELE)
+        ctx.set_material(plugin)
+        ctx.build_pattern()
+        ctx.set_option(be.OPT_ASSEMBLY, be.ASM_ROWS4)
+        u = smooth_disp(inp.nodes, 0.02)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.assemble_K(be.VEC_DOF)
+        K0 = ctx.get_K_bsr()
+        Lmax = ctx.pattern_info().max_row_blocks
+        cuts = sorted({1, Lmax // 3, Lmax // 2, Lmax, 19, 28})
+        took = 0
+        for gp in (2, 4):
+            for lcut in cuts:
+                try:
+                    ctx.set_option(be.TUNE_ROWS4_TILE, 1000 * gp + lcut)
+                    ctx.assemble_K(be.VEC_DOF)
+                except be.FemcyError as e:                        # the tile of the longest rows does not fit the LDS
+                    assert "LDS" in str(e) and lcut >= 28
+                    continue
+                K1 = ctx.get_K_bsr()
+                assert np.array_equal(K1.indices, K0.indices) and np.array_equal(K1.data, K0.data), (gp, lcut)
+                took += 1
+        assert took >= 8
+        ctx.set_option(be.TUNE_ROWS4_TILE, 0)
+        with pytest.raises(be.FemcyError):
+            ctx.set_option(be.TUNE_ROWS4_TILE, 3028)
+
+
 @pytest.mark.parametrize("name", ["twist_plate_C3D4.inp", "twist_C3D10_coarse.inp"])
 def test_assemble_K_general_C(gpu_ctx_factory, name):
     """a material plugin whose C does NOT have the cubic pattern (anisotropic, fully populated, symmetric): every

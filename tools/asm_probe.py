@@ -26,6 +26,9 @@ ctx.set_element(Element_quadratic_tetrahedral() if quad else Element_linear_tetr
 ctx.set_material(LinearIsotropic(*m["elastic"]))
 ctx.build_pattern()
 ctx.set_option(be.OPT_ASSEMBLY, mode)
+if os.environ.get("FEMCY_ROWS4_TILE"):                          # "GP,LCUT": FEMCY_TUNE_ROWS4_TILE = 1000 GP + LCUT
+    gp, lcut = (int(v) for v in os.environ["FEMCY_ROWS4_TILE"].split(","))
+    ctx.set_option(be.TUNE_ROWS4_TILE, 1000 * gp + lcut)
 ctx.upload(be.VEC_DOF, np.zeros(ctx.n))
 for _ in range(3):
     ctx.assemble_K(be.VEC_DOF)
