@@ -11,7 +11,10 @@ restatement is pinned instead by the reference's own published known answers -- 
 FEMcy row: sigma_yy at D = 93.56 (CPS3), 93.32 node / 84.40 Gauss point (CPS6), all three
 reproduced to the printed digit through the reference's own CG at eps = 1e-3 (round 5:
 tests/test_oracle_c.py::test_as_written_cg_reproduces_all_three_published_numbers,
-tests/test_oracle_pins.py::test_readme_*) -- and by analytic properties (tests/test_oracle_*.py).
+tests/test_oracle_pins.py::test_readme_*); README.md:95 Fig. 2 (d), FEMcy's own large-deformation
+load-deflection curve of the cantilever, marker centres measured in the picture (8 points, worst
+0.15 of 29.1: test_readme_load_deflection_curve_pins_the_large_deformation_path) -- and by analytic
+properties (tests/test_oracle_*.py).
 
 All `file:line` citations are relative to /root/reference.
 

@@ -106,6 +106,58 @@ def test_deck_displacements(name, tol):
     assert abs(system.stats["linear_solves"] - solves) <= (0 if failed == 0 else 2 * failed)
 
 
+def test_readme_load_deflection_curve_through_the_driver():
+    """README.md:95, Fig. 2 (d) -- the reference's own large-deformation load-deflection curve of the cantilever (marker
+    centres measured in the picture: tests/golden/make_golden_curve.py, tests/test_oracle_pins.py) -- through the
+    product: reader, Newton / increment driver, device assembly, force, Dirichlet, factorisation.  Ten increments of
+    0.1, u_y of the node at the middle of the free end after each: the oracle's values to 1e-6, the picture's to its
+    reading accuracy (0.2 = 1.5 pixels), the same Newton iteration counts and number of linear solves."""
+    import json
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    with open(os.path.join(GOLDEN, "readme_load_deflection.json")) as f:
+        g = json.load(f)
+    tip = g["oracle"]["tip_node"]
+    # small deformation: the linear answer from the undeformed state
+    inp = InpInfo(deck("beamDeflec_quadPSE_smallD_load800_freeEnd.inp"))
+    inp.time_incs = dict(inp.time_incs, ini_inc=1.0, max_inc=1.0)
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    system.solve(inp)
+    small = system.dof.to_numpy()[2 * tip + 1]
+    system.ctx.close()
+    assert abs(small - g["oracle"]["small_deformation"][10]) < 1e-6 * 64.0
+    for k, v in enumerate(g["small_deformation"]):
+        if v is not None and g["small_deformation_visible_fraction"][k] > 0.9:
+            assert abs(small * k / 10.0 - v) < 0.2
+    # large deformation
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    inp.time_incs = dict(inp.time_incs, ini_inc=0.1, max_inc=0.1)
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    curve, loops = [0.0], [0]
+    advance = system.advance_inc
+
+    def recording(*a, **kw):
+        ok, nl = advance(*a, **kw)
+        if ok and system.time1 > 0.1 * len(curve) - 0.05:
+            curve.append(float(system.dof.to_numpy()[2 * tip + 1]))
+            loops.append(int(nl))
+        return ok, nl
+    system.advance_inc = recording
+    system.solve(inp)
+    stats = dict(system.stats)
+    system.ctx.close()
+    print("load-deflection curve:", [round(c, 3) for c in curve], "picture:", g["large_deformation"], "newton loops", loops)
+    assert len(curve) == 11 and all(i["converged"] for i in system.increments)
+    assert np.abs(np.array(curve) - np.array(g["oracle"]["large_deformation"])).max() < 1e-6 * 30.0
+    assert loops == g["oracle"]["newton_loops"] and stats["linear_solves"] == g["oracle"]["linear_solves"]
+    seen = [(k, v) for k, v in enumerate(g["large_deformation"]) if v is not None]
+    assert len(seen) == 8 and max(abs(curve[k] - v) for k, v in seen) < 0.2
+    assert abs(curve[10] - 29.108) < 0.05 and abs(curve[10] - small) > 35.0       # (the linear answer: 64.3)
+
+
 def test_twist_prescribed_rotation():
     system, u = run("twist_plate_C3D4")
     assert abs(np.abs(u).max() - 80.0) < 1e-9               # 180 degrees about (40, 5): max |u| = plate width

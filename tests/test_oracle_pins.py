@@ -118,6 +118,60 @@ def test_cook_membrane_silhouette_of_the_reference_png():
     assert abs(np.ptp(inp.nodes[:, 1]) / np.ptp(inp.nodes[:, 0]) - 1.25) < 1e-12
 
 
+def test_readme_load_deflection_curve_pins_the_large_deformation_path():
+    """a reference-PRODUCED large-deformation result: README.md:95, Fig. 2 (d) plots FEMcy's vertical deflection of the
+    cantilever's free end against the load for `tests/beam_deflection/load800_freeEnd_{smallDef,largeDef}` -- eleven
+    points per curve at 0, 80 ... 800 MPa.  tests/golden/make_golden_curve.py measured the marker centres in the
+    picture (7.85 pixels per unit of deflection; discs of the orange series partly covered by the Abaqus series, one
+    blue disc under the legend): readings good to about 0.15 (one pixel and the markers' own placement).
+      * small deformation: the linear solution from the undeformed state, 64.35 at 800 MPa (P L^3 / 3 E I = 64.0 plus
+        shear), every visible point within 0.2;
+      * LARGE deformation (geometric nonlinear: deformation gradient, sigma(F), nodal force, modified Newton with the
+        reference's 1 % tolerance, boost / damp relaxation -- the whole large-deformation path): u_y of the node at the
+        middle of the free end after ten increments of 0.1 -- 16.51, 20.02, 22.65, 24.64, 26.17, 27.37, 28.33, 29.13
+        against the picture's 16.66, 20.06, 22.58, 24.68, 26.21, 27.42, 28.28, 29.11.  (The corners of the free end move
+        30.57 / 27.69: the plotted node is the middle one; Abaqus' own curve in the same picture ends at 30.0.)"""
+    import json
+    with open(os.path.join(GOLDEN, "readme_load_deflection.json")) as f:
+        g = json.load(f)
+    inp = InpInfo(deck("beamDeflec_quadPSE_smallD_load800_freeEnd.inp"))
+    tip = int(np.argmin(np.linalg.norm(inp.nodes - np.array([40.0, 2.0]), axis=1)))
+    assert tip == g["oracle"]["tip_node"] and np.allclose(inp.nodes[tip], [40.0, 2.0])
+    s = oracle_system_from_inp(inp)
+    s.solve(dict(inp.time_incs, ini_inc=1.0, max_inc=1.0), inp.dirichlet_bc_info, inp.neumann_bc_info)
+    small = s.dof[2 * tip + 1]
+    assert abs(small - 64.348448) < 1e-5
+    seen = [(k, v) for k, v in enumerate(g["small_deformation"]) if v is not None and g["small_deformation_visible_fraction"][k] > 0.9]
+    assert len(seen) >= 7 and all(abs(small * k / 10.0 - v) < 0.2 for k, v in seen)
+
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    s = oracle_system_from_inp(inp)
+    curve = [0.0]
+    advance = s.advance_inc
+
+    def recording(bcs):
+        ok, loops = advance(bcs)
+        if ok and s.time1 > 0.1 * len(curve) - 0.05:
+            curve.append(float(s.dof[2 * tip + 1]))
+        return ok, loops
+    s.advance_inc = recording
+    s.solve(dict(inp.time_incs, ini_inc=0.1, max_inc=0.1), inp.dirichlet_bc_info, inp.neumann_bc_info)
+    assert len(curve) == 11 and np.allclose(curve, g["oracle"]["large_deformation"], rtol=1e-9, atol=1e-9)
+    seen = [(k, v) for k, v in enumerate(g["large_deformation"]) if v is not None]
+    assert [k for k, _ in seen] == [3, 4, 5, 6, 7, 8, 9, 10]
+    worst = max(abs(curve[k] - v) for k, v in seen)
+    assert worst < 0.2, worst                                       # 0.147 at 240 MPa, 0.02 at 800
+    assert abs(curve[10] - 29.108) < 0.05
+    # the curve bends: the linear answer at 800 MPa would be 64.3, and the corners of the free end are 1.4 away
+    u = s.dof.reshape(-1, 2)
+    lo = int(np.argmin(np.linalg.norm(inp.nodes - np.array([40.0, 0.0]), axis=1)))
+    hi = int(np.argmin(np.linalg.norm(inp.nodes - np.array([40.0, 4.0]), axis=1)))
+    assert abs(u[lo, 1] - 30.57) < 0.01 and abs(u[hi, 1] - 27.69) < 0.01
+    # Abaqus' curve in the same picture (its own increments): within 3 % of FEMcy's at the end, the same below 240 MPa
+    ab = np.array(g["large_deformation_abaqus"])
+    assert abs(ab[-1, 1] - 30.0) < 0.05 and abs(np.interp(160.0, ab[:, 0], ab[:, 1]) - curve[2]) < 0.15
+
+
 def test_nafems_le1_target():
     """the elliptic membrane is NAFEMS LE1: sigma_yy at D = 92.7 MPa (README.md:46, CoFEA benchmark 004) -- a known
     answer that does not come from FEMcy.  On the reference's densest decks the oracle gives 92.718 (CPS6, 0.02 % off)
