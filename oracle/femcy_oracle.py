@@ -13,7 +13,9 @@ reproduced to the printed digit through the reference's own CG at eps = 1e-3 (ro
 tests/test_oracle_c.py::test_as_written_cg_reproduces_all_three_published_numbers,
 tests/test_oracle_pins.py::test_readme_*); README.md:95 Fig. 2 (d), FEMcy's own large-deformation
 load-deflection curve of the cantilever, marker centres measured in the picture (8 points, worst
-0.15 of 29.1: test_readme_load_deflection_curve_pins_the_large_deformation_path) -- and by analytic
+0.15 of 29.1: test_readme_load_deflection_curve_pins_the_large_deformation_path) and its GIF of the
+same beam bending (21 frames, bounding boxes within a pixel: test_reference_gif_of_the_bending_beam_*)
+-- and by analytic
 properties (tests/test_oracle_*.py).
 
 All `file:line` citations are relative to /root/reference.

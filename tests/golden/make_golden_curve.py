@@ -14,6 +14,12 @@ Beside the readings the file gets the ORACLE's curve of the same decks (tests/go
 beamDeflec_quadPSE_{smallD_load800_freeEnd,largeD_load800}.inp = the reference's tests/beam_deflection/load800_freeEnd_*),
 ten increments of 0.1, u_y of the node at the middle of the free end (40, 2): what the device driver is held to.
 
+A second reference-produced record of the same cantilever: tests/beam_deflection/load800_freeEnd_largeDef/
+beamDeflec_quadPSE_largeD_load800_stable.gif -- 21 frames = the window after every converged increment of a run in twenty
+increments of 0.05 (stiffnessMtrx.py:668-711 shows / saves one picture at the start and one per increment; body.py:100-162
+keeps ONE camera, looking straight at the plane of a 2-D body, so all frames share one scale).  Frame 0 is the undeformed
+40 x 4 beam = 316 x 32 pixels: 7.9 pixels per unit.  Recorded: the bounding box of the non-black pixels of every frame.
+
 usage: python tests/golden/make_golden_curve.py"""
 import json
 import os
@@ -27,6 +33,44 @@ SRC = "/root/reference/README.assets/load-deflection-curve.png"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "readme_load_deflection.json")
 COLOURS = {"small_deformation": (31, 119, 180), "large_deformation": (255, 127, 14)}
 ABAQUS = (44, 160, 44)          # the third series (drawn last, never covered; its loads are not multiples of 80)
+
+
+GIF = "/root/reference/tests/beam_deflection/load800_freeEnd_largeDef/beamDeflec_quadPSE_largeD_load800_stable.gif"
+
+
+def gif_boxes():
+    im = Image.open(GIF)
+    boxes = []
+    for i in range(im.n_frames):
+        im.seek(i)
+        a = np.asarray(im.convert("RGB")).astype(int)
+        ys, xs = np.where(a.sum(axis=2) > 40)                       # black background
+        boxes.append([int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)])
+    return boxes
+
+
+def oracle_boxes():
+    """the deformed beam's bounding box (all nodes) after every increment of 0.05."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    from helpers import deck, oracle_system_from_inp
+    from femcy_amd.reader import InpInfo
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    s = oracle_system_from_inp(inp)
+    boxes, newton = [[40.0, 4.0]], [0]
+    advance = s.advance_inc
+
+    def recording(bcs):
+        ok, loops = advance(bcs)
+        if ok:
+            X = inp.nodes + s.dof.reshape(-1, 2)
+            boxes.append([float(np.ptp(X[:, 0])), float(np.ptp(X[:, 1]))])
+            newton.append(int(loops))
+        return ok, loops
+    s.advance_inc = recording
+    s.solve(dict(inp.time_incs, ini_inc=0.05, max_inc=0.05), inp.dirichlet_bc_info, inp.neumann_bc_info)
+    assert len(boxes) == 21 and all(i["converged"] for i in s.increments)
+    return boxes, newton, s.n_solves
 
 
 def oracle_curves():
@@ -153,11 +197,21 @@ def main():
     tip, small, large, newton, solves = oracle_curves()
     out["oracle"] = {"tip_node": tip, "small_deformation": small, "large_deformation": large,
                      "newton_loops": newton, "linear_solves": solves}
+    boxes = gif_boxes()
+    assert len(boxes) == 21 and boxes[0] == [316, 32]
+    ob, on, osolves = oracle_boxes()
+    out["stable_gif"] = {"source": "tests/beam_deflection/load800_freeEnd_largeDef/beamDeflec_quadPSE_largeD_load800_stable.gif, "
+                                   "21 frames of 512 x 512", "load_MPa": [40.0 * k for k in range(21)],
+                         "pixels_per_unit": boxes[0][0] / 40.0, "box_pixels": boxes,
+                         "oracle_box": ob, "oracle_newton_loops": on, "oracle_linear_solves": osolves}
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
     for series in list(COLOURS) + ["large_deformation_abaqus"]:
         print(series, out[series], out.get(series + "_visible_fraction", ""))
     print("oracle", out["oracle"])
+    sc = out["stable_gif"]["pixels_per_unit"]
+    print("gif frames: worst |oracle - picture| of the box:",
+          max(max(abs(o[0] - b[0] / sc), abs(o[1] - b[1] / sc)) for o, b in zip(ob, boxes)))
 
 
 if __name__ == "__main__":

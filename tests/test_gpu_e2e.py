@@ -158,6 +158,39 @@ def test_readme_load_deflection_curve_through_the_driver():
     assert abs(curve[10] - 29.108) < 0.05 and abs(curve[10] - small) > 35.0       # (the linear answer: 64.3)
 
 
+def test_reference_gif_of_the_bending_beam_through_the_driver():
+    """the reference's beamDeflec_quadPSE_largeD_load800_stable.gif (21 frames: twenty increments of 0.05, one scale;
+    tests/test_oracle_pins.py has the reading) through the product: the deformed beam's bounding box after every
+    increment = the oracle's to 1e-6 and the picture's to a pixel, same Newton counts."""
+    import json
+    from femcy_amd.body import Body
+    from femcy_amd.reader import InpInfo
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    with open(os.path.join(GOLDEN, "readme_load_deflection.json")) as f:
+        g = json.load(f)["stable_gif"]
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    inp.time_incs = dict(inp.time_incs, ini_inc=0.05, max_inc=0.05)
+    body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
+    system = System_of_equations(body, list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    boxes, loops = [[40.0, 4.0]], [0]
+    advance = system.advance_inc
+
+    def recording(*a, **kw):
+        ok, nl = advance(*a, **kw)
+        if ok:
+            X = inp.nodes + system.dof.to_numpy().reshape(-1, 2)
+            boxes.append([np.ptp(X[:, 0]), np.ptp(X[:, 1])])
+            loops.append(int(nl))
+        return ok, nl
+    system.advance_inc = recording
+    system.solve(inp)
+    solves = system.stats["linear_solves"]
+    system.ctx.close()
+    assert len(boxes) == 21 and np.abs(np.array(boxes) - np.array(g["oracle_box"])).max() < 1e-6 * 40.0
+    assert loops == g["oracle_newton_loops"] and solves == g["oracle_linear_solves"]
+    assert np.abs(np.array(boxes) - np.array(g["box_pixels"]) / g["pixels_per_unit"]).max() < 0.16
+
+
 def test_twist_prescribed_rotation():
     system, u = run("twist_plate_C3D4")
     assert abs(np.abs(u).max() - 80.0) < 1e-9               # 180 degrees about (40, 5): max |u| = plate width

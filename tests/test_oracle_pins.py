@@ -172,6 +172,38 @@ def test_readme_load_deflection_curve_pins_the_large_deformation_path():
     assert abs(ab[-1, 1] - 30.0) < 0.05 and abs(np.interp(160.0, ab[:, 0], ab[:, 1]) - curve[2]) < 0.15
 
 
+def test_reference_gif_of_the_bending_beam_pins_twenty_large_deformation_states():
+    """a second reference-PRODUCED record of the large-deformation path: tests/beam_deflection/load800_freeEnd_largeDef/
+    beamDeflec_quadPSE_largeD_load800_stable.gif, 21 frames = the window at the start and after each of twenty
+    increments of 0.05 (stiffnessMtrx.py:668-711), one fixed camera (body.py:100-162), frame 0 = the undeformed 40 x 4
+    beam on 316 x 32 pixels.  The bounding box of every frame (tests/golden/make_golden_curve.py) against the oracle's
+    deformed beam after the same increment: width 40.0 -> 25.2 (the free end moves 14.8 towards the wall), height
+    4.0 -> 31.7 -- all 42 numbers within 0.16 (a pixel is 0.127); the linear answer would be 40 x 68."""
+    import json
+    with open(os.path.join(GOLDEN, "readme_load_deflection.json")) as f:
+        g = json.load(f)["stable_gif"]
+    inp = InpInfo(deck("beamDeflec_quadPSE_largeD_load800.inp"))
+    s = oracle_system_from_inp(inp)
+    boxes = [[40.0, 4.0]]
+    advance = s.advance_inc
+
+    def recording(bcs):
+        ok, loops = advance(bcs)
+        if ok:
+            X = inp.nodes + s.dof.reshape(-1, 2)
+            boxes.append([np.ptp(X[:, 0]), np.ptp(X[:, 1])])
+        return ok, loops
+    s.advance_inc = recording
+    s.solve(dict(inp.time_incs, ini_inc=0.05, max_inc=0.05), inp.dirichlet_bc_info, inp.neumann_bc_info)
+    assert len(boxes) == 21 and np.allclose(boxes, g["oracle_box"], rtol=1e-9, atol=1e-9)
+    sc = g["pixels_per_unit"]
+    assert sc == 7.9 and g["box_pixels"][0] == [316, 32] and g["box_pixels"][20] == [199, 250]
+    seen = np.array(g["box_pixels"]) / sc
+    worst = np.abs(np.array(boxes) - seen).max()
+    assert worst < 0.16, worst                                      # measured 0.151
+    assert abs(boxes[20][0] - 25.24) < 0.01 and abs(boxes[20][1] - 31.69) < 0.01
+
+
 def test_nafems_le1_target():
     """the elliptic membrane is NAFEMS LE1: sigma_yy at D = 92.7 MPa (README.md:46, CoFEA benchmark 004) -- a known
     answer that does not come from FEMcy.  On the reference's densest decks the oracle gives 92.718 (CPS6, 0.02 % off)
