@@ -58,7 +58,7 @@ TUNE_ROWS4_TILE = 116       # ROWS4 assembly, round-5 experiment: 1000 GP + LCUT
 TUNE_DIRECT_UPDATE = 115    # femcy_direct_solve tile update: -1 auto, 0 VALU, 1 / 2 matrix cores
 TUNE_PERSIST_MAX_MB = 114   # persistent PCG: streamed-matrix limit in MiB (0 = none, the default since round 5; 240 = rounds 2-4)
 OPT_OVERLAP = 9          # multi-rank, neighbour exchange: 1 (default) = exchange overlapped with the interior product
-ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2, ASM_ROWS3, ASM_ROWS4 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+ASM_GATHER, ASM_ATOMIC, ASM_ROWS, ASM_AUTO, ASM_GATHER_SYM, ASM_GATHER_SYM_ROWSUM, ASM_ROWS2, ASM_ROWS3, ASM_ROWS4, ASM_PAIRS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 EXPORTS = [
     "femcy_ctx_create", "femcy_ctx_destroy", "femcy_last_error", "femcy_version", "femcy_set_option", "femcy_sync",

@@ -150,6 +150,13 @@ struct Ctx {
                                       // diagonal; -2 if a > b (the mirror lane stores it); -1 padding
     int32_t* d_ne_ptr = nullptr;      // [nn+1] node -> incident elements
     int32_t* d_ne_idx = nullptr;      // [ne*npe] packed e*npe+la
+    // pair lists of FEMCY_ASM_PAIRS (pattern.cpp: ensure_pairs, built on first use): per chunk of 16 consecutive storage
+    // positions the (row, incident element) pairs in (row, ascending element) order -- code e*npe+la and row inside the chunk
+    std::vector<int32_t> h_node_of, h_ne_ptr, h_ne_idx;
+    int32_t* d_pr_ptr = nullptr;      // [4 * nslices + 1]
+    int32_t* d_pr_code = nullptr;     // [ne*npe]
+    uint8_t* d_pr_row = nullptr;      // [ne*npe]
+    int64_t pairs_serial = -1;        // pattern_serial the lists were built for
 
     // ---- Gauss-point fields
     double* d_dsdx = nullptr;
@@ -366,6 +373,7 @@ int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange
 int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
 int64_t persist_streamed_bytes(Ctx* c);
+int ensure_pairs(Ctx* c);       // pattern.cpp: d_pr_ptr / d_pr_code / d_pr_row for the current pattern
 int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps
 int ensure_pos_vectors(Ctx* c);   // d_posb / d_posx (storage-order right-hand side / solution) + d_bcolp
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions

@@ -246,6 +246,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
     dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order);
+    dev_free(&c->d_pr_ptr); dev_free(&c->d_pr_code); dev_free(&c->d_pr_row);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
     for (auto& v : c->d_vec) dev_free(&v);
@@ -295,7 +296,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
     CTX_OR_FAIL(ctx);
     switch (option) {
         case FEMCY_OPT_ASSEMBLY:
-            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_ROWS4, "bad assembly mode %lld", (long long)value);
+            FEMCY_REQUIRE(value >= FEMCY_ASM_GATHER && value <= FEMCY_ASM_PAIRS, "bad assembly mode %lld", (long long)value);
             c->opt_assembly = (int)value;
             break;
         case FEMCY_OPT_DIRECT_MAX_BYTES:

@@ -1283,6 +1283,132 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
 #undef R4_CNT
 }
 
+// row-centric assembly, fifth form (round 6; FEMCY_ASM_PAIRS): written for the 2-D quadratic families, whose rows are
+// SHORT (a CPE8 corner node has 4 incident elements and 21 blocks, a mid-side node 2 and 13) and MANY (1 M-DOF beam:
+// 494 k rows) -- the opposite of C3D10.  The generic k_assemble_rows spends a wavefront, two barriers and 28 scattered
+// 8-byte gathers per lane on each of them (profiles/r06_pmc_asm_cpe8_rows.txt); rows2 / rows4 pay ~1 000 instructions of
+// pass machinery per row.  Here:
+//   * a wavefront owns a CHUNK of 16 adjacent rows of a slice (workgroup = slice) and walks the chunk's (row, incident
+//     element) pairs, listed in storage order by the host (ensure_pairs): one scalar load for the chunk's range, one
+//     coalesced load for up to 64 pair codes, then the records -- three dependent round trips per chunk, not per row;
+//   * NPE lanes per pair, lane (q, t) = column node t of pair q: its NGP gradient loads ARE the element's record, each
+//     byte fetched once per pair, 128 contiguous bytes per Gauss point and pair (CPE8); the row node's gradients are
+//     lane (q, la)'s and det J w lane (q, g)'s: ds_bpermute, no second fetch, no staging pass;
+//   * a block is linear in the geometric sum S_ab = sum_g |J| w (grad N_a (x) grad N_b) whatever the (mesh-wide) C is:
+//     K_ab[i][k] = sum_jl C[v(i,j)][v(k,l)] S[j][l].  Lanes accumulate S (6 f64 instructions per Gauss point in 2-D)
+//     into a wave-private LDS tile [entry][row][slot] with ds_add_f64; the map T = C[v(.,.)][v(.,.)] is applied once
+//     per STORED block at the end (a kernel argument: scalar registers);
+//   * the tile is the chunk's part of the slice in K's own layout: written as 16 rows x 16 bytes = 256 contiguous
+//     bytes per (slot, entry pair), padding slots and padding rows as the zeros the tile started with.
+// Deterministic: fixed pair order, ds_add_f64 of one instruction applied in lane order (asserted per box by
+// test_fullsize_properties), no workgroup barrier at all.  Two steps of records are in flight (register sets A / B).
+template <int DD>
+struct SumMap {
+    double t[DD * DD];      // K[ik] = sum_jl t[ik * DD + jl] S[jl]
+};
+
+template <int NPE, int NGP, int DM>
+__global__ void __launch_bounds__(256) k_assemble_pairs(int32_t nslices, int32_t Lmax,
+                                                        const int32_t* __restrict__ pr_ptr,
+                                                        const int32_t* __restrict__ pr_code,
+                                                        const uint8_t* __restrict__ pr_row,
+                                                        const uint16_t* __restrict__ slotj,
+                                                        const int64_t* __restrict__ slice_off,
+                                                        const double* __restrict__ dsdx, const double* __restrict__ vol,
+                                                        const SumMap<DM * DM> T, double* __restrict__ Kvals) {
+    constexpr int DD = DM * DM, RPW = 16, PPW = 64 / NPE, RD = NGP * NPE * DM;
+    static_assert(NGP <= NPE, "det J w of Gauss point g is fetched by the lane of column node g");
+    extern __shared__ __attribute__((aligned(16))) double lds_pairs[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t s = blockIdx.x;
+    if (s >= nslices) return;
+    const int64_t off = slice_off[s];
+    const int32_t L = (int32_t)(slice_off[s + 1] - off);
+    const int Lp = L | 1;                                        // odd row stride: the 16 rows of a read start in 16 banks
+    double* __restrict__ acc = lds_pairs + (size_t)wave * (DD * RPW * (Lmax | 1));
+    for (int i = lane; i < DD * RPW * Lp; i += 64) acc[i] = 0.0;
+    const int32_t chunk = s * (SLICE / RPW) + wave;
+    const int32_t p0 = __builtin_amdgcn_readfirstlane(pr_ptr[chunk]);
+    const int32_t np = __builtin_amdgcn_readfirstlane(pr_ptr[chunk + 1]) - p0;
+    const int q = lane / NPE, t = lane - q * NPE, gbase = q * NPE;
+    const bool lane_ok = q < PPW;                                // NPE = 6: lanes 60..63 have no pair
+    const int tg = t % NGP;
+
+    double GA[NGP][DM], GB[NGP][DM];
+    double VA = 0.0, VB = 0.0;
+    int32_t JA = 0, JB = 0, CA = 0, CB = 0;
+    for (int32_t base = 0; base < np; base += 64) {              // CPE8: one trip (16 rows x <= 4 elements)
+        const int32_t nb = min(64, np - base);
+        const int32_t codes = pr_code[p0 + base + (lane < nb ? lane : 0)];
+        const int32_t rows = pr_row[p0 + base + (lane < nb ? lane : 0)];
+        const int nst = (nb + PPW - 1) / PPW;
+        // every load of a step is unconditional (a lane without a pair reads pair 0 of the batch and drops the values)
+#define PR_LOAD(G_, V_, J_, C_, st_)                                                                   \
+        {                                                                                              \
+            const int pi_ = (st_) * PPW + q;                                                           \
+            const bool ok_ = lane_ok && pi_ < nb;                                                      \
+            C_ = __shfl(codes, ok_ ? pi_ : 0, 64);                                                     \
+            const int64_t e_ = C_ / NPE;                                                               \
+            const double* __restrict__ rb_ = dsdx + e_ * RD + t * DM;                                  \
+            _Pragma("unroll") for (int g = 0; g < NGP; ++g) load_row<DM>(rb_ + g * (NPE * DM), G_[g]); \
+            V_ = vol[e_ * NGP + tg];                                                                   \
+            J_ = slotj[(int64_t)C_ * NPE + t];                                                         \
+        }
+#define PR_COMPUTE(G_, V_, J_, C_, st_)                                                                \
+        {                                                                                              \
+            const int pi_ = (st_) * PPW + q;                                                           \
+            const bool ok_ = lane_ok && pi_ < nb;                                                      \
+            const int la_ = C_ % NPE;                                                                  \
+            const int rl_ = __shfl(rows, ok_ ? pi_ : 0, 64);                                           \
+            double S_[DD];                                                                             \
+            _Pragma("unroll") for (int k = 0; k < DD; ++k) S_[k] = 0.0;                                \
+            _Pragma("unroll") for (int g = 0; g < NGP; ++g) {                                          \
+                const double v_ = __shfl(V_, gbase + g, 64);                                           \
+                _Pragma("unroll") for (int i = 0; i < DM; ++i) {                                       \
+                    const double a_ = __shfl(G_[g][i], gbase + la_, 64) * v_;                          \
+                    _Pragma("unroll") for (int k = 0; k < DM; ++k) S_[i * DM + k] += a_ * G_[g][k];    \
+                }                                                                                      \
+            }                                                                                          \
+            if (ok_) {                                                                                 \
+                double* dst_ = acc + rl_ * Lp + J_;                                                    \
+                _Pragma("unroll") for (int k = 0; k < DD; ++k) atomicAdd(dst_ + k * (RPW * Lp), S_[k]); \
+            }                                                                                          \
+        }
+        PR_LOAD(GA, VA, JA, CA, 0)
+        for (int st = 0; st < nst; st += 2) {
+            if (st + 1 < nst) PR_LOAD(GB, VB, JB, CB, st + 1)
+            PR_COMPUTE(GA, VA, JA, CA, st)
+            if (st + 2 < nst) PR_LOAD(GA, VA, JA, CA, st + 2)
+            if (st + 1 < nst) PR_COMPUTE(GB, VB, JB, CB, st + 1)
+        }
+#undef PR_LOAD
+#undef PR_COMPUTE
+    }
+    wave_lds_sync();                                             // the atomics have landed
+    // write-out: lane (rl, js) takes slots js, js + 4, ... of row rl; 16 lanes = 16 adjacent rows = 256 contiguous bytes
+    const int rl = lane & (RPW - 1), js = lane >> 4;
+    const int r = wave * RPW + rl;
+    double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
+    for (int32_t j = js; j < L; j += 64 / RPW) {
+        double S[DD], Kb[DD];
+#pragma unroll
+        for (int k = 0; k < DD; ++k) S[k] = acc[(k * RPW + rl) * Lp + j];
+#pragma unroll
+        for (int ik = 0; ik < DD; ++ik) {
+            double a = 0.0;
+#pragma unroll
+            for (int jl = 0; jl < DD; ++jl) a += T.t[ik * DD + jl] * S[jl];
+            Kb[ik] = a;
+        }
+        double* dst = Krow + (int64_t)j * (DD * SLICE);
+#pragma unroll
+        for (int pc = 0; pc < DD / 2; ++pc)
+            reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
+        if (DD & 1) dst[(DD / 2) * (2 * SLICE) + r] = Kb[DD - 1];
+    }
+}
+
+
 // ----------------------------------------------------------------------------- nodal force gather
 // assemble_nodal_force_GN_kernel (stiffnessMtrx.py:620-644) is node-parallel with a serial loop over the padded
 // nodeEles row that reads a gradient row, a stress tensor and a weight per (element, Gauss point).  Here the element
@@ -1567,6 +1693,27 @@ int launch_geom(Ctx* c, const double* d_u, unsigned what) {
     return FEMCY_OK;
 }
 
+// FEMCY_ASM_PAIRS: instantiated element families, LDS of a workgroup (four chunk tiles [dm^2][16 rows][Lmax | 1])
+static bool pairs_instantiated(const Ctx* c) {
+    return c->dm == 2 && ((c->npe == 8 && c->nGP == 4) || (c->npe == 6 && c->nGP == 3) || (c->npe == 4 && c->nGP == 4) ||
+                          (c->npe == 3 && c->nGP == 1));
+}
+static size_t pairs_lds(const Ctx* c) {
+    return (size_t)4 * c->dm * c->dm * 16 * (c->max_row_blocks | 1) * sizeof(double);
+}
+// T[(i,k)][(j,l)] = C[v(i,j)][v(k,l)], v = the Voigt index of the reference's B matrices (kblock_add)
+template <int DM>
+static SumMap<DM * DM> sum_map(const Ctx* c) {
+    constexpr int NS = DM == 3 ? 6 : 3;
+    auto v = [](int i, int j) { return i == j ? i : (DM == 2 ? 2 : i + j + 2); };   // 3-D: (0,1) 3, (0,2) 4, (1,2) 5
+    SumMap<DM * DM> m;
+    for (int i = 0; i < DM; ++i)
+        for (int k = 0; k < DM; ++k)
+            for (int j = 0; j < DM; ++j)
+                for (int l = 0; l < DM; ++l) m.t[(i * DM + k) * DM * DM + j * DM + l] = c->h_C[v(i, j) * NS + v(k, l)];
+    return m;
+}
+
 int launch_assemble(Ctx* c) {
     const int bs = 256;
     size_t th = timing_begin(c, T_ASM);
@@ -1580,6 +1727,8 @@ int launch_assemble(Ctx* c) {
             const size_t lds4 = (size_t)4 * 2 * (3 * 120 + 12 + ((c->max_row_blocks * 9 + 1) & ~1) + 2) * sizeof(double);
             if (lds4 + 512 <= (size_t)c->small_max_lds) mode = FEMCY_ASM_ROWS4;
         }
+        // round 6: the 2-D quadratic families (many short rows) -- 16 rows per wave, pair lists in storage order
+        if (c->dm == 2 && c->npe > 4 && pairs_instantiated(c) && pairs_lds(c) + 512 <= (size_t)c->small_max_lds) mode = FEMCY_ASM_PAIRS;
     }
     if (c->opt_tangent == 1) {
         FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
@@ -1707,6 +1856,29 @@ int launch_assemble(Ctx* c) {
         else { if (c->C_is_cubic) FEMCY_ROWS4(true, 0); else FEMCY_ROWS4(false, 0); }
 #undef FEMCY_ROWS4
     } else if (mode == FEMCY_ASM_ROWS2 || mode == FEMCY_ASM_ROWS3) {
+    } else if (mode == FEMCY_ASM_PAIRS) {
+        FEMCY_REQUIRE(pairs_instantiated(c), "PAIRS assembly is instantiated for the 2-D families (npe %d, nGP %d, dm %d)",
+                      c->npe, c->nGP, c->dm);
+        const size_t lds = pairs_lds(c);
+        FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "PAIRS assembly needs %zu B of LDS per workgroup (longest row: %d "
+                      "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
+        int rc = ensure_pairs(c);
+        if (rc) return rc;
+        const SumMap<4> T = sum_map<2>(c);
+#define FEMCY_PAIRS(NPE_, NGP_)                                                                                        \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_pairs<NPE_, NGP_, 2>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL((k_assemble_pairs<NPE_, NGP_, 2>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,  \
+                           c->max_row_blocks, c->d_pr_ptr, c->d_pr_code, c->d_pr_row, c->d_slotj, c->d_slice_off,      \
+                           c->d_dsdx, c->d_vol, T, c->d_Kvals);                                                        \
+    } while (0)
+        if (c->npe == 8) FEMCY_PAIRS(8, 4);
+        else if (c->npe == 6) FEMCY_PAIRS(6, 3);
+        else if (c->npe == 4) FEMCY_PAIRS(4, 4);
+        else FEMCY_PAIRS(3, 1);
+#undef FEMCY_PAIRS
     } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);
         const size_t lds = (size_t)4 * c->max_row_blocks * c->dm * c->dm * sizeof(double);

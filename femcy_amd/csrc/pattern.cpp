@@ -144,6 +144,45 @@ int ensure_footprint(Ctx* c) {
     return FEMCY_OK;
 }
 
+// Pair lists of the FEMCY_ASM_PAIRS assembly: a wavefront owns a chunk of 16 consecutive storage positions (a quarter of
+// a slice) and walks the (row, incident element) pairs of its rows, NPE lanes per pair.  The list is in storage order, so
+// the kernel's chain is pr_ptr (scalar) -> codes (one coalesced load) -> records, instead of node_of -> ne_ptr -> ne_idx
+// -> records.  Order inside a chunk: by row, then ascending element = the summation order of every stored block.
+int ensure_pairs(Ctx* c) {
+    if (c->pairs_serial == c->pattern_serial) return FEMCY_OK;
+    constexpr int RPW = 16;
+    const int64_t npos = (int64_t)c->nslices * SLICE;
+    const int64_t nchunks = npos / RPW;
+    std::vector<int32_t> ptr((size_t)nchunks + 1, 0);
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        int32_t cnt = 0;
+        for (int r = 0; r < RPW; ++r) {
+            const int32_t a = c->h_node_of[(size_t)ch * RPW + r];
+            if (a >= 0) cnt += c->h_ne_ptr[a + 1] - c->h_ne_ptr[a];
+        }
+        ptr[ch + 1] = ptr[ch] + cnt;
+    }
+    std::vector<int32_t> code((size_t)ptr[nchunks]);
+    std::vector<uint8_t> row((size_t)ptr[nchunks]);
+    parallel_for(nchunks, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t ch = lo; ch < hi; ++ch) {
+            int32_t w = ptr[ch];
+            for (int r = 0; r < RPW; ++r) {
+                const int32_t a = c->h_node_of[(size_t)ch * RPW + r];
+                if (a < 0) continue;
+                for (int32_t k = c->h_ne_ptr[a]; k < c->h_ne_ptr[a + 1]; ++k) {
+                    code[w] = c->h_ne_idx[k];
+                    row[w++] = (uint8_t)r;
+                }
+            }
+        }
+    });
+    int rc;
+    if ((rc = upload(&c->d_pr_ptr, ptr)) || (rc = upload(&c->d_pr_code, code)) || (rc = upload(&c->d_pr_row, row))) return rc;
+    c->pairs_serial = c->pattern_serial;
+    return FEMCY_OK;
+}
+
 int build_pattern(Ctx* c) {
     const int32_t nn = c->nn, ne = c->ne, npe = c->npe, dm = c->dm;
     const int32_t* el = c->h_elems.data();
@@ -440,6 +479,9 @@ int build_pattern(Ctx* c) {
     c->h_rowlen = rowlen;
     c->h_pos = pos;
     c->h_bcol = bcol;
+    c->h_node_of = node_of;
+    c->h_ne_ptr = ne_ptr;
+    c->h_ne_idx = ne_idx;
     spmv_split(c);
 
     int rc;

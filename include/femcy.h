@@ -81,8 +81,8 @@ enum femcy_assembly {
     FEMCY_ASM_GATHER = 0, /* owner-computes: one lane per stored block, deterministic            */
     FEMCY_ASM_ATOMIC = 1, /* element scatter with f64 HW atomics (comparison / race check)        */
     FEMCY_ASM_ROWS = 2,   /* one wavefront per matrix row, LDS reduction, deterministic           */
-    FEMCY_ASM_AUTO = 3,   /* default: ROWS4 for C3D10 (ROWS2 / ROWS if its LDS does not fit), ROWS for the other npe > 4,
-                             GATHER_SYM(_ROWSUM) otherwise */
+    FEMCY_ASM_AUTO = 3,   /* default: ROWS4 for C3D10 (ROWS2 / ROWS if its LDS does not fit), PAIRS for the 2-D quadratic
+                             families (ROWS if its LDS does not fit), GATHER_SYM(_ROWSUM) otherwise */
     FEMCY_ASM_GATHER_SYM = 4, /* GATHER on the diagonal + upper blocks only, mirrored stores of K_ba = K_ab^T: 1.3x on C3D4 */
     FEMCY_ASM_GATHER_SYM_ROWSUM = 5, /* the same with the diagonal block from K_aa = -sum_{b != a} K_ab (partition of
                                 unity, checked on the element tables); AUTO picks it for npe <= 4 */
@@ -91,8 +91,13 @@ enum femcy_assembly {
                              instantiated for C3D10 and C3D4 tables whose gradients sum to zero */
     FEMCY_ASM_ROWS3 = 7,  /* ROWS2 with eight adjacent rows finished together and written as whole 128-byte lines
                              (no read-for-fill of K: round 3) */
-    FEMCY_ASM_ROWS4 = 8   /* two rows per wavefront at a time (half a wave each, three incident elements per step, the
+    FEMCY_ASM_ROWS4 = 8,  /* two rows per wavefront at a time (half a wave each, three incident elements per step, the
                              diagonal block computed like the others): round 3, C3D10; AUTO picks it there */
+    FEMCY_ASM_PAIRS = 9   /* round 6: a wavefront owns 16 adjacent rows of a slice; lanes = (row, incident element) pair x
+                             column node, the element's whole record is read once per pair by coalesced 16-byte loads
+                             (the row node's gradients come from the neighbouring lane), the geometric sums are reduced
+                             in a wave-private LDS tile and the tile is written as 256-byte runs; any constant C.
+                             2-D families; AUTO picks it for CPE6 / CPS6 / CPE8 / CPS8 */
 };
 
 enum femcy_option {

@@ -59,10 +59,12 @@ def smooth_disp(nodes, scale):
 
 
 @pytest.mark.parametrize("name", DECKS)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_assemble_K(gpu_ctx_factory, name, mode):
     from femcy_amd import backend as be
     inp, et, el, mat = load(name)
+    if mode == be.ASM_PAIRS and inp.nodes.shape[1] != 2:
+        pytest.skip("the pair-list assembly (round 6) is instantiated for the 2-D families")
     if mode in (be.ASM_ROWS2, be.ASM_ROWS3) and et not in ("C3D4", "C3D10"):
         pytest.skip("the LDS-staged row assembly is instantiated for the 3-D simplex elements")
     if mode == be.ASM_ROWS4 and et != "C3D10":
@@ -156,8 +158,11 @@ def test_assemble_K_general_C(gpu_ctx_factory, name):
     u = smooth_disp(inp.nodes, 0.02)
     ctx.upload(be.VEC_DOF, u)
     Ko = orc.assemble_K(topo, u, Cg)
-    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_ROWS4, be.ASM_AUTO):
+    for mode in (be.ASM_GATHER, be.ASM_GATHER_SYM_ROWSUM, be.ASM_ROWS, be.ASM_ROWS2, be.ASM_ROWS3, be.ASM_ROWS4, be.ASM_PAIRS,
+                 be.ASM_AUTO):
         if mode == be.ASM_ROWS4 and et != "C3D10":
+            continue
+        if mode == be.ASM_PAIRS and inp.nodes.shape[1] != 2:
             continue
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(be.VEC_DOF)

@@ -235,13 +235,88 @@ def test_one_2d_element_Ke_equals_the_symbolic_matrix(gpu_ctx_factory, etype, mk
     Ke, Kr, X, C = sp2.exact_Ke(sp2.ABAQUS[etype], (mkind, sp.Rational(7, 2), sp.Rational(3, 10)))
     el = np.arange(X.shape[0], dtype=np.int32)[None, :]
     ctx = _ctx(gpu_ctx_factory, X, el, _plane_ele(etype), _plane_mat(mkind))
-    for mode in (be.ASM_GATHER, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_AUTO, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM):
+    for mode in (be.ASM_GATHER, be.ASM_ATOMIC, be.ASM_ROWS, be.ASM_AUTO, be.ASM_GATHER_SYM, be.ASM_GATHER_SYM_ROWSUM, be.ASM_PAIRS):
         ctx.set_option(be.OPT_ASSEMBLY, mode)
         ctx.assemble_K(-1)
         K = ctx.get_K_bsr().toarray()
         assert np.abs(K - Kr).max() < 1e-13 * np.abs(Kr).max(), mode
     if etype != "CPS8":
         assert np.abs(K - Ke).max() < 1e-13 * np.abs(Ke).max()
+
+
+@pytest.mark.parametrize("etype", PLANE)
+def test_pair_list_assembly_edge_cases_and_general_C(gpu_ctx_factory, etype):
+    """FEMCY_ASM_PAIRS (round 6) where its bookkeeping can go wrong: a generated mesh whose node count is not a multiple of
+    16 or 64 (a last chunk / slice with padding rows), nodes no element refers to (rows without pairs: a zero diagonal
+    block), chunks with more than 64 pairs (a fan of triangles around one node), a fully populated anisotropic C (the
+    geometric-sum form is linear in C[v(i,j)][v(k,l)], not only in isotropic constants), a deformed configuration;
+    against the oracle's scatter assembly, and bit-identical when repeated."""
+    from types import SimpleNamespace
+    from femcy_amd import backend as be
+    ed = elem_def(etype)
+    rng = np.random.default_rng(3)
+    if etype in ("CPS3", "CPS6"):
+        # a fan of triangles around node 0 (CPS3: one row with 40 incident elements, > 64 pairs in its chunk; CPS6: 16,
+        # a 49-block row whose tile still fits the LDS), then a strip
+        nfan = 40 if etype == "CPS3" else 16
+        ang = np.linspace(0.0, 2 * np.pi, nfan, endpoint=False)
+        pts = [np.zeros(2)] + [np.array([np.cos(a), np.sin(a)]) * (1.0 + 0.1 * np.sin(3 * a)) for a in ang]
+        tris = [(0, 1 + k, 1 + (k + 1) % nfan) for k in range(nfan)]
+        for k in range(23):                                      # the strip, attached to nothing
+            b = len(pts)
+            pts += [np.array([3.0 + k, 0.0]), np.array([4.0 + k, 0.1]), np.array([3.3 + k, 1.0])]
+            tris.append((b, b + 1, b + 2))
+        pts = np.array(pts)
+        corners = np.array(tris, dtype=np.int32)
+        quads = False
+    else:
+        nx, ny = 13, 5
+        gx, gy = np.meshgrid(np.arange(nx + 1.0), np.arange(ny + 1.0), indexing="ij")
+        pts = np.stack([gx.ravel() + 0.1 * np.sin(gy.ravel()), gy.ravel() + 0.07 * np.cos(gx.ravel())], axis=1)
+        idx = lambda i, j: i * (ny + 1) + j
+        corners = np.array([(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(nx) for j in range(ny)],
+                           dtype=np.int32)
+        quads = True
+    if etype in ("CPS6", "CPS8"):                                 # mid-side nodes, one per distinct edge
+        pts = [p for p in pts]
+        mids = {}
+        el = []
+        nc = corners.shape[1]
+        for c in corners:
+            row = list(c)
+            for k in range(nc):
+                key = tuple(sorted((int(c[k]), int(c[(k + 1) % nc]))))
+                if key not in mids:
+                    mids[key] = len(pts)
+                    pts.append(0.5 * (pts[key[0]] + pts[key[1]]) + 0.01 * rng.standard_normal(2))
+                row.append(mids[key])
+            el.append(row)
+        pts = np.array(pts)
+        el = np.array(el, dtype=np.int32)
+    else:
+        el = corners
+    pts = np.vstack([pts, [[50.0, 50.0], [51.0, 50.0], [50.0, 51.0]]])     # never referenced
+    assert ed.npe == el.shape[1]
+    A = rng.standard_normal((3, 3))
+    base = _plane_mat("pstrain")
+    C = np.asarray(base.C) + 0.2 * np.abs(base.C).max() * (A + A.T)
+    mat = SimpleNamespace(kind=base.kind, C=C, params=base.params)
+    ctx = _ctx(gpu_ctx_factory, pts, el, _plane_ele(etype), mat)
+    topo = orc.Topology(pts, el, ed)
+    u = 0.02 * rng.standard_normal(pts.size)
+    ctx.upload(be.VEC_DOF, u)
+    Ko = orc.assemble_K(topo, u, C)
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_PAIRS)
+    ctx.assemble_K(be.VEC_DOF)
+    K1 = ctx.get_K_bsr()
+    assert abs(K1.tocsr() - Ko).max() < 1e-12 * abs(Ko).max()
+    assert np.abs(K1.toarray()[-6:, :]).max() == 0.0 and np.abs(K1.toarray()[:, -6:]).max() == 0.0
+    ctx.assemble_K(be.VEC_DOF)
+    K2 = ctx.get_K_bsr()
+    assert np.array_equal(K1.data, K2.data) and np.array_equal(K1.indices, K2.indices)
+    ctx.set_option(be.OPT_ASSEMBLY, be.ASM_GATHER)
+    ctx.assemble_K(be.VEC_DOF)
+    assert abs(ctx.get_K_bsr().tocsr() - K1.tocsr()).max() < 1e-12 * abs(Ko).max()
 
 
 @pytest.mark.parametrize("etype", PLANE)
