@@ -55,6 +55,9 @@ inline hipError_t malloc_checked(void** p, size_t bytes) {
         }                                           \
     } while (0)
 
+// FEMCY_TUNE_PAIRS default: XCD-contiguous (1) + 8 rows per wave (2) + Morton chunk order (32) + 3 chunks per wave (128):
+// 113-115 us on the 1 M-DOF CPE8 beam against 126 with all bits clear (profiles/r06_asm_cpe8_knobs.txt)
+constexpr int FEMCY_PAIRS_DEFAULT = 163;
 constexpr int SLICE = 64;           // nodes per SELL slice = one wavefront
 constexpr int MAX_PARTIALS = 4096;  // upper bound on per-launch reduction partials
 
@@ -150,13 +153,14 @@ struct Ctx {
                                       // diagonal; -2 if a > b (the mirror lane stores it); -1 padding
     int32_t* d_ne_ptr = nullptr;      // [nn+1] node -> incident elements
     int32_t* d_ne_idx = nullptr;      // [ne*npe] packed e*npe+la
-    // pair lists of FEMCY_ASM_PAIRS (pattern.cpp: ensure_pairs, built on first use): per chunk of 16 consecutive storage
+    // pair lists of FEMCY_ASM_PAIRS (pattern.cpp: ensure_pairs, built on first use): per chunk of 16 (or 8) consecutive storage
     // positions the (row, incident element) pairs in (row, ascending element) order -- code e*npe+la and row inside the chunk
     std::vector<int32_t> h_node_of, h_ne_ptr, h_ne_idx;
-    int32_t* d_pr_ptr = nullptr;      // [4 * nslices + 1]
-    int32_t* d_pr_code = nullptr;     // [ne*npe]
-    uint8_t* d_pr_row = nullptr;      // [ne*npe]
-    int64_t pairs_serial = -1;        // pattern_serial the lists were built for
+    int32_t* d_pr_ptr = nullptr;      // PairBatch descriptors (32 B) in PROCESSING order
+    int32_t* d_pr_unit = nullptr;     // [units + 1] first batch of every wavefront's unit of chunks
+    int32_t* d_pr_code = nullptr;     // [ne*npe + 64] row inside the chunk << 27 | e*npe+la
+    int64_t pairs_serial = -1;        // pattern_serial * 64 + rows per chunk the lists were built for
+    int tune_pairs = FEMCY_PAIRS_DEFAULT;   // FEMCY_TUNE_PAIRS (kernels_assembly.hip)
 
     // ---- Gauss-point fields
     double* d_dsdx = nullptr;
@@ -373,7 +377,7 @@ int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange
 int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
 int64_t persist_streamed_bytes(Ctx* c);
-int ensure_pairs(Ctx* c);       // pattern.cpp: d_pr_ptr / d_pr_code / d_pr_row for the current pattern
+int ensure_pairs(Ctx* c, int rows_per_chunk, bool spatial_order, int chunks_per_wave);   // pattern.cpp: d_pr_unit / d_pr_ptr / d_pr_code for the current pattern
 int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps
 int ensure_pos_vectors(Ctx* c);   // d_posb / d_posx (storage-order right-hand side / solution) + d_bcolp
 int ensure_bcolp(Ctx* c);   // d_bcolp = pos[bcol]: block columns as storage positions

@@ -246,7 +246,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
     dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order);
-    dev_free(&c->d_pr_ptr); dev_free(&c->d_pr_code); dev_free(&c->d_pr_row);
+    dev_free(&c->d_pr_ptr); dev_free(&c->d_pr_unit); dev_free(&c->d_pr_code);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
     for (auto& v : c->d_vec) dev_free(&v);
@@ -374,6 +374,13 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || ((value / 1000 == 2 || value / 1000 == 4) && value % 1000 > 0),
                           "ROWS4 tile write-out: 0 (off) or 1000 GP + LCUT with GP 2 or 4 and LCUT > 0 blocks");
             c->tune_rows4_tile = (int)value;
+            break;
+        case FEMCY_TUNE_PAIRS:
+            if (value == -1) value = FEMCY_PAIRS_DEFAULT;
+            FEMCY_REQUIRE(value >= 0 && value < 1024 && ((value >> 1) & 3) <= 1 && ((value >> 3) & 3) <= 2, "PAIRS assembly knobs: -1 (default) or bit 0 "
+                          "XCD-contiguous, bits 1-2 rows per wave (0: 16, 1: 8), bits 3-4 steps in flight - 2 (0..2), bit 5 Morton order, "
+                          "bits 6-9 chunks per wave - 1");
+            c->tune_pairs = (int)value;
             break;
         case FEMCY_TUNE_PERSIST_MAX_MB:
             FEMCY_REQUIRE(value >= 0 && value <= (1 << 20), "streamed-matrix limit of the persistent PCG: 0 (none) .. 2^20 MiB");

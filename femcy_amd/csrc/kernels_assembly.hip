@@ -92,10 +92,13 @@ __global__ void __launch_bounds__(256) k_geom(int32_t ne, int32_t nGP, const dou
     constexpr int WG = NPE * DM, WT = DM * DM;
     constexpr bool STAGE = WG <= 16;
     // round 3: wider records (C3D10: 30 doubles per Gauss point, four Gauss points) go through the same staging area in
-    // chunks of 15 with an element stride -- 49 -> ~30 us of the C3D10 element pass were its 960-byte-strided stores
-    constexpr bool WIDE = !STAGE && WG % 15 == 0;
-    constexpr int CHK = 15;
-    __shared__ double stage_lds[STAGE ? 257 * WG : (WIDE ? 257 * CHK : 1)];
+    // chunks of 15 with an element stride -- 49 -> ~30 us of the C3D10 element pass were its 960-byte-strided stores.
+    // round 6: so do the records of elements with several Gauss points whatever their width (CPE8: 16 doubles per Gauss
+    // point, four Gauss points -- a lane's 128 contiguous bytes 512 bytes from its neighbour's: 64 partial lines per store
+    // instruction), in chunks of the largest divisor of the record width up to 16
+    constexpr int CHK = WG % 16 == 0 ? 16 : WG % 15 == 0 ? 15 : WG % 12 == 0 ? 12 : WG % 8 == 0 ? 8 : WG % 6 == 0 ? 6 : 1;
+    constexpr bool WIDE = CHK > 1;
+    __shared__ double stage_lds[STAGE ? 257 * (WG > CHK ? WG : CHK) : (WIDE ? 257 * CHK : 1)];
     const int32_t e0 = blockIdx.x * blockDim.x;
     const int nvalid = min(256, ne - e0);
     const bool valid = (int)threadIdx.x < nvalid;
@@ -1302,112 +1305,222 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
 //     bytes per (slot, entry pair), padding slots and padding rows as the zeros the tile started with.
 // Deterministic: fixed pair order, ds_add_f64 of one instruction applied in lane order (asserted per box by
 // test_fullsize_properties), no workgroup barrier at all.  Two steps of records are in flight (register sets A / B).
+// Where its time goes (build with -DFEMCY_PAIRS_PROBE=<bits>, results meaningless; profiles/r06_pairs_probe.txt): bit 1 no
+// global stores, 2 no LDS atomics, 4 no record loads, 8 no tile zeroing / LDS reads at the end, 16 no cross-lane reads.
+#ifdef FEMCY_PAIRS_PROBE
+#define PAIRS_PROBE_BIT(b_) ((FEMCY_PAIRS_PROBE & (b_)) != 0)
+#else
+#define PAIRS_PROBE_BIT(b_) 0
+#endif
+// the value of lane (quad base + G) in every lane of the quad: v_mov_b32 with quad_perm:[G, G, G, G], no LDS traffic
+template <int G>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), G * 0x55, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), G * 0x55, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int DD>
 struct SumMap {
     double t[DD * DD];      // K[ik] = sum_jl t[ik * DD + jl] S[jl]
 };
 
-template <int NPE, int NGP, int DM>
-__global__ void __launch_bounds__(256) k_assemble_pairs(int32_t nslices, int32_t Lmax,
-                                                        const int32_t* __restrict__ pr_ptr,
+// RPW = rows per wavefront (a chunk: 16 or 8 adjacent rows = 256 / 128 contiguous bytes per store run), DEPTH = steps of
+// records in flight per wave, XCDC = workgroup b takes the (b / 8)-th unit of XCD (b % 8)'s CONTIGUOUS share of the
+// processing order (workgroups are dispatched round-robin over the XCDs: an element's record is then fetched into ONE
+// L2 and found there by the other rows of the element, instead of into up to eight).
+//
+// A wave takes a UNIT of consecutive chunks of the processing order and runs them as ONE stream of steps.  The host
+// cuts every chunk into batches of <= 64 pairs (one register of pair codes; a CPE8 chunk is one batch) and a batch runs
+// as groups of DEPTH steps; the loop below is one group per trip, straight-line, with ONE exit at the latch and every
+// load unconditional -- the form in which the compiler counts its waits (s_waitcnt vmcnt(N), N = the loads issued
+// since) instead of draining the queue: the first form of this kernel (a loop nest over chunks, batches and steps with
+// conditional prefetches) compiled to vmcnt(0) before every compute and was as fast with 2 as with 4 steps in flight,
+// with and without prefetch across chunks (profiles/r06_asm_cpe8_knobs.txt).  While group g computes, the records of
+// group g + 1 are in flight -- in the last group of a batch the first group of the NEXT batch, whose pair codes were
+// requested a batch earlier and whose descriptor two batches earlier (scalar loads): the chain descriptor -> codes ->
+// records is paid once per wave.  The write-out leaves the tile zeroed (each LDS word is read and cleared by one lane).
+constexpr int PAIR_ROW_SHIFT = 27;  // pair word: row inside the chunk << 27 | element * npe + local node (ensure_pairs)
+struct PairBatch {
+    int32_t chunk, p0, nb, L;       // chunk id (slice * (64 / RPW) + part), first pair, pairs (<= 64), slice width in blocks
+    int64_t off;                    // slice_off of the chunk's slice
+    int32_t last, pad;              // 1 = last batch of its chunk: write the tile out
+};
+
+template <int NPE, int NGP, int DM, int RPW, int DEPTH, bool XCDC>
+__global__ void __launch_bounds__(256) k_assemble_pairs(int32_t nunits, int32_t Lmax,
+                                                        const int32_t* __restrict__ unit_ptr,
+                                                        const PairBatch* __restrict__ pr_desc,
                                                         const int32_t* __restrict__ pr_code,
-                                                        const uint8_t* __restrict__ pr_row,
                                                         const uint16_t* __restrict__ slotj,
-                                                        const int64_t* __restrict__ slice_off,
                                                         const double* __restrict__ dsdx, const double* __restrict__ vol,
                                                         const SumMap<DM * DM> T, double* __restrict__ Kvals) {
-    constexpr int DD = DM * DM, RPW = 16, PPW = 64 / NPE, RD = NGP * NPE * DM;
+    constexpr int DD = DM * DM, PPW = 64 / NPE, RD = NGP * NPE * DM, CPS = SLICE / RPW;
     static_assert(NGP <= NPE, "det J w of Gauss point g is fetched by the lane of column node g");
     extern __shared__ __attribute__((aligned(16))) double lds_pairs[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t s = blockIdx.x;
-    if (s >= nslices) return;
-    const int64_t off = slice_off[s];
-    const int32_t L = (int32_t)(slice_off[s + 1] - off);
-    const int Lp = L | 1;                                        // odd row stride: the 16 rows of a read start in 16 banks
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int32_t wg = blockIdx.x;
+    if (XCDC) {
+        const int32_t per = gridDim.x >> 3;                      // the launch rounds the grid up to a multiple of 8
+        wg = (wg & 7) * per + (wg >> 3);
+    }
+    const int32_t unit = wg * 4 + wave;
+    if (unit >= nunits) return;
+    int32_t b = __builtin_amdgcn_readfirstlane(unit_ptr[unit]);
+    const int32_t bend = __builtin_amdgcn_readfirstlane(unit_ptr[unit + 1]);     // > b: a chunk has at least one batch
     double* __restrict__ acc = lds_pairs + (size_t)wave * (DD * RPW * (Lmax | 1));
-    for (int i = lane; i < DD * RPW * Lp; i += 64) acc[i] = 0.0;
-    const int32_t chunk = s * (SLICE / RPW) + wave;
-    const int32_t p0 = __builtin_amdgcn_readfirstlane(pr_ptr[chunk]);
-    const int32_t np = __builtin_amdgcn_readfirstlane(pr_ptr[chunk + 1]) - p0;
+    if (!PAIRS_PROBE_BIT(8))
+        for (int i = lane; i < DD * RPW * (Lmax | 1); i += 64) acc[i] = 0.0;
     const int q = lane / NPE, t = lane - q * NPE, gbase = q * NPE;
     const bool lane_ok = q < PPW;                                // NPE = 6: lanes 60..63 have no pair
     const int tg = t % NGP;
 
-    double GA[NGP][DM], GB[NGP][DM];
-    double VA = 0.0, VB = 0.0;
-    int32_t JA = 0, JB = 0, CA = 0, CB = 0;
-    for (int32_t base = 0; base < np; base += 64) {              // CPE8: one trip (16 rows x <= 4 elements)
-        const int32_t nb = min(64, np - base);
-        const int32_t codes = pr_code[p0 + base + (lane < nb ? lane : 0)];
-        const int32_t rows = pr_row[p0 + base + (lane < nb ? lane : 0)];
-        const int nst = (nb + PPW - 1) / PPW;
-        // every load of a step is unconditional (a lane without a pair reads pair 0 of the batch and drops the values)
-#define PR_LOAD(G_, V_, J_, C_, st_)                                                                   \
-        {                                                                                              \
-            const int pi_ = (st_) * PPW + q;                                                           \
-            const bool ok_ = lane_ok && pi_ < nb;                                                      \
-            C_ = __shfl(codes, ok_ ? pi_ : 0, 64);                                                     \
-            const int64_t e_ = C_ / NPE;                                                               \
-            const double* __restrict__ rb_ = dsdx + e_ * RD + t * DM;                                  \
-            _Pragma("unroll") for (int g = 0; g < NGP; ++g) load_row<DM>(rb_ + g * (NPE * DM), G_[g]); \
-            V_ = vol[e_ * NGP + tg];                                                                   \
-            J_ = slotj[(int64_t)C_ * NPE + t];                                                         \
-        }
-#define PR_COMPUTE(G_, V_, J_, C_, st_)                                                                \
-        {                                                                                              \
-            const int pi_ = (st_) * PPW + q;                                                           \
-            const bool ok_ = lane_ok && pi_ < nb;                                                      \
-            const int la_ = C_ % NPE;                                                                  \
-            const int rl_ = __shfl(rows, ok_ ? pi_ : 0, 64);                                           \
-            double S_[DD];                                                                             \
-            _Pragma("unroll") for (int k = 0; k < DD; ++k) S_[k] = 0.0;                                \
-            _Pragma("unroll") for (int g = 0; g < NGP; ++g) {                                          \
-                const double v_ = __shfl(V_, gbase + g, 64);                                           \
-                _Pragma("unroll") for (int i = 0; i < DM; ++i) {                                       \
-                    const double a_ = __shfl(G_[g][i], gbase + la_, 64) * v_;                          \
-                    _Pragma("unroll") for (int k = 0; k < DM; ++k) S_[i * DM + k] += a_ * G_[g][k];    \
-                }                                                                                      \
-            }                                                                                          \
-            if (ok_) {                                                                                 \
-                double* dst_ = acc + rl_ * Lp + J_;                                                    \
-                _Pragma("unroll") for (int k = 0; k < DD; ++k) atomicAdd(dst_ + k * (RPW * Lp), S_[k]); \
-            }                                                                                          \
-        }
-        PR_LOAD(GA, VA, JA, CA, 0)
-        for (int st = 0; st < nst; st += 2) {
-            if (st + 1 < nst) PR_LOAD(GB, VB, JB, CB, st + 1)
-            PR_COMPUTE(GA, VA, JA, CA, st)
-            if (st + 2 < nst) PR_LOAD(GA, VA, JA, CA, st + 2)
-            if (st + 1 < nst) PR_COMPUTE(GB, VB, JB, CB, st + 1)
-        }
-#undef PR_LOAD
-#undef PR_COMPUTE
-    }
-    wave_lds_sync();                                             // the atomics have landed
-    // write-out: lane (rl, js) takes slots js, js + 4, ... of row rl; 16 lanes = 16 adjacent rows = 256 contiguous bytes
-    const int rl = lane & (RPW - 1), js = lane >> 4;
-    const int r = wave * RPW + rl;
-    double* __restrict__ Krow = Kvals + off * (int64_t)(DD * SLICE);
-    for (int32_t j = js; j < L; j += 64 / RPW) {
-        double S[DD], Kb[DD];
+    double G[DEPTH][NGP][DM];
+    double V[DEPTH];
+    int32_t J[DEPTH], C[DEPTH], R[DEPTH];
+    // every load is unconditional: a lane without a pair reads pair 0 of the batch and drops the values, an empty batch
+    // reads the zero padding behind the lists (element 0), the batch after the unit's last one is that batch again
+    auto load = [&](int d, int st, int32_t codes, int32_t nb) {
+        const int pi = st * PPW + q;
+        const bool ok = lane_ok && pi < nb;
+        const int32_t packed = __shfl(codes, ok ? pi : 0, 64);   // row of the chunk << 27 | element * NPE + local row node
+        C[d] = packed & ((1 << PAIR_ROW_SHIFT) - 1);
+        R[d] = packed >> PAIR_ROW_SHIFT;
+        const int64_t e = C[d] / NPE;
+        const double* __restrict__ rb = dsdx + e * RD + t * DM;
+        if (PAIRS_PROBE_BIT(4)) {
 #pragma unroll
-        for (int k = 0; k < DD; ++k) S[k] = acc[(k * RPW + rl) * Lp + j];
+            for (int g = 0; g < NGP; ++g)
 #pragma unroll
-        for (int ik = 0; ik < DD; ++ik) {
-            double a = 0.0;
-#pragma unroll
-            for (int jl = 0; jl < DD; ++jl) a += T.t[ik * DD + jl] * S[jl];
-            Kb[ik] = a;
+                for (int i = 0; i < DM; ++i) G[d][g][i] = (double)(C[d] + g + i);
+            V[d] = 1.0;
+            J[d] = (C[d] + t) % 13;
+            return;
         }
-        double* dst = Krow + (int64_t)j * (DD * SLICE);
 #pragma unroll
-        for (int pc = 0; pc < DD / 2; ++pc)
-            reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
-        if (DD & 1) dst[(DD / 2) * (2 * SLICE) + r] = Kb[DD - 1];
-    }
-}
+        for (int g = 0; g < NGP; ++g) load_row<DM>(rb + g * (NPE * DM), G[d][g]);
+        V[d] = vol[e * NGP + tg];
+        J[d] = slotj[(int64_t)C[d] * NPE + t];
+    };
+    auto compute = [&](int d, int st, int32_t nb, int Lp) {
+        const int pi = st * PPW + q;
+        const bool ok = lane_ok && pi < nb;
+        const int la = C[d] % NPE;
+        const int rl = R[d];
+        double S[DD];
+#pragma unroll
+        for (int k = 0; k < DD; ++k) S[k] = 0.0;
+#pragma unroll
+        for (int g = 0; g < NGP; ++g) {
+            double v;
+            if constexpr (NGP == 4 && NPE % 4 == 0) {
+                // lane t holds det J w of Gauss point t % 4: position g of EVERY quad -> a quad broadcast (DPP, no LDS)
+                v = g == 0 ? quad_bcast<0>(V[d]) : g == 1 ? quad_bcast<1>(V[d]) : g == 2 ? quad_bcast<2>(V[d]) : quad_bcast<3>(V[d]);
+            } else {
+                v = PAIRS_PROBE_BIT(16) ? V[d] : __shfl(V[d], gbase + g, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < DM; ++i) {
+                const double a = (PAIRS_PROBE_BIT(16) ? G[d][g][i] + la : __shfl(G[d][g][i], gbase + la, 64)) * v;
+#pragma unroll
+                for (int k = 0; k < DM; ++k) S[i * DM + k] += a * G[d][g][k];
+            }
+        }
+        if (ok) {
+            double* dst = acc + rl * Lp + J[d];
+            if (PAIRS_PROBE_BIT(2)) {
+                if (S[0] + S[1] + S[DD - 1] == 1.2345) dst[0] = S[0];
+            } else {
+#pragma unroll
+                for (int k = 0; k < DD; ++k) atomicAdd(dst + k * (RPW * Lp), S[k]);
+            }
+        }
+    };
+    auto list_load = [&](const PairBatch& B, int32_t& codes) { codes = pr_code[B.p0 + (lane < B.nb ? lane : 0)]; };
 
+    // the state advances by SELECTS, not branches: a load into a loop-carried register inside a conditional block makes
+    // the compiler copy the freshly loaded register at the latch -- a wait for everything in flight, every trip
+    auto sel = [](bool c, const PairBatch& x, const PairBatch& y) {
+        PairBatch r;
+        r.chunk = c ? x.chunk : y.chunk;
+        r.p0 = c ? x.p0 : y.p0;
+        r.nb = c ? x.nb : y.nb;
+        r.L = c ? x.L : y.L;
+        r.off = c ? x.off : y.off;
+        r.last = c ? x.last : y.last;
+        r.pad = 0;
+        return r;
+    };
+    const int32_t blast = bend - 1;
+    PairBatch B = pr_desc[b];
+    PairBatch Bn = pr_desc[min(b + 1, blast)];
+    PairBatch Bnn = pr_desc[min(b + 2, blast)];
+    PairBatch Bn3 = pr_desc[min(b + 3, blast)];
+    int32_t codes, codes_n, codes_nn;
+    list_load(B, codes);
+    list_load(Bn, codes_n);
+    list_load(Bnn, codes_nn);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(d, d, codes, B.nb);
+    int32_t g = 0;
+    do {
+        const int32_t nst = (B.nb + PPW - 1) / PPW;
+        const bool last_group = (g + 1) * DEPTH >= nst;          // also the only group of an empty batch
+        const int Lp = B.L | 1;                                  // odd row stride: the rows of a read start in different banks
+        const int32_t src_codes = last_group ? codes_n : codes;
+        const int32_t src_nb = last_group ? Bn.nb : B.nb;
+        const int32_t src_st0 = last_group ? 0 : (g + 1) * DEPTH;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            compute(d, g * DEPTH + d, B.nb, Lp);
+            load(d, src_st0 + d, src_codes, src_nb);
+        }
+        if (last_group && B.last) {
+            wave_lds_sync();                                     // the atomics have landed
+            // write-out: lane (rl, js) takes slots js, js + 64 / RPW, ... of row rl; RPW lanes = RPW adjacent rows =
+            // 16 RPW contiguous bytes; the tile is left zeroed for the next chunk
+            const int32_t s = B.chunk / CPS, r0 = (B.chunk - s * CPS) * RPW;
+            const int rl = lane & (RPW - 1), js = lane / RPW;
+            const int r = r0 + rl;
+            double* __restrict__ Krow = Kvals + B.off * (int64_t)(DD * SLICE);
+            for (int32_t j = js; j < B.L; j += 64 / RPW) {
+                double S[DD], Kb[DD];
+#pragma unroll
+                for (int k = 0; k < DD; ++k) {
+                    S[k] = PAIRS_PROBE_BIT(8) ? (double)(j + k) : acc[(k * RPW + rl) * Lp + j];
+                    if (!PAIRS_PROBE_BIT(8)) acc[(k * RPW + rl) * Lp + j] = 0.0;
+                }
+#pragma unroll
+                for (int ik = 0; ik < DD; ++ik) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int jl = 0; jl < DD; ++jl) a += T.t[ik * DD + jl] * S[jl];
+                    Kb[ik] = a;
+                }
+                double* dst = Krow + (int64_t)j * (DD * SLICE);
+                if (PAIRS_PROBE_BIT(1)) {
+                    if (Kb[0] + Kb[1] + Kb[DD - 1] == 1.2345) dst[r] = Kb[0];
+                    continue;
+                }
+#pragma unroll
+                for (int pc = 0; pc < DD / 2; ++pc)
+                    reinterpret_cast<double2*>(dst + pc * (2 * SLICE))[r] = make_double2(Kb[2 * pc], Kb[2 * pc + 1]);
+                if (DD & 1) dst[(DD / 2) * (2 * SLICE) + r] = Kb[DD - 1];
+            }
+            wave_lds_sync();                                     // the zeros are in place before the next chunk's atomics
+        }
+        const bool adv = last_group;
+        b = adv ? b + 1 : b;
+        g = adv ? 0 : g + 1;
+        B = sel(adv, Bn, B);
+        codes = adv ? codes_n : codes;
+        Bn = sel(adv, Bnn, Bn);
+        codes_n = adv ? codes_nn : codes_n;                      // requested a trip ago or earlier: no wait beyond the records'
+        Bnn = sel(adv, Bn3, Bnn);
+        list_load(Bnn, codes_nn);                                // every trip (the same list again while the batch lasts)
+        Bn3 = pr_desc[min(b + 3, blast)];
+    } while (b < bend);
+}
 
 // ----------------------------------------------------------------------------- nodal force gather
 // assemble_nodal_force_GN_kernel (stiffnessMtrx.py:620-644) is node-parallel with a serial loop over the padded
@@ -1693,13 +1806,15 @@ int launch_geom(Ctx* c, const double* d_u, unsigned what) {
     return FEMCY_OK;
 }
 
-// FEMCY_ASM_PAIRS: instantiated element families, LDS of a workgroup (four chunk tiles [dm^2][16 rows][Lmax | 1])
+// FEMCY_ASM_PAIRS: instantiated element families, LDS of a workgroup (four chunk tiles [dm^2][rows per wave][Lmax | 1])
 static bool pairs_instantiated(const Ctx* c) {
     return c->dm == 2 && ((c->npe == 8 && c->nGP == 4) || (c->npe == 6 && c->nGP == 3) || (c->npe == 4 && c->nGP == 4) ||
                           (c->npe == 3 && c->nGP == 1));
 }
+static bool pairs_fits(const Ctx* c) { return (int64_t)c->ne * c->npe < ((int64_t)1 << 27); }   // the packed pair word
+static int pairs_rpw(const Ctx* c) { return ((c->tune_pairs >> 1) & 3) == 1 ? 8 : 16; }
 static size_t pairs_lds(const Ctx* c) {
-    return (size_t)4 * c->dm * c->dm * 16 * (c->max_row_blocks | 1) * sizeof(double);
+    return (size_t)4 * c->dm * c->dm * pairs_rpw(c) * (c->max_row_blocks | 1) * sizeof(double);
 }
 // T[(i,k)][(j,l)] = C[v(i,j)][v(k,l)], v = the Voigt index of the reference's B matrices (kblock_add)
 template <int DM>
@@ -1728,7 +1843,8 @@ int launch_assemble(Ctx* c) {
             if (lds4 + 512 <= (size_t)c->small_max_lds) mode = FEMCY_ASM_ROWS4;
         }
         // round 6: the 2-D quadratic families (many short rows) -- 16 rows per wave, pair lists in storage order
-        if (c->dm == 2 && c->npe > 4 && pairs_instantiated(c) && pairs_lds(c) + 512 <= (size_t)c->small_max_lds) mode = FEMCY_ASM_PAIRS;
+        if (c->dm == 2 && c->npe > 4 && pairs_instantiated(c) && pairs_fits(c) && pairs_lds(c) + 512 <= (size_t)c->small_max_lds)
+            mode = FEMCY_ASM_PAIRS;
     }
     if (c->opt_tangent == 1) {
         FEMCY_REQUIRE(c->mat_kind != FEMCY_MAT_PSTRESS, "the consistent tangent is not available for plane stress");
@@ -1859,25 +1975,49 @@ int launch_assemble(Ctx* c) {
     } else if (mode == FEMCY_ASM_PAIRS) {
         FEMCY_REQUIRE(pairs_instantiated(c), "PAIRS assembly is instantiated for the 2-D families (npe %d, nGP %d, dm %d)",
                       c->npe, c->nGP, c->dm);
+        FEMCY_REQUIRE(pairs_fits(c), "PAIRS assembly packs (row, element, local node) into 32 bits: ne * npe must stay below 2^27");
+        // FEMCY_TUNE_PAIRS: bit 0 = XCD-contiguous ranges of the processing order, bits 1-2 = rows per wave (0: 16, 1: 8),
+        // bits 3-4 = steps of records in flight (0: 2, 1: 3, 2: 4), bit 5 = chunks in Morton order of their centroids,
+        // bits 6-9 = chunks per wave - 1
+        const int tp = c->tune_pairs;
+        const int cpw = 1 + ((tp >> 6) & 15);
+        const int rpw = pairs_rpw(c), depth = 2 + ((tp >> 3) & 3);
+        const bool xcdc = (tp & 1) != 0;
         const size_t lds = pairs_lds(c);
         FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "PAIRS assembly needs %zu B of LDS per workgroup (longest row: %d "
                       "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
-        int rc = ensure_pairs(c);
+        int rc = ensure_pairs(c, rpw, (tp & 32) != 0, cpw);
         if (rc) return rc;
         const SumMap<4> T = sum_map<2>(c);
-#define FEMCY_PAIRS(NPE_, NGP_)                                                                                        \
+        const int32_t nchunks = c->nslices * (SLICE / rpw);
+        const int32_t nunits = (nchunks + cpw - 1) / cpw;
+        const int grid = ((nunits + 3) / 4 + 7) / 8 * 8;
+#define FEMCY_PAIRS_K(NPE_, NGP_, RPW_, DEPTH_, X_)                                                                    \
     do {                                                                                                               \
         if (lds > 48 * 1024)                                                                                           \
-            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_pairs<NPE_, NGP_, 2>),             \
+            FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_pairs<NPE_, NGP_, 2, RPW_, DEPTH_, X_>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((k_assemble_pairs<NPE_, NGP_, 2>), dim3(c->nslices), dim3(bs), lds, c->stream, c->nslices,  \
-                           c->max_row_blocks, c->d_pr_ptr, c->d_pr_code, c->d_pr_row, c->d_slotj, c->d_slice_off,      \
-                           c->d_dsdx, c->d_vol, T, c->d_Kvals);                                                        \
+        hipLaunchKernelGGL((k_assemble_pairs<NPE_, NGP_, 2, RPW_, DEPTH_, X_>), dim3(grid), dim3(bs), lds, c->stream,  \
+                           nunits, c->max_row_blocks, c->d_pr_unit, (const PairBatch*)c->d_pr_ptr, c->d_pr_code,            \
+                           c->d_slotj, c->d_dsdx, c->d_vol, T, c->d_Kvals);                                      \
+    } while (0)
+#define FEMCY_PAIRS_D(NPE_, NGP_, RPW_, X_)                                                                            \
+    do {                                                                                                               \
+        if (depth == 2) FEMCY_PAIRS_K(NPE_, NGP_, RPW_, 2, X_);                                                        \
+        else if (depth == 3) FEMCY_PAIRS_K(NPE_, NGP_, RPW_, 3, X_);                                                   \
+        else FEMCY_PAIRS_K(NPE_, NGP_, RPW_, 4, X_);                                                                   \
+    } while (0)
+#define FEMCY_PAIRS(NPE_, NGP_)                                                                                        \
+    do {                                                                                                               \
+        if (rpw == 16) { if (xcdc) FEMCY_PAIRS_D(NPE_, NGP_, 16, true); else FEMCY_PAIRS_D(NPE_, NGP_, 16, false); }   \
+        else           { if (xcdc) FEMCY_PAIRS_D(NPE_, NGP_, 8, true); else FEMCY_PAIRS_D(NPE_, NGP_, 8, false); }     \
     } while (0)
         if (c->npe == 8) FEMCY_PAIRS(8, 4);
         else if (c->npe == 6) FEMCY_PAIRS(6, 3);
         else if (c->npe == 4) FEMCY_PAIRS(4, 4);
         else FEMCY_PAIRS(3, 1);
+#undef FEMCY_PAIRS_K
+#undef FEMCY_PAIRS_D
 #undef FEMCY_PAIRS
     } else if (mode == FEMCY_ASM_ROWS) {
         const int grid = std::min((c->nn + 3) / 4, 256 * 16);

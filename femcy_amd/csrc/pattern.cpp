@@ -148,11 +148,12 @@ int ensure_footprint(Ctx* c) {
 // a slice) and walks the (row, incident element) pairs of its rows, NPE lanes per pair.  The list is in storage order, so
 // the kernel's chain is pr_ptr (scalar) -> codes (one coalesced load) -> records, instead of node_of -> ne_ptr -> ne_idx
 // -> records.  Order inside a chunk: by row, then ascending element = the summation order of every stored block.
-int ensure_pairs(Ctx* c) {
-    if (c->pairs_serial == c->pattern_serial) return FEMCY_OK;
-    constexpr int RPW = 16;
+int ensure_pairs(Ctx* c, int RPW, bool spatial, int cpw) {
+    const int64_t key = ((c->pattern_serial * 64 + RPW) * 2 + (spatial ? 1 : 0)) * 64 + cpw;
+    if (c->pairs_serial == key) return FEMCY_OK;
     const int64_t npos = (int64_t)c->nslices * SLICE;
     const int64_t nchunks = npos / RPW;
+    const int dm = c->dm;
     std::vector<int32_t> ptr((size_t)nchunks + 1, 0);
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         int32_t cnt = 0;
@@ -162,8 +163,7 @@ int ensure_pairs(Ctx* c) {
         }
         ptr[ch + 1] = ptr[ch] + cnt;
     }
-    std::vector<int32_t> code((size_t)ptr[nchunks]);
-    std::vector<uint8_t> row((size_t)ptr[nchunks]);
+    std::vector<int32_t> code((size_t)ptr[nchunks] + 64, 0);    // + 64 zeros: the list of an empty chunk is read, not used
     parallel_for(nchunks, [&](int64_t lo, int64_t hi, int) {
         for (int64_t ch = lo; ch < hi; ++ch) {
             int32_t w = ptr[ch];
@@ -171,15 +171,75 @@ int ensure_pairs(Ctx* c) {
                 const int32_t a = c->h_node_of[(size_t)ch * RPW + r];
                 if (a < 0) continue;
                 for (int32_t k = c->h_ne_ptr[a]; k < c->h_ne_ptr[a + 1]; ++k) {
-                    code[w] = c->h_ne_idx[k];
-                    row[w++] = (uint8_t)r;
+                    code[w++] = c->h_ne_idx[k] | (r << 27);     // kernels_assembly.hip: PAIR_ROW_SHIFT (the launcher checks ne * npe < 2^27)
                 }
             }
         }
     });
+    // processing order of the chunks.  A record is needed by every node of its element: npe fetches, from rows that lie
+    // in different slices (different mesh lines, different length classes of the sorting windows).  In storage order the
+    // fetches of one record are megabytes of other records apart (CPE8 1280 x 128: ~11 MB; an XCD's L2 holds 4) and all but
+    // the first come from the Infinity Cache over the fabric: FETCH 3.7 x the records (profiles/r06_pmc_asm_cpe8_pairs.txt).
+    // So the chunks are taken in Morton order of their centroids -- chunks close in space run close in time, and with
+    // XCD-contiguous ranges of that order on the same L2.
+    std::vector<int32_t> order((size_t)nchunks);
+    for (int64_t ch = 0; ch < nchunks; ++ch) order[ch] = (int32_t)ch;
+    if (spatial && (int64_t)c->h_nodes.size() == (int64_t)c->nn * dm) {
+        double lo[3] = {0, 0, 0}, ext = 0.0;
+        for (int d = 0; d < dm; ++d) {
+            double mn = c->h_nodes[d], mx = mn;
+            for (int32_t a = 1; a < c->nn; ++a) {
+                mn = std::min(mn, c->h_nodes[(size_t)a * dm + d]);
+                mx = std::max(mx, c->h_nodes[(size_t)a * dm + d]);
+            }
+            lo[d] = mn;
+            ext = std::max(ext, mx - mn);
+        }
+        const int bits = dm == 3 ? 20 : 30;
+        const double scale = ext > 0.0 ? (double)(((int64_t)1 << bits) - 1) / ext : 0.0;
+        std::vector<uint64_t> mkey((size_t)nchunks, ~(uint64_t)0);     // chunks of padding rows only: last
+        parallel_for(nchunks, [&](int64_t clo, int64_t chi, int) {
+            for (int64_t ch = clo; ch < chi; ++ch) {
+                double ctr[3] = {0, 0, 0};
+                int cnt = 0;
+                for (int r = 0; r < RPW; ++r) {
+                    const int32_t a = c->h_node_of[(size_t)ch * RPW + r];
+                    if (a < 0) continue;
+                    for (int d = 0; d < dm; ++d) ctr[d] += c->h_nodes[(size_t)a * dm + d];
+                    ++cnt;
+                }
+                if (!cnt) continue;
+                uint64_t k = 0;
+                uint64_t q[3];
+                for (int d = 0; d < dm; ++d) q[d] = (uint64_t)((ctr[d] / cnt - lo[d]) * scale + 0.5);
+                for (int b = bits - 1; b >= 0; --b)
+                    for (int d = dm - 1; d >= 0; --d) k = (k << 1) | ((q[d] >> b) & 1);
+                mkey[ch] = k;
+            }
+        });
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mkey[x] < mkey[y]; });
+    }
+    // batches (<= 64 pairs of one chunk) in processing order (kernels_assembly.hip: PairBatch, 32 bytes) and the first
+    // batch of every unit of `cpw` chunks (one wavefront's work)
+    std::vector<int32_t> desc, unit_ptr;
+    desc.reserve((size_t)nchunks * 8);
+    for (int64_t k = 0; k < nchunks; ++k) {
+        if (k % cpw == 0) unit_ptr.push_back((int32_t)(desc.size() / 8));
+        const int32_t ch = order[k];
+        const int64_t s = (int64_t)ch * RPW / SLICE;
+        const int64_t off = c->h_slice_off[s];
+        const int32_t np = ptr[ch + 1] - ptr[ch];
+        const int32_t nbat = std::max(1, (np + 63) / 64);
+        for (int32_t bb = 0; bb < nbat; ++bb) {
+            int32_t d8[8] = {ch, ptr[ch] + 64 * bb, std::min(64, np - 64 * bb), c->h_slice_len[s], 0, 0, bb + 1 == nbat ? 1 : 0, 0};
+            memcpy(&d8[4], &off, 8);
+            desc.insert(desc.end(), d8, d8 + 8);
+        }
+    }
+    unit_ptr.push_back((int32_t)(desc.size() / 8));
     int rc;
-    if ((rc = upload(&c->d_pr_ptr, ptr)) || (rc = upload(&c->d_pr_code, code)) || (rc = upload(&c->d_pr_row, row))) return rc;
-    c->pairs_serial = c->pattern_serial;
+    if ((rc = upload(&c->d_pr_unit, unit_ptr)) || (rc = upload(&c->d_pr_ptr, desc)) || (rc = upload(&c->d_pr_code, code))) return rc;
+    c->pairs_serial = key;
     return FEMCY_OK;
 }
 

@@ -207,6 +207,11 @@ enum femcy_option {
                                         LCUT blocks a wave owns 16 consecutive rows and writes 2 GP adjacent rows (GP 2 or 4)
                                         at a time from a tile of its own LDS (64 / 128 contiguous bytes per slot instead
                                         of 32); 0 = off (default: 288 - 295 us against 295, profiles/r05_pmc_rows4_tile.txt) */
+    FEMCY_TUNE_PAIRS = 117,          /* FEMCY_ASM_PAIRS: -1 = default (163), else bit 0 = workgroups take XCD-contiguous ranges of
+                                        the processing order, bits 1-2 = rows per wavefront (0: 16, 1: 8), bits 3-4 = steps of
+                                        element records in flight - 2 (0..2), bit 5 = chunks processed in Morton order of their
+                                        centroids, bits 6-9 = chunks per wavefront - 1; the same bits of K whatever the value
+                                        (profiles/r06_asm_cpe8_knobs.txt) */
     FEMCY_TUNE_PERSIST_MAX_MB = 114, /* persistent PCG: largest STREAMED part of the matrix (MiB) it takes; 0 = no limit
                                         (default since round 5: 61 against 78 us per iteration on the 124 k C3D10 plate
                                         whose 287 MB stream comes from HBM); rounds 2-4 used 240 (tests, comparison

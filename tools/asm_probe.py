@@ -38,6 +38,8 @@ ctx.set_option(be.OPT_ASSEMBLY, mode)
 if os.environ.get("FEMCY_ROWS4_TILE"):                          # "GP,LCUT": FEMCY_TUNE_ROWS4_TILE = 1000 GP + LCUT
     gp, lcut = (int(v) for v in os.environ["FEMCY_ROWS4_TILE"].split(","))
     ctx.set_option(be.TUNE_ROWS4_TILE, 1000 * gp + lcut)
+if os.environ.get("FEMCY_PROBE_PAIRS"):                         # FEMCY_TUNE_PAIRS bits
+    ctx.set_option(be.TUNE_PAIRS, int(os.environ["FEMCY_PROBE_PAIRS"]))
 ctx.upload(be.VEC_DOF, np.zeros(ctx.n))
 for _ in range(3):
     ctx.assemble_K(be.VEC_DOF)
@@ -48,6 +50,6 @@ for _ in range(reps):
 tm = ctx.timing()
 info = ctx.pattern_info()
 print(f"{wl}: {ctx.ne} elements, {ctx.n} DOF, nnzb {info.nnzb}, longest row {info.max_row_blocks} blocks")
-print(f"{wl} mode {mode} lib {os.path.basename(be.LIB_PATH)}: geom {tm['geom_ms']/tm['geom_launches']*1e3:.1f} us, "
+print(f"{wl} mode {mode} knobs {os.environ.get('FEMCY_PROBE_PAIRS', '-')} lib {os.path.basename(be.LIB_PATH)}: geom {tm['geom_ms']/tm['geom_launches']*1e3:.1f} us, "
       f"assemble {tm['assemble_ms']/tm['assemble_launches']*1e3:.1f} us")
 ctx.close()
