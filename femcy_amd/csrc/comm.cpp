@@ -392,8 +392,8 @@ int comm_allgather_host(Ctx* c, const void* send, int32_t bytes, void* recv) {
     const int R_ = c->nranks;
     const int64_t nd = (bytes + 7) / 8;                  // carried as doubles (bit patterns are only copied)
     double *d_s = nullptr, *d_r = nullptr;
-    FEMCY_HIP(hipMalloc((void**)&d_s, sizeof(double) * nd));
-    if (hipMalloc((void**)&d_r, sizeof(double) * nd * R_) != hipSuccess) {
+    FEMCY_HIP(dmalloc(&d_s, sizeof(double) * nd));
+    if (dmalloc(&d_r, sizeof(double) * nd * R_) != hipSuccess) {
         (void)hipFree(d_s);
         set_error("allgather_host: hipMalloc failed");
         return FEMCY_ENOMEM;
@@ -452,7 +452,7 @@ int comm_mailbox_export(Ctx* c, void* blob256) {
                                                     hipDeviceMallocFinegrained) == hipSuccess;
         if (!c->mbox_finegrained) {
             (void)hipGetLastError();
-            FEMCY_HIP(hipMalloc((void**)&c->d_mbox, sizeof(unsigned long long) * words));
+            FEMCY_HIP(dmalloc(&c->d_mbox, sizeof(unsigned long long) * words));
         }
         c->mbox_words = words;
         FEMCY_HIP(hipMemset(c->d_mbox, 0, sizeof(unsigned long long) * words));
@@ -556,11 +556,11 @@ int comm_mailbox_import(Ctx* c, int32_t nblobs, const void* blobs) {
     }
     if (c->d_mr_tab) (void)hipFree(c->d_mr_tab);
     c->d_mr_tab = nullptr;
-    FEMCY_HIP(hipMalloc((void**)&c->d_mr_tab, tab.size() * sizeof(int32_t)));
+    FEMCY_HIP(dmalloc(&c->d_mr_tab, tab.size() * sizeof(int32_t)));
     FEMCY_HIP(hipMemcpy(c->d_mr_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (c->d_peer_tab) (void)hipFree(c->d_peer_tab);
     c->d_peer_tab = nullptr;
-    FEMCY_HIP(hipMalloc((void**)&c->d_peer_tab, sizeof(unsigned long long*) * 16));
+    FEMCY_HIP(dmalloc(&c->d_peer_tab, sizeof(unsigned long long*) * 16));
     FEMCY_HIP(hipMemcpy(c->d_peer_tab, c->h_peer_mbox.data(), sizeof(unsigned long long*) * R, hipMemcpyHostToDevice));
     c->persist_multi_local = ok;
     return FEMCY_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/femcy.h"
@@ -20,32 +21,48 @@ void set_error(const char* fmt, ...);
         }                                                                                       \
     } while (0)
 
-// FEMCY_DEBUG_POISON=1 (environment, read once): every device allocation of the library is filled with 0xFF bytes
-// (a NaN as f64, -1 as i32) before it is used.  A kernel that reads memory nobody wrote -- which a fresh process hides,
-// because fresh device memory is zero, and a long-lived one does not, because the allocator hands freed blocks back --
-// then fails deterministically: the race / uninitialised-read check of the -m gpu suite (tools/records/r05_gpu2.sh).
-inline hipError_t malloc_checked(void** p, size_t bytes) {
+// Every device allocation of the library goes through dmalloc.  FEMCY_DEBUG_POISON=1 (environment, read once) fills
+// each one with 0xFF bytes (a NaN as f64, -1 as i32) before it is used: a kernel that reads memory nobody wrote -- which a
+// fresh process hides, because fresh device memory is zero, and a long-lived one does not, because the allocator hands
+// freed blocks back -- then fails deterministically: the race / uninitialised-read check of the -m gpu suite
+// (tools/records/r05_gpu2.sh).  In that mode a fill that cannot be issued or completed is an allocation failure, not a
+// silently unpoisoned buffer.
+inline hipError_t dmalloc(void** p, size_t bytes) {
     static const bool poison = [] {
         const char* e = getenv("FEMCY_DEBUG_POISON");
         return e && e[0] && e[0] != '0';
     }();
     const hipError_t rc = hipMalloc(p, bytes);
-    if (rc == hipSuccess && poison && bytes) {
-        // the fill must have LANDED before the caller's first copy into the new buffer (on the null stream it could land
-        // after it: index arrays of -1 and a memory fault that was the checker's own), and it must not wait for other
-        // streams (a device-wide synchronisation deadlocks against the co-dependent persistent kernels of several ranks
-        // in one process until their spin limit): its own non-blocking stream, synchronised here
-        static hipStream_t fill_stream = [] {
-            hipStream_t st = nullptr;
-            (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            return st;
-        }();
-        (void)hipMemsetAsync(*p, 0xFF, bytes, fill_stream);
-        (void)hipStreamSynchronize(fill_stream);
+    if (rc != hipSuccess || !poison || !bytes) return rc;
+    // the fill must have LANDED before the caller's first copy into the new buffer (on the null stream it could land
+    // after it: index arrays of -1 and a memory fault that was the checker's own), and it must not wait for other
+    // streams (a device-wide synchronisation deadlocks against the co-dependent persistent kernels of several ranks
+    // in one process until their spin limit): a non-blocking stream of its own ON THE DEVICE OF THE ALLOCATION (several
+    // ranks of one process hold one device each), synchronised here
+    constexpr int MAXDEV = 64;
+    static hipStream_t fill_stream[MAXDEV] = {};
+    static std::mutex mu;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && (dev < 0 || dev >= MAXDEV)) e = hipErrorInvalidDevice;
+    hipStream_t st = nullptr;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!fill_stream[dev]) e = hipStreamCreateWithFlags(&fill_stream[dev], hipStreamNonBlocking);
+        st = fill_stream[dev];
     }
-    return rc;
+    if (e == hipSuccess) e = hipMemsetAsync(*p, 0xFF, bytes, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    return e;
 }
-#define hipMalloc(p, n) ::femcy::malloc_checked((void**)(p), (n))
+template <class T>
+inline hipError_t dmalloc(T** p, size_t bytes) {
+    return dmalloc(reinterpret_cast<void**>(p), bytes);
+}
 
 #define FEMCY_REQUIRE(cond, ...)                    \
     do {                                            \

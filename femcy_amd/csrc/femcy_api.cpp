@@ -27,9 +27,9 @@ static int dev_alloc(T** p, size_t count, bool zero = true) {
         *p = nullptr;
     }
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    hipError_t e = hipMalloc((void**)p, bytes);
+    hipError_t e = dmalloc(p, bytes);
     if (e != hipSuccess) {
-        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        set_error("dmalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return FEMCY_ENOMEM;
     }
     if (zero) FEMCY_HIP(hipMemset(*p, 0, bytes));
@@ -845,8 +845,8 @@ int femcy_dofset_create(femcy_ctx* ctx, const int32_t* dofs, int32_t k, int32_t*
     FEMCY_REQUIRE(c->have_mesh && id_out && k >= 0 && (k == 0 || dofs), "bad dofset arguments");
     for (int32_t i = 0; i < k; ++i) FEMCY_REQUIRE(dofs[i] >= 0 && dofs[i] < c->n, "DOF %d out of range", dofs[i]);
     Ctx::DofSet ds{nullptr, nullptr, k};
-    FEMCY_HIP(hipMalloc((void**)&ds.d_dofs, std::max<size_t>(k, 1) * sizeof(int32_t)));
-    FEMCY_HIP(hipMalloc((void**)&ds.d_vals, std::max<size_t>(k, 1) * sizeof(double)));
+    FEMCY_HIP(dmalloc(&ds.d_dofs, std::max<size_t>(k, 1) * sizeof(int32_t)));
+    FEMCY_HIP(dmalloc(&ds.d_vals, std::max<size_t>(k, 1) * sizeof(double)));
     if (k) FEMCY_HIP(hipMemcpy(ds.d_dofs, dofs, sizeof(int32_t) * k, hipMemcpyHostToDevice));
     c->dofsets.push_back(ds);
     *id_out = (int32_t)c->dofsets.size() - 1;
@@ -907,7 +907,7 @@ int femcy_dofset_dirichlet_linear(femcy_ctx* ctx, int32_t id, double value, int 
 // ------------------------------------------------------------------------------- Neumann load sets
 static int to_device(void* dptr, const void* h, size_t bytes) {
     void** d = (void**)dptr;
-    FEMCY_HIP(hipMalloc(d, std::max<size_t>(bytes, 8)));
+    FEMCY_HIP(dmalloc(d, std::max<size_t>(bytes, 8)));
     if (bytes) FEMCY_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return FEMCY_OK;
 }
@@ -965,8 +965,8 @@ int femcy_loadset_create(femcy_ctx* ctx, int32_t nft, int32_t nfn, int32_t nip, 
     if (!rc) rc = to_device(&ls.d_node, ld_node.data(), sizeof(int32_t) * ld_node.size());
     if (!rc) rc = to_device(&ls.d_ptr, ld_ptr.data(), sizeof(int32_t) * ld_ptr.size());
     if (!rc) rc = to_device(&ls.d_slot, order.data(), sizeof(int32_t) * nslot);
-    if (!rc && hipMalloc((void**)&ls.d_contrib, std::max<size_t>(nslot, 1) * c->dm * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
-    if (!rc && hipMalloc((void**)&ls.d_dir, 3 * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
+    if (!rc && dmalloc(&ls.d_contrib, std::max<size_t>(nslot, 1) * c->dm * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
+    if (!rc && dmalloc(&ls.d_dir, 3 * sizeof(double)) != hipSuccess) rc = FEMCY_ENOMEM;
     if (rc) {
         loadset_free(ls);
         if (rc == FEMCY_ENOMEM) set_error("out of device memory for a load set of %d facets", nload);
@@ -1083,8 +1083,8 @@ int femcy_extrapolate(femcy_ctx* ctx, int gp_field, int comp, const double* E, d
         }
     } tE, tout;
     const size_t nE = (size_t)c->npe * c->nGP, nout = (size_t)c->ne * c->npe;
-    FEMCY_HIP(hipMalloc((void**)&tE.p, nE * sizeof(double)));
-    FEMCY_HIP(hipMalloc((void**)&tout.p, nout * sizeof(double)));
+    FEMCY_HIP(dmalloc(&tE.p, nE * sizeof(double)));
+    FEMCY_HIP(dmalloc(&tout.p, nout * sizeof(double)));
     FEMCY_HIP(hipMemcpyAsync(tE.p, E, nE * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = launch_extrapolate(c, tE.p, field, width, comp, tout.p);
     if (!rc) FEMCY_HIP(hipMemcpyAsync(out, tout.p, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1419,7 +1419,7 @@ int femcy_comm_tune(femcy_ctx* ctx, int32_t iters, int32_t* chosen, double* us) 
     std::vector<double> all((size_t)c->nranks * 3);
     FEMCY_HIP(hipMemcpy(c->d_commbuf, pack, sizeof(pack), hipMemcpyHostToDevice));
     double* d_all = nullptr;
-    FEMCY_HIP(hipMalloc((void**)&d_all, sizeof(double) * all.size()));
+    FEMCY_HIP(dmalloc(&d_all, sizeof(double) * all.size()));
     rc = comm_allgather(c, c->d_commbuf, d_all, 3);
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = FEMCY_EHIP;
     if (!rc && hipMemcpy(all.data(), d_all, sizeof(double) * all.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = FEMCY_EHIP;

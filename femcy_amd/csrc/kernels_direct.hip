@@ -575,7 +575,7 @@ int alloc(Tp** p, size_t count) {
         (void)hipFree(*p);
         *p = nullptr;
     }
-    if (hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(Tp)) != hipSuccess) {
+    if (dmalloc(p, std::max<size_t>(count, 1) * sizeof(Tp)) != hipSuccess) {
         (void)hipGetLastError();
         *p = nullptr;
         set_error("direct solve: out of device memory (%zu bytes)", count * sizeof(Tp));

@@ -1068,8 +1068,8 @@ int ensure_pos_vectors(Ctx* c) {
         if (c->d_posx) (void)hipFree(c->d_posx);
         c->d_posb = c->d_posx = nullptr;
         c->pos_cap = 0;
-        FEMCY_HIP(hipMalloc((void**)&c->d_posb, sizeof(double) * need));
-        FEMCY_HIP(hipMalloc((void**)&c->d_posx, sizeof(double) * need));
+        FEMCY_HIP(dmalloc(&c->d_posb, sizeof(double) * need));
+        FEMCY_HIP(dmalloc(&c->d_posx, sizeof(double) * need));
         FEMCY_HIP(hipMemsetAsync(c->d_posb, 0, sizeof(double) * need, c->stream));
         FEMCY_HIP(hipMemsetAsync(c->d_posx, 0, sizeof(double) * need, c->stream));
         c->pos_cap = need;
@@ -1130,7 +1130,7 @@ int split_prepare(Ctx* c) {
         if (!is_if[s2]) list.push_back(s2);
     if (c->d_split_list) (void)hipFree(c->d_split_list);
     c->d_split_list = nullptr;
-    FEMCY_HIP(hipMalloc((void**)&c->d_split_list, std::max<size_t>(list.size(), 1) * sizeof(int32_t)));
+    FEMCY_HIP(dmalloc(&c->d_split_list, std::max<size_t>(list.size(), 1) * sizeof(int32_t)));
     FEMCY_HIP(hipMemcpy(c->d_split_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!c->comm_stream) FEMCY_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     if (!c->ev_iface) FEMCY_HIP(hipEventCreateWithFlags(&c->ev_iface, hipEventDisableTiming));
@@ -1475,7 +1475,7 @@ static int pcg_small_solve(Ctx* c, const double* d_b, double* d_x, double eps, i
         if (c->d_small) (void)hipFree(c->d_small);
         c->d_small = nullptr;
         c->small_cap = 2 * npad + 2 * G + 8;
-        FEMCY_HIP(hipMalloc((void**)&c->d_small, sizeof(double) * c->small_cap));
+        FEMCY_HIP(dmalloc(&c->d_small, sizeof(double) * c->small_cap));
     }
     SmallPcg a;
     a.slice_len = c->d_slice_len; a.slice_off = c->d_slice_off; a.bcol = c->d_bcol; a.node_of = c->d_node_of;
@@ -1635,7 +1635,7 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
             if (!coresident(c, fn, BS, 0, fused_g)) fused_g = 0;
         }
         if (fused_g && !c->d_fused) {
-            FEMCY_HIP(hipMalloc((void**)&c->d_fused, 1024 * 2 * 16));
+            FEMCY_HIP(dmalloc(&c->d_fused, 1024 * 2 * 16));
             FEMCY_HIP(hipMemsetAsync(c->d_fused, 0, 1024 * 2 * 16, c->stream));
         }
     }

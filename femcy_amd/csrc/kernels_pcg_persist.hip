@@ -1114,7 +1114,7 @@ int persist_buffers(Ctx* c, int G, int64_t npad, PersistPcg* a) {
         if (c->d_persist) (void)hipFree(c->d_persist);
         c->d_persist = nullptr;
         c->persist_cap = need;
-        FEMCY_HIP(hipMalloc((void**)&c->d_persist, sizeof(double) * need));
+        FEMCY_HIP(dmalloc(&c->d_persist, sizeof(double) * need));
     }
     a->dbuf = c->d_persist;
     a->part1 = c->d_persist + 3 * npad;
@@ -1143,7 +1143,7 @@ int ensure_bcolp(Ctx* c) {
     if (c->d_bcolp) (void)hipFree(c->d_bcolp);
     c->d_bcolp = nullptr;
     const int64_t nb = c->stored_rows * SLICE;
-    FEMCY_HIP(hipMalloc((void**)&c->d_bcolp, std::max<int64_t>(nb, 1) * sizeof(int32_t)));
+    FEMCY_HIP(dmalloc(&c->d_bcolp, std::max<int64_t>(nb, 1) * sizeof(int32_t)));
     hipLaunchKernelGGL(k_bcol_to_pos, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, nb,
                        (const int32_t*)c->d_bcol, (const int32_t*)c->d_pos, c->d_bcolp);
     FEMCY_HIP(hipGetLastError());
@@ -1199,14 +1199,18 @@ bool persist_pattern_fits(Ctx* c) {
     if (!persist_shape(c, &sh) || c->dm != 3) return false;      // (the multi-rank kernel is instantiated for 3 x 3 blocks)
     const int G = sh.G;
     if (c->opt_persist >= 2) return true;
-    // evaluated here once so that every rank applies the same verdict: the streamed part of the matrix fits the
-    // Infinity Cache.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
+    // evaluated here once so that every rank applies the same verdict.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
     // as fast) does not apply across ranks: what the one-launch path competes with there is three launches PLUS two
     // collectives per iteration (49 us against 32 at 1 M elements per rank; a strong-scaling slab of the 1 M plate on
     // 8 ranks has 375 slices)
     if (c->nslices < G / 2) return false;
+    // ACROSS RANKS the streamed part still has to fit the Infinity Cache (240 MiB, the rule of rounds 2-4): round 5 lifted
+    // the limit for a single rank on a measurement (124 k C3D10, 287 MB streamed from HBM: 61 against 78 us), but no
+    // multi-rank run has streamed a larger matrix from HBM while polling its mailboxes -- the rule stays until one has
+    // (FEMCY_TUNE_PERSIST_MAX_MB lowers it further; FEMCY_OPT_PCG_PERSIST = 2 above takes any size)
+    const int64_t limit = std::min<int64_t>(c->persist_max_bytes, (int64_t)240 << 20);
     const int64_t row_bytes = (int64_t)(c->dm * c->dm * 8 + 4) * 64;
-    return c->stored_rows * row_bytes <= c->persist_max_bytes || persist_streamed_bytes(c) <= c->persist_max_bytes;
+    return c->stored_rows * row_bytes <= limit || persist_streamed_bytes(c) <= limit;
 }
 
 // eligibility + launch; *handled = false when the system does not qualify (too small, too large, ranks not agreed)
@@ -1285,7 +1289,7 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
                 }
                 if (c->d_persist_assign) (void)hipFree(c->d_persist_assign);
                 c->d_persist_assign = nullptr;
-                FEMCY_HIP(hipMalloc((void**)&c->d_persist_assign, assign.size() * sizeof(int32_t)));
+                FEMCY_HIP(dmalloc(&c->d_persist_assign, assign.size() * sizeof(int32_t)));
                 FEMCY_HIP(hipMemcpyAsync(c->d_persist_assign, assign.data(), assign.size() * sizeof(int32_t),
                                          hipMemcpyHostToDevice, c->stream));
                 FEMCY_HIP(hipStreamSynchronize(c->stream));
@@ -1435,7 +1439,7 @@ int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_p
         if (c->d_probe) (void)hipFree(c->d_probe);
         c->d_probe = nullptr;
         c->probe_cap = bytes;
-        FEMCY_HIP(hipMalloc((void**)&c->d_probe, (size_t)bytes + 64));
+        FEMCY_HIP(dmalloc(&c->d_probe, (size_t)bytes + 64));
         FEMCY_HIP(hipMemsetAsync(c->d_probe, 0, (size_t)bytes, c->stream));
     }
     // dynamic LDS sets the residency: one workgroup per CU as the solver, or exactly per_cu of them

@@ -36,7 +36,7 @@ static int upload(T** dptr, const std::vector<T>& h) {
         *dptr = nullptr;
     }
     size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-    FEMCY_HIP(hipMalloc((void**)dptr, bytes));
+    FEMCY_HIP(dmalloc(dptr, bytes));
     if (!h.empty()) FEMCY_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return FEMCY_OK;
 }
@@ -561,7 +561,7 @@ int build_pattern(Ctx* c) {
 
     if (c->d_Kvals) (void)hipFree(c->d_Kvals);
     size_t kbytes = (size_t)stored_rows * dm * dm * SLICE * sizeof(double);
-    FEMCY_HIP(hipMalloc((void**)&c->d_Kvals, std::max<size_t>(kbytes, 8)));
+    FEMCY_HIP(dmalloc(&c->d_Kvals, std::max<size_t>(kbytes, 8)));
     FEMCY_HIP(hipMemset(c->d_Kvals, 0, kbytes));
     return FEMCY_OK;
 }

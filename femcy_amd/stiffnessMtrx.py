@@ -56,18 +56,22 @@ class System_of_equations:
         # `solve_dof` (reference :272-276) sends systems of at least 1e5 DOF to its CG (eps = 1e-3, maxit = n); the constant
         # is a parameter here so that the CG leg can be driven on any deck (tests: cg_branch_from = 0)
         self.cg_branch_from = cg_branch_from
-        if direct not in ("auto", "cholesky", "pcg"):
-            raise ValueError("direct must be 'auto' (default: whichever of the two is faster on this system), 'cholesky' "
-                             "(band factorisation on the device) or 'pcg' (tight PCG)")
+        if direct not in ("auto", "auto-timed", "cholesky", "pcg"):
+            raise ValueError("direct must be 'auto' (default: chosen by the band of the system), 'auto-timed' (chosen by "
+                             "timing both on the running system), 'cholesky' (band factorisation on the device) or 'pcg' "
+                             "(tight PCG)")
         self.direct = direct
         # direct = "auto": both stand-ins for the reference's spsolve return the solution to ~1e-12, so which one runs is
         # a question of time only.  The band factorisation costs n * bandwidth^2 flops behind a chain of dependent
         # launches (~20 us per panel of 32 unknowns + the tile updates), the tight PCG iterations * (matrix bytes /
         # memory bandwidth); on 2-D decks and 3-D ones up to ~4e4 DOF the factorisation wins by 1.5 ... 20 x, on 3-D
         # meshes towards 1e5 DOF (bands of 2 000 ... 2 900 sub-diagonals) the PCG is up to 2 x faster
-        # (profiles/r05_direct_limit.txt).  First solve: by the band (femcy_direct_plan); from then on by the measured
-        # times of both (each timed twice, alternating, if the first solve took more than 5 ms: `_auto_method`).
+        # (profiles/r05_direct_limit.txt).  "auto" decides from the band alone (femcy_direct_plan: a property of the mesh,
+        # the same answer on every run and every machine -- round 6; round 5 timed both solvers on the running system,
+        # which made the 1e-9 ... 1e-12 difference between them, and with it borderline Newton counts, depend on the
+        # load of the host).  "auto-timed" keeps that exploration for whoever wants the faster solver and accepts that.
         self._auto = {"first": None, "ms": {}, "tried": set(), "pcg_ok": True, "pick": None}
+        self.direct_log = []              # the solver that served each solve of the direct branch, in order
 
         # ---- device state: mesh, element tables, material, sparsity pattern
         self.ctx = ctx if ctx is not None else be.Context(device)
@@ -205,10 +209,11 @@ class System_of_equations:
     AUTO_TRY_OTHER_MS = 5.0      # a first solve slower than this makes the second solve time the other method
 
     def _auto_method(self) -> str:
-        """direct = "auto": 'cholesky' or 'pcg' for the next solve of the reference's direct branch.  First solve: by the
-        band; if it took more than AUTO_TRY_OTHER_MS the next three solves alternate other / first / other, so that each
-        method is timed twice (the first call of either carries one-off costs: band allocation, hipGraph capture), and the
-        faster one (minimum of its samples) serves the rest of the run."""
+        """'cholesky' or 'pcg' for the next solve of the reference's direct branch.  direct = "auto": by the band
+        (femcy_direct_plan), once, for the whole run.  direct = "auto-timed": the first solve by the band; if it took more
+        than AUTO_TRY_OTHER_MS the next three solves alternate other / first / other, so that each method is timed twice
+        (the first call of either carries one-off costs: band allocation, hipGraph capture), and the faster one (minimum
+        of its samples) serves the rest of the run.  A PCG that broke down or did not converge leaves the race either way."""
         a = self._auto
         if a["pick"] is not None:
             return a["pick"]
@@ -220,6 +225,8 @@ class System_of_equations:
             except (be.FemcyError, AttributeError):
                 wide = False
             a["first"] = "pcg" if wide else "cholesky"
+            if self.direct == "auto":                            # deterministic: the band decides, for the whole run
+                a["pick"] = a["first"]
             return a["first"]
         first = a["first"]
         other = "pcg" if first == "cholesky" else "cholesky"
@@ -238,29 +245,41 @@ class System_of_equations:
 
     def solve_by_scipy(self):
         """the reference's direct branch (`spsolve`, :219-251; the name is kept): band Cholesky on the device, or the
-        tight PCG where that is faster (direct = "auto")."""
-        if self.part is None and self.direct == "auto":
+        tight PCG where that is faster (direct = "auto" / "auto-timed")."""
+        if self.part is None and self.direct in ("auto", "auto-timed"):
             method = self._auto_method()
             a = self._auto
-            self.ctx.sync()
+            timed = self.direct == "auto-timed"
+            if timed:
+                self.ctx.sync()
             t0 = time.perf_counter()
             if method == "pcg":
                 a["tried"].add("pcg")
-                du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
-                if self.PCG.converged:
-                    a["ms"]["pcg"] = min(a["ms"].get("pcg", 1e30), (time.perf_counter() - t0) * 1e3)
+                # an exploratory solve: K may be the indefinite matrix of a diverging Newton iterate, on which CG breaks
+                # down (NaN: FEMCY_ENUMERIC) or wanders -- the factorisation (L S L^T takes negative pivots, as the
+                # reference's LU does) then serves this solve and every later one
+                try:
+                    du = self.solve_by_CG(eps=self.direct_eps, maxit=int(min(10 * self.n_system, 2 ** 31 - 1)))
+                    failed, applied = not self.PCG.converged, True
+                except be.FemcyError as e:
+                    if e.status != be.FEMCY_ENUMERIC:
+                        raise
+                    failed, applied = True, False                # the breakdown left before _take_solution: dof untouched
+                if not failed:
+                    if timed:
+                        a["ms"]["pcg"] = min(a["ms"].get("pcg", 1e30), (time.perf_counter() - t0) * 1e3)
                     a.setdefault("samples", {})["pcg"] = a.get("samples", {}).get("pcg", 0) + 1
+                    self.direct_log.append("pcg")
                     return du
-                # not converged within 10 n iterations (nu -> 0.5, an indefinite Newton iterate): this solve is redone
-                # by the factorisation, and the PCG is out of the race for this system
                 a["pcg_ok"], a["pick"] = False, "cholesky"
-                self.stats["linear_solves"] -= 1
-                if self.geometric_nonlinear:
-                    tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, 1.0, self.PCG.x)       # undo dof -= x
+                if applied:
+                    self.stats["linear_solves"] -= 1
+                    if self.geometric_nonlinear:
+                        tg.a_equals_b_plus_c_mul_d(self.dof, self.dof, 1.0, self.PCG.x)       # undo dof -= x
                 t0 = time.perf_counter()
             a["tried"].add("cholesky")
             du = self._solve_direct()
-            if self.direct_info is not None:
+            if self.direct_info is not None and timed:
                 a["ms"]["cholesky"] = min(a["ms"].get("cholesky", 1e30), (time.perf_counter() - t0) * 1e3)
             # (a rejected factorisation -- ENUMERIC, served by the tight PCG inside _solve_direct -- still counts as a sample:
             # the exploration must end)
@@ -270,7 +289,7 @@ class System_of_equations:
 
     def _solve_direct(self):
         self.direct_info = None
-        if self.part is None and self.direct in ("cholesky", "auto"):
+        if self.part is None and self.direct in ("cholesky", "auto", "auto-timed"):
             self._linear_system()
             try:
                 self.direct_info = self.ctx.direct_solve(self.PCG.b.id, self.PCG.x.id)
@@ -289,6 +308,7 @@ class System_of_equations:
             else:
                 self.PCG.iterations, self.PCG.converged = 0, True
                 self.stats["direct_solves"] += 1
+                self.direct_log.append("cholesky")
                 return self._take_solution()
         # a mesh split over ranks (or direct="pcg"): CG in floating point can need more than n iterations on an
         # ill-conditioned K (nu -> 0.5), so the cap is 10 n here instead of the reference CG's n
@@ -300,6 +320,7 @@ class System_of_equations:
             raise be.FemcyError("tight PCG in place of the direct solve: stopped at max|r| = {:.3e} > {:.1e} * {:.3e} "
                                 "after {} iterations".format(self.PCG.rmax, self.direct_eps, self.PCG.r0,
                                                              self.PCG.iterations), status=be.FEMCY_ENUMERIC)
+        self.direct_log.append("pcg")
         return du
 
     def solve_dof(self):
