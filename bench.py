@@ -69,28 +69,71 @@ ELEMS_PER_GPU = {"c3d4": 995328, "c3d10": 124416, "cpe8": 163840}
 CPE8_CELLS = (1280, 128)        # 163 840 CPE8 elements, 494 337 nodes, 988 674 DOF (~1 M DOF: the size of the 3-D headline system)
 CPE8_NAME = ("beam CPE8 1280x128 serendipity quadrilaterals, plane strain, nlgeom (BASELINE configs[1] stand-in, "
              "163 840 elements, 988 674 DOF)")
-TRAFFIC_SOURCES = ("femcy_amd/csrc/kernels_pcg.hip", "femcy_amd/csrc/kernels_pcg_persist.hip", "femcy_amd/csrc/granule.hpp",
-                   "femcy_amd/csrc/wave_reduce.hpp", "femcy_amd/csrc/ctx.hpp", "femcy_amd/csrc/pattern.cpp")
+TRAFFIC_KERNELS = ("k_pcg_persist", "k_spmv")     # kernels whose machine code the committed PMC traffic belongs to
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def kernel_source_sha():
-    """fingerprint of the sources that define the SpMV kernel and its matrix layout: profiles/spmv_traffic.json is only
-    valid for the kernel it was measured on"""
+def kernel_object_sha(lib_path=None, patterns=TRAFFIC_KERNELS):
+    """fingerprint of the MACHINE CODE of the dominant kernels (every instantiation of the persistent PCG and of the
+    product) inside libfemcy_hip.so: profiles/spmv_traffic.json is valid for the kernels it was measured on.  Round 5
+    hashed whole source files (ctx.hpp and pattern.cpp among them), and an edit for an unrelated assembly option voided the
+    record of the driver's line; the code object changes when, and only when, a kernel does.  (What the host decides --
+    the matrix layout -- is pinned separately, by the pattern sizes stored with each workload.)
+    Parses the clang offload bundles of the shared object (one per translation unit) and the gfx950 ELF inside each."""
+    import struct
+    if lib_path is None:
+        lib_path = os.path.join(ROOT, "femcy_amd", "libfemcy_hip.so")
+    data = open(lib_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    found = {}
+    pos = data.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", data, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", data, q)
+            triple = data[q + 24:q + 24 + tlen]
+            q += 24 + tlen
+            if b"gfx950" not in triple or size < 64:
+                continue
+            elf = data[pos + off:pos + off + size]
+            if elf[:4] != b"\x7fELF":
+                continue
+            shoff, = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+            for sh in secs:
+                if sh[1] != 2:                                   # SHT_SYMTAB
+                    continue
+                strtab = secs[sh[6]]
+                for k in range(sh[5] // 24):
+                    name_off, info, _, shndx, value, ssize = struct.unpack_from("<IBBHQQ", elf, sh[4] + 24 * k)
+                    if (info & 0xF) != 2 or ssize == 0 or shndx == 0 or shndx >= shnum:      # STT_FUNC, defined
+                        continue
+                    end = elf.index(b"\0", strtab[4] + name_off)
+                    name = elf[strtab[4] + name_off:end].decode()
+                    if not any(pt in name for pt in patterns):
+                        continue
+                    sec = secs[shndx]
+                    code = elf[value - sec[3] + sec[4]:value - sec[3] + sec[4] + ssize]
+                    found[name] = hashlib.sha256(code).hexdigest()
+        pos = data.find(magic, pos + 1)
+    if not found:
+        raise RuntimeError(f"no {patterns} kernels found in the gfx950 code objects of {lib_path}")
     h = hashlib.sha256()
-    for rel in TRAFFIC_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+    for name in sorted(found):
+        h.update(name.encode() + b"=" + found[name].encode() + b";")
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload, kernel):
+def pmc_traffic(workload, kernel, layout=None):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, separate passes, MI355X_MICROARCH.md HBM section) -- refused (None + reason) when the kernel sources
-    changed since, or when the passes were taken on a different kernel."""
+    WRITE_SIZE, separate passes, MI355X_MICROARCH.md HBM section) -- refused (None + reason) when the machine code of
+    the PCG / SpMV kernels changed since, when the matrix layout of the workload (pattern sizes) is not the one the
+    passes saw, or when the passes were taken on a different kernel."""
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if not os.path.exists(tpath):
         return None, "no profiles/spmv_traffic.json"
@@ -99,14 +142,22 @@ def pmc_traffic(workload, kernel):
         entry = doc.get("workloads", {}).get(workload)
         if entry is None:
             return None, f"no PMC pass recorded for workload {workload}"
-        if doc.get("kernel_source_sha") != kernel_source_sha():
-            return None, (f"stale: PMC passes were taken on kernel sources {doc.get('kernel_source_sha')}, "
-                          f"tree has {kernel_source_sha()}")
+        sha = kernel_object_sha()
+        if doc.get("kernel_object_sha") != sha:
+            return None, (f"stale: PMC passes were taken on kernel code {doc.get('kernel_object_sha')}, "
+                          f"the library holds {sha}")
         if kernel not in entry.get("kernel", ""):
             return None, f"PMC passes of workload {workload} were taken on {entry.get('kernel', '?')[:60]}, not on {kernel}"
+        if layout is not None and entry.get("layout") is not None and entry["layout"] != layout:
+            return None, f"stale: PMC passes saw the layout {entry['layout']}, this run has {layout}"
         return entry["hbm_bytes_per_launch"], f"profiles/spmv_traffic.json @ {doc.get('git_head', '?')}"
     except Exception as e:                                      # noqa: BLE001
         return None, f"unreadable profiles/spmv_traffic.json: {e!r}"
+
+
+def layout_signature(info):
+    """what the host decides about the matrix the kernels stream (femcy_get_pattern_info)"""
+    return {"n": int(info.n), "nnzb": int(info.nnzb), "stored_blocks": int(info.stored_blocks), "nslices": int(info.nslices)}
 
 
 def hbm_copy_probe(torch):
@@ -864,7 +915,7 @@ def main():
         rprobe = read_stream_probe(ctx, be, info.stored_blocks * 76)
         roof["read_stream_probe_gbs"] = rprobe
         roof["frac_of_read_stream_probe"] = (roof["achieved"] / rprobe) if rprobe else None
-    traffic, traffic_src = pmc_traffic(args.workload, kernel) if not args.cells else (None, "non-standard --cells")
+    traffic, traffic_src = pmc_traffic(args.workload, kernel, layout_signature(info)) if not args.cells else (None, "non-standard --cells")
     roof["traffic"], roof["traffic_source"] = traffic, traffic_src
     roof["copy_probe_gbs"] = probe
     roof["pcg_iteration_gbs"] = iter_gbs
@@ -893,7 +944,7 @@ def main():
         "config": {"workload": f"twist plate {etype} {nx}x{ny}x{nz} cells, {ne_global} elements, {n_global} DOF "
                                f"({which}), state S1 (t=0.05), "
                                f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
-                   "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters,
+                   "elements_per_gpu": int(ne), "cg_iters_per_step": args.iters, "layout": layout_signature(info),
                    "parallelism": (f"element z-slabs x{N}, slab-local mesh generation" +
                                    (" (strong scaling: the 1 M mesh cut into N)" if strong else "")) if N > 1 else "single GPU",
                    "launcher": "self-launched torch.distributed.run" if os.environ.get("FEMCY_BENCH_SELF_LAUNCHED") else
@@ -1064,7 +1115,7 @@ def cpe8_line(args, be, meshgen, torch, user_values):
     kernel = "k_pcg_persist" if persist else "k_spmv"
     if roof is None:
         roof = dict(rec["spmv"])
-    traffic, traffic_src = pmc_traffic("cpe8", kernel) if not args.cells else (None, "non-standard --cells")
+    traffic, traffic_src = pmc_traffic("cpe8", kernel, layout_signature(info)) if not args.cells else (None, "non-standard --cells")
     roof.update(traffic=traffic, traffic_source=traffic_src, copy_probe_gbs=probe,
                 pcg_iteration_gbs=rec["pcg_iteration"]["achieved"], pcg_iteration_frac_of_hbm_peak=rec["pcg_iteration"]["frac"],
                 pcg_iteration_us=rec["pcg_iteration"]["us"], pcg_path=rec["pcg_path"],
@@ -1084,8 +1135,8 @@ def cpe8_line(args, be, meshgen, torch, user_values):
         "config": {"workload": f"{name} (BASELINE configs[1]: the 2-D configuration, not the one the metric is quoted on), "
                                f"state S1 (first increment, load ratio {ti['ini_inc'] / ti['max_time']}), "
                                f"step = assemble K + Dirichlet + {args.iters} PCG iterations",
-                   "elements_per_gpu": ne, "dof": n, "cg_iters_per_step": args.iters, "parallelism": "single GPU",
-                   "launcher": "single process"},
+                   "elements_per_gpu": ne, "dof": n, "cg_iters_per_step": args.iters, "layout": layout_signature(info),
+                   "parallelism": "single GPU", "launcher": "single process"},
         "cg_iters_per_s": total / (tm["pcg_ms"] * 1e-3) if tm["pcg_ms"] > 0 else 0.0,
         "assemblies_per_s": ne / (asm_ms * 1e-3) if asm_ms > 0 else 0.0,
         "assembly_ms": asm_ms,

@@ -227,9 +227,14 @@ def test_readme_digits_through_the_device_cg_branch():
     """README.md:70 prints FEMcy's CPS6 sigma_yy at D as 93.32 / 84.40: the stop iterate (128) of the reference's own
     CG at eps = 1e-3 (conjugateGradientSolver.py:103-127), not the exact solution (93.3125 -> "93.31"); see
     tests/test_oracle_pins.py::test_readme_numbers_are_the_cg_branch_at_eps_1e3.  The same deck through the product
-    with the reference's CG settings on the device (`femcy_pcg`, eps = 1e-3) must print the same digits: a
-    reference-PRODUCED number for the PCG recurrence + stopping rule on the HIP path.  CPS3: iterate 105 prints the
-    README's 93.56; the oracle stops at 104 (93.635), the device at 106 (93.575)."""
+    with the reference's CG settings on the device (`femcy_pcg`, eps = 1e-3): iterate 128 of the device recurrence must
+    print the same digits -- a reference-PRODUCED number for the PCG recurrence on the HIP path.
+    Round 6 (profiles/r06_readme_stop_margin.txt): the STOP at 128 is a knife edge -- max|r| / (eps max|r0|) at iterate
+    128 is 0.920 ... 1.023 over the six assembly variants of this library (matrices equal to 1e-16: only the order of
+    the sums differs), so two of them stop at 128 and four at 129 (84.391 / "93.31").  Round 5's "128 = 128" held
+    because AUTO happened to be the variant with 0.993; the reference's own atomics move it the same way from run to
+    run.  What is pinned: the stop within one iterate of the as-written C restatement's, and the published digits at 128.
+    CPS3: iterate 105 prints the README's 93.56; the oracle stops at 104 (93.635), the device variants at 104 ... 107."""
     from femcy_amd.body import Body
     from femcy_amd.reader import InpInfo
     from femcy_amd.stiffnessMtrx import System_of_equations
@@ -237,12 +242,18 @@ def test_readme_digits_through_the_device_cg_branch():
     body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)
     system = System_of_equations(body, list(inp.materials.values())[0], False, verbose=False, direct="pcg", direct_eps=1e-3)
     system.solve(inp)
-    assert system.PCG.iterations == 128 and system.stats["cg_iterations"] == 128
+    assert system.PCG.iterations in (128, 129) and system.stats["cg_iterations"] == system.PCG.iterations
+    nD = int(np.argmin(np.linalg.norm(inp.nodes - np.array([2., 0.]), axis=1)))
+    e, a = np.where(body.np_elements == nD)
+    if system.PCG.iterations == 129:                             # the neighbouring iterate: README's digits are NOT its digits
+        system.compute_strain_stress()
+        assert "%.2f" % system.cauchy_stress.to_numpy()[e[0], :, 1, 1].max() == "84.39"
+    # iterate 128 of the recurrence on the same system (eps = 0: the stop rule never fires)
+    system.solve_by_CG(eps=0.0, maxit=128)
+    assert system.PCG.iterations == 128
     system.compute_strain_stress()
     sig = system.cauchy_stress.to_numpy()
     nodal = system.ELE.extrapolate(system.cauchy_stress, None, comp=3)
-    nD = int(np.argmin(np.linalg.norm(inp.nodes - np.array([2., 0.]), axis=1)))
-    e, a = np.where(body.np_elements == nD)
     assert "%.2f" % nodal[e[0], a[0]] == "93.32" and "%.2f" % sig[e[0], :, 1, 1].max() == "84.40"
     # (summation orders differ from the oracle's: 128 CG iterations amplify rounding to ~2e-5 relative)
     assert abs(nodal[e[0], a[0]] - 93.3198) < 4e-3 and abs(sig[e[0], :, 1, 1].max() - 84.3969) < 2e-3
@@ -252,11 +263,11 @@ def test_readme_digits_through_the_device_cg_branch():
     system = System_of_equations(body, list(inp.materials.values())[0], False, verbose=False, direct="pcg", direct_eps=1e-3)
     system.solve(inp)
     # the oracle's stop test passes at iterate 104 by 1 % (max|r| / max|r0| = 9.90e-4); another summation order misses it
-    # there and stops at 105 or 106 (the device: 106) -- exactly the freedom that makes the README's 93.56 (iterate 105)
+    # there and stops at 105 or 106 (the device: 104 ... 107 depending on the assembly variant, profiles/r06_readme_stop_margin.txt) -- exactly the freedom that makes the README's 93.56 (iterate 105)
     # a CG-truncation artefact.  Iterates 104 / 105 / 106 give 93.635 / 93.562 / 93.575
-    assert system.PCG.iterations in (104, 105, 106)
+    assert system.PCG.iterations in (104, 105, 106, 107)
     system.compute_strain_stress()
-    want = {104: 93.635, 105: 93.5617, 106: 93.5745}[system.PCG.iterations]
+    want = {104: 93.635, 105: 93.5617, 106: 93.5745, 107: 93.5906}[system.PCG.iterations]
     # (after ~105 iterations on this matrix two summation orders differ by ~1e-4 relative in the stress)
     assert abs(system.cauchy_stress.to_numpy()[:, :, 1, 1].max() - want) < 2e-2
     # iterate 105 = the published 93.56: one more loop body than the stop rule asks for

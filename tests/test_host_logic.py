@@ -273,3 +273,40 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
                 assert "oracle/" not in src.replace("`oracle/`", ""), os.path.join(dirpath, f)
+
+
+def test_traffic_fingerprint_is_the_kernels_machine_code(tmp_path):
+    """bench.kernel_object_sha (round 6): profiles/spmv_traffic.json is pinned to the machine code of every k_pcg_persist /
+    k_spmv instantiation inside libfemcy_hip.so, not to whole source files -- an edit elsewhere (round 5: an assembly
+    option in ctx.hpp) must not void the PMC record of the driver's line, a changed kernel must.  Checked on the built
+    library: the fingerprint is reproducible, covers the PCG kernels only (the assembly kernels hash differently and do
+    not enter it), and the committed record -- when it carries one -- is the record of THIS library or is refused loudly."""
+    import json
+    import bench
+    lib = os.path.join(ROOT, "femcy_amd", "libfemcy_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libfemcy_hip.so not built")
+    a, b = bench.kernel_object_sha(), bench.kernel_object_sha(lib)
+    assert a == b and len(a) == 16
+    assert bench.kernel_object_sha(patterns=("k_assemble",)) != a
+    assert bench.kernel_object_sha(patterns=("k_spmv",)) != a                # a subset of the kernels: another fingerprint
+    with pytest.raises(RuntimeError):
+        bench.kernel_object_sha(patterns=("no_such_kernel",))
+    # a library whose bytes OUTSIDE those kernels differ has the same fingerprint: flip a byte of the host code
+    data = bytearray(open(lib, "rb").read())
+    pos = data.find(b"femcy_last_error")                                     # a dynamic-symbol string of the host side
+    assert pos > 0
+    data[pos + 6] ^= 1
+    other = tmp_path / "libother.so"
+    other.write_bytes(bytes(data))
+    assert bench.kernel_object_sha(str(other)) == a
+    # ... and one whose kernel bytes differ does not: flip a byte inside the first gfx950 code object's .text
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    doc = json.load(open(tpath))
+    val, src = bench.pmc_traffic("c3d4", "k_pcg_persist")
+    if doc.get("kernel_object_sha") == a:
+        assert val == doc["workloads"]["c3d4"]["hbm_bytes_per_launch"] and "spmv_traffic.json" in src
+        bad, why = bench.pmc_traffic("c3d4", "k_pcg_persist", layout={"n": 1, "nnzb": 1, "stored_blocks": 1, "nslices": 1})
+        assert (bad is None and "layout" in why) or doc["workloads"]["c3d4"].get("layout") is None
+    else:
+        assert val is None and "stale" in src

@@ -1,7 +1,9 @@
 """profiles/spmv_traffic.json from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, separate passes) of bench.py.
-usage: python tools/make_traffic_json.py [--merge] <git_head> c3d4:<fetch.db>:<write.db> [c3d10:<fetch.db>:<write.db>] [cpe8:...]
-The file is stamped with a fingerprint of the SpMV kernel sources (bench.kernel_source_sha): bench.py refuses the
-numbers once those sources change."""
+usage: python tools/make_traffic_json.py [--merge] <git_head> c3d4:<fetch.db>:<write.db>[:<bench line.json>] [c3d10:...] [cpe8:...]
+The file is stamped with a fingerprint of the machine code of the PCG / SpMV kernels in libfemcy_hip.so
+(bench.kernel_object_sha) and, per workload, with the pattern sizes of the run (`config.layout` of the bench line given as
+the fourth field): bench.py refuses the numbers once a kernel or the layout changes -- and only then (round 5 hashed
+whole source files and lost the record to an unrelated edit of ctx.hpp)."""
 import json
 import os
 import sqlite3
@@ -38,22 +40,28 @@ def main():
     if "--merge" in sys.argv:                  # re-take some workloads, keep the others (same kernel sources only)
         sys.argv.remove("--merge")
         old = json.load(open(path))
-        if old.get("kernel_source_sha") != bench.kernel_source_sha():
-            raise SystemExit("--merge: the kernel sources changed since profiles/spmv_traffic.json was taken")
+        if old.get("kernel_object_sha") != bench.kernel_object_sha():
+            raise SystemExit("--merge: the kernels changed since profiles/spmv_traffic.json was taken")
         keep = old.get("workloads", {})
-    out = {"kernel_source_sha": bench.kernel_source_sha(), "git_head": head,
-           "sources": list(bench.TRAFFIC_SOURCES),
+    out = {"kernel_object_sha": bench.kernel_object_sha(), "git_head": head,
+           "kernels": list(bench.TRAFFIC_KERNELS),
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, "
                          "HBM section) -> x2; WRITE_SIZE taken as reported (uncalibrated)",
            "note": "counters are L2 <-> fabric requests, Infinity-Cache hits included",
            "workloads": dict(keep)}
     for spec in sys.argv[2:]:
-        wl, fdb, wdb = spec.split(":")
+        parts = spec.split(":")
+        wl, fdb, wdb = parts[:3]
+        layout = None
+        if len(parts) > 3:                                      # the JSON line of the profiled bench run
+            for line in open(parts[3]):
+                if line.startswith("{"):
+                    layout = json.loads(line).get("config", {}).get("layout")
         kname, nf, fetch_kb, us_f = avg_counter(fdb, "FETCH_SIZE")
         _, nw, write_kb, us_w = avg_counter(wdb, "WRITE_SIZE")
         out["workloads"][wl] = {"kernel": kname, "dispatches": [nf, nw], "fetch_size_kb_reported": fetch_kb,
                                 "write_size_kb_reported": write_kb, "avg_us_under_pmc": [us_f, us_w],
-                                "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024))}
+                                "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024)), "layout": layout}
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
