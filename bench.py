@@ -1022,7 +1022,10 @@ def main():
                  lambda: meshgen.twist_plate(48, 6, 72, quadratic=True), Element_quadratic_tetrahedral()),
                 # round 5: the 2-D configuration (BASELINE configs[1]; no CPE8 beam deck is shipped, SURVEY.md 8d: the
                 # 40 x 4 beam of tests/beam_deflection meshed with serendipity quadrilaterals, plane strain, nlgeom)
-                (CPE8_NAME, lambda: meshgen.beam_quad8(*CPE8_CELLS, plane="CPE8"), None)):
+                (CPE8_NAME, lambda: meshgen.beam_quad8(*CPE8_CELLS, plane="CPE8"), None),
+                # round 6: BASELINE configs[4] OUT of cache (SURVEY 8d "C3D10 ... then raise k"): 2.99 GB of stored matrix
+                ("twist plate C3D10 96x12x144 cells (BASELINE configs[4] at k = 12: 995 328 elements, 4 183 275 DOF)",
+                 lambda: meshgen.twist_plate_k(12, quadratic=True), Element_quadratic_tetrahedral())):
             try:
                 msh = gen()
                 if ele is None:

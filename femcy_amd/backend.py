@@ -55,6 +55,7 @@ TUNE_SKIP_OCCUPANCY_CHECK = 111
 TUNE_BARRIER_SPIN_LIMIT = 112
 TUNE_PERSIST_L2_ROWS = 113
 TUNE_ROWS4_TILE = 116       # ROWS4 assembly, round-5 experiment: 1000 GP + LCUT (tile write-out), 0 = off
+TUNE_ROWS4_ORDER = 118      # ROWS4 launch order: -1 auto, 0 longest first, 1 Morton / XCD-contiguous
 TUNE_PAIRS = 117            # PAIRS assembly knobs (femcy.h)
 TUNE_DIRECT_UPDATE = 115    # femcy_direct_solve tile update: -1 auto, 0 VALU, 1 / 2 matrix cores
 TUNE_PERSIST_MAX_MB = 114   # persistent PCG: streamed-matrix limit in MiB (0 = none, the default since round 5; 240 = rounds 2-4)

@@ -141,6 +141,10 @@ struct Ctx {
     // ---- blocked SELL-64 matrix (lane = node, diagonal block in slot 0)
     int32_t nslices = 0;
     int32_t* d_asm_order = nullptr;   // row-centric assembly (rows4): slices by decreasing work (workgroup b takes entry b)
+    int32_t* d_asm_order_near = nullptr;   // ... or in Morton order of their centroids, taken in XCD-contiguous ranges (records
+                                      // beyond the Infinity Cache: FEMCY_TUNE_ROWS4_ORDER)
+    int32_t* d_asm_order_id = nullptr;     // ... or in storage order (experiments)
+    int tune_rows4_order = -1;        // -1 auto (by the size of the element records), 0 longest first, 1 locality
     XcdRanges xcd{};                  // SpMV: slice range per XCD
     int32_t spmv_grid = 0;            // 8 * max blocks per XCD
     int32_t spmv_wps = 1;             // wavefronts per slice (1, 2 or 4)

@@ -245,7 +245,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
-    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order);
+    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order); dev_free(&c->d_asm_order_near); dev_free(&c->d_asm_order_id);
     dev_free(&c->d_pr_ptr); dev_free(&c->d_pr_unit); dev_free(&c->d_pr_code);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
@@ -374,6 +374,10 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || ((value / 1000 == 2 || value / 1000 == 4) && value % 1000 > 0),
                           "ROWS4 tile write-out: 0 (off) or 1000 GP + LCUT with GP 2 or 4 and LCUT > 0 blocks");
             c->tune_rows4_tile = (int)value;
+            break;
+        case FEMCY_TUNE_ROWS4_ORDER:
+            FEMCY_REQUIRE(value >= -1 && value <= 3, "ROWS4 launch order: -1 auto, 0 longest slices first, 1 Morton order in XCD-contiguous ranges");
+            c->tune_rows4_order = (int)value;
             break;
         case FEMCY_TUNE_PAIRS:
             if (value == -1) value = FEMCY_PAIRS_DEFAULT;

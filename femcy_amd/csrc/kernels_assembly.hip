@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(int64_t npair, int32_t 
 // lost 57 us to one).  Wider slices (the corner nodes' rows) run as before.
 template <int NPE, int NGP, bool CUBIC, int GP>
 __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t Lmax, int32_t lcut, int32_t wstride,
-                                                        const int32_t* __restrict__ order,
+                                                        int32_t xcdc, const int32_t* __restrict__ order,
                                                         const int32_t* __restrict__ ne_ptr,
                                                         const int32_t* __restrict__ ne_idx,
                                                         const uint16_t* __restrict__ slotj,
@@ -1043,8 +1043,14 @@ __global__ void __launch_bounds__(256) k_assemble_rows4(int32_t nslices, int32_t
     // work on one XCD -- 303 -> 483 us with identical instruction counts, profiles/r04_pmc_rows4_node_order.txt --
     // and contiguous per-XCD ranges (balanced by blocks: 392 us, by work: 355 us) lose the mixing of long and short
     // slices the caller's numbering happens to have (its corner rows come first)
-    if ((int32_t)blockIdx.x >= nslices) return;
-    const int32_t s = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+    // round 6 (`xcdc`, with `order` = the slices in Morton order of their centroids): workgroup b takes entry b / 8 of XCD
+    // (b % 8)'s CONTIGUOUS eighth of the order -- on a mesh whose element records exceed the Infinity Cache (C3D10 k = 12:
+    // 0.99 GB) the kernel was bound by re-fetching every record once per node of its element from HBM (FETCH 5.9 GB
+    // reported for 2.8 GB of K, profiles/r06_pmc_c3d10_k12_first.txt); neighbouring slices on one L2 find them there
+    int32_t wgi = (int32_t)blockIdx.x;
+    if (xcdc) wgi = (wgi & 7) * ((int32_t)gridDim.x >> 3) + (wgi >> 3);
+    if (wgi >= nslices) return;
+    const int32_t s = __builtin_amdgcn_readfirstlane(order[wgi]);
     const int64_t off_v = slice_off[s];
     const int64_t off = ((int64_t)__builtin_amdgcn_readfirstlane((int32_t)(off_v >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)off_v);
@@ -1955,14 +1961,22 @@ int launch_assemble(Ctx* c) {
         const size_t lds = (size_t)4 * wstride * sizeof(double);
         FEMCY_REQUIRE(lds + 512 <= (size_t)c->small_max_lds, "ROWS4 assembly needs %zu B of LDS per workgroup (longest row: %d "
                       "blocks), the device allows %d", lds, c->max_row_blocks, c->small_max_lds);
-        const int r4_grid = c->nslices;
+        // launch order: by decreasing work.  The locality order (FEMCY_TUNE_ROWS4_ORDER = 1) was built for meshes whose
+        // records exceed the Infinity Cache and MEASURED slower at every size (124 k / 295 k / 995 k C3D10: 301 -> 354,
+        // 754 -> 852, 2 477 -> 2 679 us, profiles/r06_rows4_order.txt) although it removes the re-fetches: this kernel is
+        // bound by its LDS / request rate and by the balance of long and short slices, not by HBM -- kept as a knob
+        const bool r4_near = c->tune_rows4_order == 1;
+        const bool r4_natural = c->tune_rows4_order >= 2;      // experiments: 2 = storage order in XCD-contiguous ranges, 3 = storage order round-robin
+        const int r4_grid = (r4_near || c->tune_rows4_order == 2) ? (c->nslices + 7) / 8 * 8 : c->nslices;
 #define FEMCY_ROWS4(CUB_, GP_)                                                                                         \
     do {                                                                                                               \
         if (lds > 48 * 1024)                                                                                           \
             FEMCY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows4<10, 4, CUB_, GP_>),          \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
         hipLaunchKernelGGL((k_assemble_rows4<10, 4, CUB_, GP_>), dim3(r4_grid), dim3(bs), lds, c->stream, c->nslices,  \
-                           R4_LMAX, r4_lcut, wstride, (const int32_t*)c->d_asm_order, c->d_ne_ptr, c->d_ne_idx,        \
+                           R4_LMAX, r4_lcut, wstride, (r4_near || c->tune_rows4_order == 2) ? 1 : 0,                   \
+                           (const int32_t*)(r4_natural ? c->d_asm_order_id : (r4_near ? c->d_asm_order_near : c->d_asm_order)), \
+                           c->d_ne_ptr, c->d_ne_idx,                                                                   \
                            c->d_slotj, c->d_rowlen, c->d_node_of,                                                      \
                            c->d_slice_off, c->d_dsdx, c->d_vol, c->d_C, c->cubic[0], c->cubic[1], c->cubic[2],         \
                            c->d_Kvals);                                                                                \

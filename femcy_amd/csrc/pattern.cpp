@@ -144,6 +144,51 @@ int ensure_footprint(Ctx* c) {
     return FEMCY_OK;
 }
 
+// Groups of `G` consecutive storage positions (a slice, a chunk of a slice) in Morton order of their centroids: groups
+// close in space are then processed close in time and -- with XCD-contiguous ranges of the order -- by the same L2.  What
+// it is for: an element's record is needed by every node of the element, i.e. by rows that lie in different groups;
+// in storage order (or in the longest-first order of the row-centric assemblies) those fetches are megabytes of other
+// records apart and all but the first come over the fabric (CPE8 beam: FETCH 3.7 x the records; C3D10 k = 12, records
+// beyond the Infinity Cache: 6-12 x, profiles/r06_pmc_c3d10_k12_first.txt).  Groups of padding rows only sort last.
+// Leaves `order` untouched (identity) when the coordinates are not known.
+static void spatial_order(const Ctx* c, const std::vector<int32_t>& node_of, int G, std::vector<int32_t>& order) {
+    const int dm = c->dm;
+    const int64_t ngroups = (int64_t)order.size();
+    if ((int64_t)c->h_nodes.size() != (int64_t)c->nn * dm) return;
+    double lo[3] = {0, 0, 0}, ext = 0.0;
+    for (int d = 0; d < dm; ++d) {
+        double mn = c->h_nodes[d], mx = mn;
+        for (int32_t a = 1; a < c->nn; ++a) {
+            mn = std::min(mn, c->h_nodes[(size_t)a * dm + d]);
+            mx = std::max(mx, c->h_nodes[(size_t)a * dm + d]);
+        }
+        lo[d] = mn;
+        ext = std::max(ext, mx - mn);
+    }
+    const int bits = dm == 3 ? 20 : 30;
+    const double scale = ext > 0.0 ? (double)(((int64_t)1 << bits) - 1) / ext : 0.0;
+    std::vector<uint64_t> mkey((size_t)ngroups, ~(uint64_t)0);
+    parallel_for(ngroups, [&](int64_t glo, int64_t ghi, int) {
+        for (int64_t g = glo; g < ghi; ++g) {
+            double ctr[3] = {0, 0, 0};
+            int cnt = 0;
+            for (int r = 0; r < G; ++r) {
+                const int32_t a = node_of[(size_t)g * G + r];
+                if (a < 0) continue;
+                for (int d = 0; d < dm; ++d) ctr[d] += c->h_nodes[(size_t)a * dm + d];
+                ++cnt;
+            }
+            if (!cnt) continue;
+            uint64_t k = 0, q[3];
+            for (int d = 0; d < dm; ++d) q[d] = (uint64_t)((ctr[d] / cnt - lo[d]) * scale + 0.5);
+            for (int b = bits - 1; b >= 0; --b)
+                for (int d = dm - 1; d >= 0; --d) k = (k << 1) | ((q[d] >> b) & 1);
+            mkey[g] = k;
+        }
+    });
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mkey[x] < mkey[y]; });
+}
+
 // Pair lists of the FEMCY_ASM_PAIRS assembly: a wavefront owns a chunk of 16 consecutive storage positions (a quarter of
 // a slice) and walks the (row, incident element) pairs of its rows, NPE lanes per pair.  The list is in storage order, so
 // the kernel's chain is pr_ptr (scalar) -> codes (one coalesced load) -> records, instead of node_of -> ne_ptr -> ne_idx
@@ -184,41 +229,7 @@ int ensure_pairs(Ctx* c, int RPW, bool spatial, int cpw) {
     // XCD-contiguous ranges of that order on the same L2.
     std::vector<int32_t> order((size_t)nchunks);
     for (int64_t ch = 0; ch < nchunks; ++ch) order[ch] = (int32_t)ch;
-    if (spatial && (int64_t)c->h_nodes.size() == (int64_t)c->nn * dm) {
-        double lo[3] = {0, 0, 0}, ext = 0.0;
-        for (int d = 0; d < dm; ++d) {
-            double mn = c->h_nodes[d], mx = mn;
-            for (int32_t a = 1; a < c->nn; ++a) {
-                mn = std::min(mn, c->h_nodes[(size_t)a * dm + d]);
-                mx = std::max(mx, c->h_nodes[(size_t)a * dm + d]);
-            }
-            lo[d] = mn;
-            ext = std::max(ext, mx - mn);
-        }
-        const int bits = dm == 3 ? 20 : 30;
-        const double scale = ext > 0.0 ? (double)(((int64_t)1 << bits) - 1) / ext : 0.0;
-        std::vector<uint64_t> mkey((size_t)nchunks, ~(uint64_t)0);     // chunks of padding rows only: last
-        parallel_for(nchunks, [&](int64_t clo, int64_t chi, int) {
-            for (int64_t ch = clo; ch < chi; ++ch) {
-                double ctr[3] = {0, 0, 0};
-                int cnt = 0;
-                for (int r = 0; r < RPW; ++r) {
-                    const int32_t a = c->h_node_of[(size_t)ch * RPW + r];
-                    if (a < 0) continue;
-                    for (int d = 0; d < dm; ++d) ctr[d] += c->h_nodes[(size_t)a * dm + d];
-                    ++cnt;
-                }
-                if (!cnt) continue;
-                uint64_t k = 0;
-                uint64_t q[3];
-                for (int d = 0; d < dm; ++d) q[d] = (uint64_t)((ctr[d] / cnt - lo[d]) * scale + 0.5);
-                for (int b = bits - 1; b >= 0; --b)
-                    for (int d = dm - 1; d >= 0; --d) k = (k << 1) | ((q[d] >> b) & 1);
-                mkey[ch] = k;
-            }
-        });
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return mkey[x] < mkey[y]; });
-    }
+    if (spatial) spatial_order(c, c->h_node_of, RPW, order);
     // batches (<= 64 pairs of one chunk) in processing order (kernels_assembly.hip: PairBatch, 32 bytes) and the first
     // batch of every unit of `cpw` chunks (one wavefront's work)
     std::vector<int32_t> desc, unit_ptr;
@@ -527,6 +538,12 @@ int build_pattern(Ctx* c) {
         }
         std::stable_sort(asm_order.begin(), asm_order.end(), [&](int32_t x, int32_t y) { return work[x] > work[y]; });
     }
+    // ... and by locality (round 6): the same kernel on a mesh whose element records exceed the Infinity Cache is bound by
+    // re-fetching them -- every record once per node of its element, from whichever XCD the row's slice landed on.
+    // Slices in Morton order of their centroids, XCD-contiguous ranges of that order (the kernel's `xcdc` mapping).
+    std::vector<int32_t> asm_order_near(nslices);
+    for (int32_t s = 0; s < nslices; ++s) asm_order_near[s] = s;
+    spatial_order(c, node_of, SLICE, asm_order_near);
 
     // ---- commit to the context
     c->nslices = nslices;
@@ -558,6 +575,12 @@ int build_pattern(Ctx* c) {
     if ((rc = upload(&c->d_ne_ptr, ne_ptr))) return rc;
     if ((rc = upload(&c->d_ne_idx, ne_idx))) return rc;
     if ((rc = upload(&c->d_asm_order, asm_order))) return rc;
+    if ((rc = upload(&c->d_asm_order_near, asm_order_near))) return rc;
+    {
+        std::vector<int32_t> ident(nslices);
+        for (int32_t s = 0; s < nslices; ++s) ident[s] = s;
+        if ((rc = upload(&c->d_asm_order_id, ident))) return rc;
+    }
 
     if (c->d_Kvals) (void)hipFree(c->d_Kvals);
     size_t kbytes = (size_t)stored_rows * dm * dm * SLICE * sizeof(double);

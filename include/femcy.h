@@ -207,6 +207,11 @@ enum femcy_option {
                                         LCUT blocks a wave owns 16 consecutive rows and writes 2 GP adjacent rows (GP 2 or 4)
                                         at a time from a tile of its own LDS (64 / 128 contiguous bytes per slot instead
                                         of 32); 0 = off (default: 288 - 295 us against 295, profiles/r05_pmc_rows4_tile.txt) */
+    FEMCY_TUNE_ROWS4_ORDER = 118,    /* FEMCY_ASM_ROWS4 launch order: 0 = slices by decreasing work, round-robin over the XCDs (even
+                                        shares of every weight class: best while the element records sit in the Infinity
+                                        Cache), 1 = slices in Morton order of their centroids, XCD-contiguous ranges (records
+                                        re-used inside one L2: best beyond it), -1 (default) = by the size of the records;
+                                        the same bits of K either way */
     FEMCY_TUNE_PAIRS = 117,          /* FEMCY_ASM_PAIRS: -1 = default (163), else bit 0 = workgroups take XCD-contiguous ranges of
                                         the processing order, bits 1-2 = rows per wavefront (0: 16, 1: 8), bits 3-4 = steps of
                                         element records in flight - 2 (0..2), bit 5 = chunks processed in Morton order of their

@@ -577,3 +577,89 @@ def test_cpe8_bench_size_against_c_oracle(beam):
     xo, ito, r0o, rmaxo = co.cg(b, eps=0.0, maxit=30)
     assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
     assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+
+
+# ------------------------------------------------------------------- C3D10 out of cache (SURVEY 8d "then raise k", round 6)
+def test_c3d10_k12_out_of_cache_against_c_oracle():
+    """995 328 C3D10 elements, 4 183 275 DOF, 2.99 GB of stored matrix -- twelve times the Infinity Cache, eight times
+    every earlier C3D10 record: geometry, the default assembly (k_assemble_rows4) and its launch-order / write-out knobs
+    (the same bits), the 4-wave product, the Dirichlet treatment and 30 iterations of the three-launch PCG against the
+    as-written C restatement (13 GB of ELL arrays on the host), plus symmetry and the rigid translations."""
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_quadratic_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    from femcy_amd.user_defined import user_dirichletBC_values
+    from oracle.c_oracle import COracle
+    from oracle.elements import elem_def
+    from oracle.femcy_oracle import Material
+    from helpers import node_adjacency
+    m = meshgen.twist_plate_k(12, quadratic=True)
+    assert m["elements"].shape == (995328, 10) and m["nodes"].shape == (1394425, 3)
+    ctx = be.Context(0)
+    try:
+        ctx.set_mesh(m["nodes"], m["elements"])
+        ctx.set_element(Element_quadratic_tetrahedral())
+        ctx.set_material(LinearIsotropic(*m["elastic"]))
+        info = ctx.build_pattern()
+        assert (info.n, info.nnzb, info.max_row_blocks) == (4183275, 38924641, 65)
+        u = np.zeros(ctx.n)
+        cons = []
+        for bc in m["dirichlet_bc_info"]:
+            cons.append(np.asarray(bc["node_set"]) * 3 + bc["dof"])
+            if bc["user"]:
+                user_dirichletBC_values(u, bc["node_set"], 3, bc["dof"], m["nodes"], 0.05)
+        cons = np.unique(np.concatenate(cons))
+        ed = elem_def("C3D10")
+        ptr, idx = node_adjacency(m["elements"], m["nodes"].shape[0])
+        assert idx.size == info.nnzb
+        co = COracle(m["nodes"], m["elements"], ed.dN_table(), ed.gauss_weights, Material("lin3d", m["elastic"]).C, ptr, idx)
+        ctx.upload(be.VEC_DOF, u)
+        ctx.assemble_K(be.VEC_DOF)
+        co.get_dsdx_and_vol(u)
+        co.assemble()
+        assert rel(ctx.gauss_field(be.GP_VOL).to_numpy(), co.vol) < 1e-12
+        assert rel(ctx.gauss_field(be.GP_DSDX).to_numpy(), co.dsdx) < 1e-12
+        x = np.random.default_rng(0).standard_normal(ctx.n)
+        yo = co.compute_Ad(x)
+        scale = np.abs(yo).max()
+        ctx.upload(be.VEC_TMP0, x)
+        ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+        y0 = ctx.download(be.VEC_TMP1)
+        assert np.abs(y0 - yo).max() < 1e-12 * scale
+        for order in (1, 2, 3, 0):                               # launch orders of rows4: work moves between workgroups only
+            ctx.set_option(be.TUNE_ROWS4_ORDER, order)
+            ctx.assemble_K(be.VEC_DOF)
+            ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+            assert np.array_equal(ctx.download(be.VEC_TMP1), y0), order
+        ctx.set_option(be.TUNE_ROWS4_ORDER, -1)
+        z = np.random.default_rng(3).standard_normal(ctx.n)
+        ctx.upload(be.VEC_DU, z)
+        ctx.spmv(be.VEC_DU, be.VEC_TMP1)
+        Kz = ctx.download(be.VEC_TMP1)
+        assert abs(x @ Kz - z @ y0) < 1e-10 * abs(x @ Kz)
+        for i in range(3):
+            t = np.zeros(ctx.n)
+            t[i::3] = 1.0
+            ctx.upload(be.VEC_DU, t)
+            ctx.spmv(be.VEC_DU, be.VEC_TMP1)
+            assert np.abs(ctx.download(be.VEC_TMP1)).max() < 1e-9 * scale
+        ctx.internal_force(be.VEC_DOF, be.VEC_FORCE)
+        f = co.internal_force(u, 0, *m["elastic"])
+        assert rel(ctx.download(be.VEC_FORCE), f) < 1e-11
+        ctx.vector(be.VEC_RHS).fill(0.0)
+        ctx.vec_sub(be.VEC_RESIDUAL, be.VEC_FORCE, be.VEC_RHS)
+        ctx.assemble_K(be.VEC_DOF)
+        ctx.dirichlet_newton(cons, be.VEC_RESIDUAL)
+        co.get_dsdx_and_vol(u)
+        co.assemble()
+        co.zero_rows_cols_unit_diag(cons)
+        f[cons] = 0.0
+        assert rel(ctx.download(be.VEC_RESIDUAL), f) < 1e-11
+        it, r0, rmax = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=30)
+        xo, ito, r0o, rmaxo = co.cg(f, eps=0.0, maxit=30)
+        assert it == ito == 30 and abs(r0 - r0o) < 1e-11 * r0o and abs(rmax - rmaxo) < 1e-6 * rmaxo
+        assert np.linalg.norm(ctx.download(be.VEC_X) - xo) / np.linalg.norm(xo) < 1e-8
+        tm = ctx.timing()
+        assert tm["solves_three"] >= 1 and tm["solves_persist"] == 0     # 21 790 slices: beyond the persistent kernel's layout
+    finally:
+        ctx.close()

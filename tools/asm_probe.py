@@ -19,8 +19,11 @@ if wl == "cpe8":
     nx, ny = (int(v) for v in os.environ.get("FEMCY_PROBE_CELLS", "1280,128").split(","))
     m = meshgen.beam_quad8(nx, ny, plane="CPE8")
 else:
-    m = (meshgen.twist_plate(48, 6, 72, quadratic=True, renumber=os.environ.get("FEMCY_BENCH_RENUM", "0") == "1") if quad
-         else meshgen.twist_plate_k(12))
+    if os.environ.get("FEMCY_PROBE_K"):                         # BASELINE.md family: cells (8k, k, 12k)
+        m = meshgen.twist_plate_k(int(os.environ["FEMCY_PROBE_K"]), quadratic=quad)
+    else:
+        m = (meshgen.twist_plate(48, 6, 72, quadratic=True, renumber=os.environ.get("FEMCY_BENCH_RENUM", "0") == "1") if quad
+             else meshgen.twist_plate_k(12))
 ctx = be.Context(0)
 if os.environ.get("FEMCY_BENCH_SIGMA"):
     ctx.set_option(be.OPT_SELL_SIGMA, int(os.environ["FEMCY_BENCH_SIGMA"]))
@@ -38,6 +41,8 @@ ctx.set_option(be.OPT_ASSEMBLY, mode)
 if os.environ.get("FEMCY_ROWS4_TILE"):                          # "GP,LCUT": FEMCY_TUNE_ROWS4_TILE = 1000 GP + LCUT
     gp, lcut = (int(v) for v in os.environ["FEMCY_ROWS4_TILE"].split(","))
     ctx.set_option(be.TUNE_ROWS4_TILE, 1000 * gp + lcut)
+if os.environ.get("FEMCY_PROBE_ROWS4_ORDER"):                   # FEMCY_TUNE_ROWS4_ORDER: -1 auto, 0 longest first, 1 locality
+    ctx.set_option(be.TUNE_ROWS4_ORDER, int(os.environ["FEMCY_PROBE_ROWS4_ORDER"]))
 if os.environ.get("FEMCY_PROBE_PAIRS"):                         # FEMCY_TUNE_PAIRS bits
     ctx.set_option(be.TUNE_PAIRS, int(os.environ["FEMCY_PROBE_PAIRS"]))
 ctx.upload(be.VEC_DOF, np.zeros(ctx.n))
@@ -50,6 +55,6 @@ for _ in range(reps):
 tm = ctx.timing()
 info = ctx.pattern_info()
 print(f"{wl}: {ctx.ne} elements, {ctx.n} DOF, nnzb {info.nnzb}, longest row {info.max_row_blocks} blocks")
-print(f"{wl} mode {mode} knobs {os.environ.get('FEMCY_PROBE_PAIRS', '-')} lib {os.path.basename(be.LIB_PATH)}: geom {tm['geom_ms']/tm['geom_launches']*1e3:.1f} us, "
+print(f"{wl} mode {mode} knobs {os.environ.get('FEMCY_PROBE_PAIRS', '-')} rows4 order {os.environ.get('FEMCY_PROBE_ROWS4_ORDER', '-')} lib {os.path.basename(be.LIB_PATH)}: geom {tm['geom_ms']/tm['geom_launches']*1e3:.1f} us, "
       f"assemble {tm['assemble_ms']/tm['assemble_launches']*1e3:.1f} us")
 ctx.close()
