@@ -299,7 +299,14 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     const int nwx = (G / PNX) * 4;                               // waves per XCD
     const int wx = (blockIdx.x / PNX) * 4 + wave;                // this wave among them
     int32_t sl[SPW], Ls[SPW], node[SPW], dpos[SPW];
-    int64_t offs[SPW];
+    uint32_t inmask = 0;                                          // bit t: this lane is a node of slice t (not a padding lane)
+#define IN(t_) (((inmask >> (t_)) & 1u) != 0)
+    // per-slice scalars are kept SMALL: first stored block row as 32 bits (femcy_build_pattern refuses more than 2^31 stored
+    // blocks), the three row marks packed into one word.  With seven scalar words per slice the 6- and 7-slice shapes of
+    // 3 x 3 blocks needed 77 / 110 scalar spill slots -- more than the 64 lanes of one spill register -- and faulted on
+    // the first launch ("write access to a read-only page", every mesh size; 54 slots at five slices run): round 6
+    int32_t offs32[SPW];
+#define OFFS(t_) ((int64_t)offs32[t_])
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
         const int32_t s = __builtin_amdgcn_readfirstlane(a.assign[((size_t)xk * nwx + wx) * SPW + t]);
@@ -307,9 +314,12 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         sl[t] = act ? s : -1;
         Ls[t] = act ? __builtin_amdgcn_readfirstlane(a.slice_len[s]) : 0;
         const int64_t o = act ? a.slice_off[s] : 0;
-        offs[t] = ((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o);
+        offs32[t] = __builtin_amdgcn_readfirstlane((int)(uint32_t)o);
         node[t] = act ? a.node_of[(int64_t)s * 64 + lane] : -1;
+        // (round 6: `node` lives until the vectors are initialised and is re-loaded for the final store of x -- the loop
+        // tests the bit.  With 6 / 7 slices of 3 x 3 blocks per wave hipcc 7.0 kept node[t] in an accumulation register it
+        // also handed to a double: the final store went through garbage, profiles/r06_persist_spw67_fault.txt)
+        if (node[t] >= 0) inmask |= 1u << t;
         // where this lane's d lives in the published vector: its node (round 2), or its storage position (VAR & 4)
         dpos[t] = WIDE ? (act ? s * 64 + lane : 0) : (node[t] >= 0 ? node[t] : 0);
     }
@@ -322,29 +332,31 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
         for (int jj = 0; jj < RJ; ++jj) {
             const bool has = jj < Ls[t];
-            const double* src = a.vals + (offs[t] + (has ? jj : 0)) * (int64_t)(DD * 64);
+            const double* src = a.vals + (OFFS(t) + (has ? jj : 0)) * (int64_t)(DD * 64);
 #pragma unroll
             for (int k = 0; k < DD; ++k) rv[t][jj][k] = has ? src[kv_index<DM>(0, k, lane)] : 0.0;
-            rcl[t][jj] = has ? a.bcol[(offs[t] + jj) * 64 + lane] : dpos[t];
+            rcl[t][jj] = has ? a.bcol[(OFFS(t) + jj) * 64 + lane] : dpos[t];
         }
     // LDS rows are handed out from the LAST slice backwards, so that slice 0 keeps streamed rows: its first batch is
-    // the one prefetched during the synchronisation windows (below).  jl[t] .. je[t]-1 = the slice's rows in LDS.
-    int32_t jl[SPW], je[SPW], ql[SPW];
+    // the one prefetched during the synchronisation windows (below).  JL(t) .. JE(t)-1 = the slice's rows in LDS.
+    uint32_t jq[SPW];                                             // jl | ql << 8 | je << 16
+#define JL(t_) ((int32_t)(jq[t_] & 0xffu))
+#define QL(t_) ((int32_t)((jq[t_] >> 8) & 0xffu))
+#define JE(t_) ((int32_t)(jq[t_] >> 16))
     {
         int qn = 0;
 #pragma unroll
         for (int t = SPW - 1; t >= 0; --t) {
-            jl[t] = min(RJ, Ls[t]);
-            const int nl = max(0, min(Ls[t] - jl[t], a.lds_rows - qn));
-            ql[t] = qn;
-            je[t] = jl[t] + nl;
+            const int jl_ = min(RJ, Ls[t]);
+            const int nl = max(0, min(Ls[t] - jl_, a.lds_rows - qn));
+            jq[t] = (uint32_t)jl_ | ((uint32_t)qn << 8) | ((uint32_t)(jl_ + nl) << 16);
             qn += nl;
-            for (int32_t j = jl[t]; j < je[t]; ++j) {
-                const int q = ql[t] + (j - jl[t]);
-                const double* src = a.vals + (offs[t] + j) * (int64_t)(DD * 64);
+            for (int32_t j = JL(t); j < JE(t); ++j) {
+                const int q = QL(t) + (j - JL(t));
+                const double* src = a.vals + (OFFS(t) + j) * (int64_t)(DD * 64);
 #pragma unroll
                 for (int k = 0; k < DD; ++k) lvals[(q * DD + k) * 64 + lane] = src[kv_index<DM>(0, k, lane)];
-                lcols[q * 64 + lane] = a.bcol[(offs[t] + j) * 64 + lane];
+                lcols[q * 64 + lane] = a.bcol[(OFFS(t) + j) * 64 + lane];
             }
         }
     }
@@ -447,9 +459,9 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 for (int k = 0; k < DD; ++k) e[u][k] = 0.0;
             }
     };
-    const int32_t* __restrict__ bc0 = a.bcol + offs[0] * 64 + lane;
-    const double2* __restrict__ vp0 = reinterpret_cast<const double2*>(a.vals + offs[0] * (int64_t)(DD * 64)) + lane;
-    const double* __restrict__ vs0 = a.vals + offs[0] * (int64_t)(DD * 64) + NP * 128 + lane;
+    const int32_t* __restrict__ bc0 = a.bcol + OFFS(0) * 64 + lane;
+    const double2* __restrict__ vp0 = reinterpret_cast<const double2*>(a.vals + OFFS(0) * (int64_t)(DD * 64)) + lane;
+    const double* __restrict__ vs0 = a.vals + OFFS(0) * (int64_t)(DD * 64) + NP * 128 + lane;
     // rows of the batch prefetched during the synchronisation windows.  bit 4 of dbg: no prefetch (a layout variant, not
     // work skipping).  Tagged-granule form: wave 0 sweeps the granules during those windows, and VMEM returns in order
     // -- a prefetch of its own would sit in front of every sweep -- so wave 0 does not prefetch (the host hands it
@@ -457,11 +469,14 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #ifndef FEMCY_INB_PREFETCH
 #define FEMCY_INB_PREFETCH 1
 #endif
-    const int npf = ((a.dbg & 16) || (A2A && wave == 0) || (INB && !FEMCY_INB_PREFETCH)) ? 0 : max(0, min(CH, Ls[0] - je[0]));
+    // (seven slices of 3 x 3 blocks per wave: 210 registers of vectors -- no prefetch buffer, its 76 registers are what
+    // the shape does not have; with it hipcc 7.0 produced a kernel whose first iterate was wrong, round 6)
+    constexpr bool PREFETCH = !(DM == 3 && SPW >= 7);
+    const int npf = (!PREFETCH || (a.dbg & 16) || (A2A && wave == 0) || (INB && !FEMCY_INB_PREFETCH)) ? 0 : max(0, min(CH, Ls[0] - JE(0)));
     int32_t pcol[CH];
     double pe[CH][DD];
-    const int32_t jpf = npf > 0 ? je[0] : 0;                               // (npf = 0: row 0's column, unused)
-    load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe);
+    const int32_t jpf = npf > 0 ? JE(0) : 0;                               // (npf = 0: row 0's column, unused)
+    if (PREFETCH) load_rows(bc0, vp0, vs0, jpf, npf, JE(0) + a.l2_rows, pcol, pe);
     // ---- x0 = 0, r = b, d = M r
     double xo[SPW][DM], rr[SPW][DM], mm[SPW][DM], dd[SPW][DM], Ad[SPW][DM];
     double accs = 0.0, accm = 0.0;
@@ -625,12 +640,12 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
         for (int t = 0; t < SPW; ++t) {
             const int32_t L = Ls[t];
-            const int32_t* __restrict__ bcp = a.bcol + offs[t] * 64 + lane;
-            const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + offs[t] * (int64_t)(DD * 64)) + lane;
-            const double* __restrict__ vs = a.vals + offs[t] * (int64_t)(DD * 64) + NP * 128 + lane;
-            int32_t j = je[t];                                               // first streamed block row
+            const int32_t* __restrict__ bcp = a.bcol + OFFS(t) * 64 + lane;
+            const double2* __restrict__ vp = reinterpret_cast<const double2*>(a.vals + OFFS(t) * (int64_t)(DD * 64)) + lane;
+            const double* __restrict__ vs = a.vals + OFFS(t) * (int64_t)(DD * 64) + NP * 128 + lane;
+            int32_t j = JE(t);                                               // first streamed block row
             // slice 0: its first streamed batch was loaded while the wave sat in the last synchronisation points
-            if (t == 0 && npf > 0 && !PDBG(a, 1)) {
+            if (PREFETCH && t == 0 && npf > 0 && !PDBG(a, 1)) {
                 double xg[CH][DM];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(pcol[u], poff, xg[u]);
@@ -679,9 +694,9 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 }
             }
             // block rows held in LDS, CH at a time (a short batch repeats its last row's gather and skips the multiply)
-            for (int32_t jr = jl[t]; jr < je[t] && !PDBG(a, 2); jr += CH) {
-                const int nb = min(CH, je[t] - jr);
-                const int q = ql[t] + (jr - jl[t]);
+            for (int32_t jr = JL(t); jr < JE(t) && !PDBG(a, 2); jr += CH) {
+                const int nb = min(CH, JE(t) - jr);
+                const int q = QL(t) + (jr - JL(t));
                 double xg[CH][DM];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(lcols[(q + min(u, nb - 1)) * 64 + lane], poff, xg[u]);
@@ -705,7 +720,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 int32_t colA[CH], colB[CH];
                 double eA[CH][DD], eB[CH][DD];
                 int nbA = min(CH, L - j), nbB = 0;
-                load_rows(bcp, vp, vs, j, nbA, je[t] + a.l2_rows, colA, eA);
+                load_rows(bcp, vp, vs, j, nbA, JE(t) + a.l2_rows, colA, eA);
                 for (;;) {
                     {
                         double xg[CH][DM];
@@ -714,7 +729,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                         __builtin_amdgcn_sched_barrier(0);
                         const int32_t jn = j + nbA;
                         nbB = max(0, min(CH, L - jn));
-                        load_rows(bcp, vp, vs, nbB > 0 ? jn : j, nbB, je[t] + a.l2_rows, colB, eB);
+                        load_rows(bcp, vp, vs, nbB > 0 ? jn : j, nbB, JE(t) + a.l2_rows, colB, eB);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
@@ -735,7 +750,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                         __builtin_amdgcn_sched_barrier(0);
                         const int32_t jn = j + nbB;
                         nbA = max(0, min(CH, L - jn));
-                        load_rows(bcp, vp, vs, nbA > 0 ? jn : j, nbA, je[t] + a.l2_rows, colA, eA);
+                        load_rows(bcp, vp, vs, nbA > 0 ? jn : j, nbA, JE(t) + a.l2_rows, colA, eA);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
@@ -757,7 +772,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 const int nb = min(CH, L - j);
                 int32_t col[CH];
                 double e[CH][DD], xg[CH][DM];
-                load_rows(bcp, vp, vs, j, nb, je[t] + a.l2_rows, col, e);
+                load_rows(bcp, vp, vs, j, nb, JE(t) + a.l2_rows, col, e);
 #pragma unroll
                 for (int u = 0; u < CH; ++u) gather_d(col[u], poff, xg[u]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -779,7 +794,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
             for (int r = 0; r < DM; ++r) {
                 Ad[t][r] = acc[t][r];
-                if (node[t] >= 0) dot += dd[t][r] * acc[t][r];
+                if (IN(t)) dot += dd[t][r] * acc[t][r];
             }
         return dot;
     };
@@ -839,8 +854,8 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #pragma unroll
                     for (int k = 0; k < DD; ++k) pe[u][k] = 0.0;
                 }
-            } else {
-                load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe);
+            } else if (PREFETCH) {
+                load_rows(bc0, vp0, vs0, jpf, npf, JE(0) + a.l2_rows, pcol, pe);
             }
             ++round;
             __syncthreads();
@@ -848,7 +863,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             dAd = bc[0];
         } else {
             if (tid == 0) pst(a.part1 + (size_t)(it & 1) * G + blockIdx.x, (sm1[0] + sm1[1]) + (sm1[2] + sm1[3]));
-            if (!grid_barrier(a, round++, &s_fail, [&] { load_rows(bc0, vp0, vs0, jpf, npf, je[0] + a.l2_rows, pcol, pe); })) { done = 3; return; }
+            if (!grid_barrier(a, round++, &s_fail, [&] { if (PREFETCH) load_rows(bc0, vp0, vs0, jpf, npf, JE(0) + a.l2_rows, pcol, pe); })) { done = 3; return; }
             double ps = 0.0;
             for (int k = tid; k < G; k += PBS) ps += pld(a.part1 + (size_t)(it & 1) * G + k);
             ps = wave_sum(ps);
@@ -899,7 +914,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
                 xo[t][c] += alpha * dd[t][c];
                 const double ri = rr[t][c] - alpha * Ad[t][c];
                 rr[t][c] = ri;
-                if (node[t] >= 0) {
+                if (IN(t)) {
                     if (!MULTI || ((ownbits >> (t * DM + c)) & 1u)) accs += ri * mm[t][c] * ri;
                     accm = fmax(accm, pabs(ri));
                 }
@@ -921,7 +936,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
             for (int t = 0; t < SPW; ++t) {
 #pragma unroll
                 for (int c = 0; c < DM; ++c) dd[t][c] = mm[t][c] * rr[t][c] + beta * dd[t][c];
-                if (sl[t] >= 0 && (WIDE || node[t] >= 0)) publish_d(dpos[t], noff, dd[t]);
+                if (sl[t] >= 0 && (WIDE || IN(t))) publish_d(dpos[t], noff, dd[t]);
                 // V_INBAND: re-arm the buffer the iteration after next publishes into (last read one iteration ago)
                 if (INB && sl[t] >= 0) arm_d(dpos[t], ((it + 1) % 3) * a.npad * 8);
             }
@@ -953,9 +968,10 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
     while (!done && it < a.maxit) iteration();
 #pragma unroll
     for (int t = 0; t < SPW; ++t)
-        if (node[t] >= 0) {
+        if (IN(t)) {
+            const int64_t nd = a.node_of[(int64_t)sl[t] * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < DM; ++c) a.x[(int64_t)node[t] * DM + c] = xo[t][c];
+            for (int c = 0; c < DM; ++c) a.x[nd * DM + c] = xo[t][c];
         }
     if (blockIdx.x == 0 && tid == 0) {
         a.st->iters = it;
@@ -965,6 +981,11 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         a.st->rMr[0] = rMr;
     }
 }
+#undef IN
+#undef OFFS
+#undef JL
+#undef QL
+#undef JE
 
 // ------------------------------------------------------------------------------------------------ ceiling probes
 // What the persistent kernel runs against (bench.py's roofline): (1) the rate at which the chip streams a read-only
@@ -1163,7 +1184,7 @@ int64_t persist_streamed_bytes(Ctx* c);
 
 // the launch shape of the persistent kernel for this pattern: slices per wave (SPW: the kernel's register arrays),
 // block rows per slice in registers (RJ) and per wave in LDS.  3 x 3 blocks: SPW 3 (RJ 4 / 5) or 4 (RJ 3) -- up to
-// 4 096 slices = 786 k DOF; 2 x 2 blocks (round 5): additionally SPW 6 (RJ 3) and 8 (RJ 2) -- a lane's vectors take
+// 4 096 slices = 786 k DOF -- and, round 6, 5 (RJ 1) and 6 (RJ 0): up to 6 144 slices = 1.18 M DOF; 2 x 2 blocks (round 5): additionally SPW 6 (RJ 3) and 8 (RJ 2) -- a lane's vectors take
 // 20 registers per slice instead of 30, a block row 9 instead of 19 -- up to 8 192 slices = 1.05 M DOF in 2-D
 // (BASELINE configs[1] at the size of the 3-D headline system).  false = the pattern does not fit.
 struct PersistShape { int G, nwx, SPW, rj, lds_rows; int32_t maxrange; };
@@ -1177,9 +1198,13 @@ bool persist_shape(const Ctx* c, PersistShape* out) {
     const int per_wave = (sh.maxrange + sh.nwx - 1) / sh.nwx;
     const bool on = c->opt_persist_rj != 0;
     if (c->dm == 3) {
-        if (per_wave > 4) return false;
-        sh.SPW = per_wave > 3 ? 4 : 3;
-        sh.rj = sh.SPW == 3 ? c->opt_persist_rj : (on ? 3 : 0);
+        // (7 slices per wave -- 1.37 M DOF, the C3D10 plate at k = 8 -- is written and compiles without spills, but its
+        // kernel faults or returns a wrong first iterate under hipcc 7.0 with and without the prefetch buffer
+        // (profiles/r06_persist_spw67_fault.txt): not admitted; FEMCY_DEBUG_FORCE_SPW reaches it for whoever debugs it)
+        if (per_wave > 6) return false;
+        sh.SPW = per_wave > 3 ? per_wave : 3;
+        if (const char* e = getenv("FEMCY_DEBUG_FORCE_SPW")) sh.SPW = std::min(7, std::max(sh.SPW, atoi(e)));
+        sh.rj = sh.SPW == 3 ? c->opt_persist_rj : (!on ? 0 : (sh.SPW == 4 ? 3 : (sh.SPW >= 6 ? 0 : 1)));
     } else {
         if (per_wave > 8) return false;
         sh.SPW = per_wave > 6 ? 8 : (per_wave > 4 ? 6 : (per_wave > 3 ? 4 : 3));
@@ -1196,7 +1221,8 @@ bool persist_shape(const Ctx* c, PersistShape* out) {
 bool persist_pattern_fits(Ctx* c) {
     if (!c->opt_persist || !c->have_pattern) return false;
     PersistShape sh;
-    if (!persist_shape(c, &sh) || c->dm != 3) return false;      // (the multi-rank kernel is instantiated for 3 x 3 blocks)
+    if (!persist_shape(c, &sh) || c->dm != 3 || sh.SPW > 4) return false;   // (the multi-rank kernel is instantiated for 3 x 3 blocks,
+                                                                  // three or four slices per wave)
     const int G = sh.G;
     if (c->opt_persist >= 2) return true;
     // evaluated here once so that every rank applies the same verdict.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
@@ -1370,8 +1396,20 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
             else if (c->opt_persist_rj == 2) { FEMCY_PERSIST_V(3, 3, 2) }
 #endif
             else { FEMCY_PERSIST_V(3, 3, 0) }
-        } else if (c->dm == 3) {
+        } else if (c->dm == 3 && SPW == 4) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
+        } else if (c->dm == 3) {
+            // round 6: 5 and 6 slices per wave for 3 x 3 blocks (up to 6 144 slices = 1.18 M DOF keep one launch per solve).
+            // A lane's five vectors take 30 registers per slice: 150 / 180 of the 512, so one block row per slice (19
+            // registers) at five slices and none at six is all that stays in registers; default variant only.  Every
+            // shape is held to the three-launch loop's iterates by tests/test_gpu_pcg_persist.py -- <3,6,1> compiled to a
+            // kernel that kept node[t] in an accumulation register it also gave to a double (debug-agent dump in
+            // profiles/r06_persist_spw67_fault.txt) and is NOT used
+            FEMCY_REQUIRE((var & 15) == FEMCY_PERSIST_DEFAULT_VARIANT, "5 .. 7 slices per wave exist for the default variant of the persistent PCG only");
+            // (registers, hipcc 7.0: <3,5,1> / <3,6,1> 486 without spills, <3,5,2> and <3,7,1> spill 12 / 32, <3,7,0> 419)
+            if (SPW == 5) { if (c->opt_persist_rj) FEMCY_PERSIST(3, 5, 1, FEMCY_PERSIST_DEFAULT_VARIANT); else FEMCY_PERSIST(3, 5, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
+            else if (SPW == 6) { FEMCY_PERSIST(3, 6, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
+            else { FEMCY_PERSIST(3, 7, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
         } else if (SPW == 3) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }
         } else if (SPW == 4) {

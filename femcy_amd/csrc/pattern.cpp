@@ -52,8 +52,11 @@ void spmv_split(Ctx* c) {
     if (wps != 1 && wps != 2 && wps != 4) {
         const double mean_len = nslices ? (double)stored_rows / nslices : 0.0;
         // rocprofv3, C3D10 plate (mean 27 blocks per row): 99 / 88 / 84 us for 1 / 2 / 4 wavefronts per slice;
-        // C3D4 (15 blocks per row): equal
-        wps = mean_len <= 20.0 ? 1 : 4;
+        // C3D4 (15 blocks per row): equal (round 6, launch to launch: 30.7 / 31.4 / 31.1 us at 1 M elements, 284 / 297 / 307
+        // at 8 M -- one wave per slice stays).  2 x 2 blocks (round 6, CPE8 beam of 1 M DOF, 15.6 blocks per row, 36 bytes
+        // per block: a wave's share of a slice is half the bytes of a 3 x 3 one): 51.6 / 51.0 / 45.8 us = 0.72 -> 0.81 of
+        // HBM with four waves per slice (profiles/r06_spmv_wps.txt)
+        wps = c->dm == 2 ? (mean_len > 8.0 ? 4 : 1) : (mean_len <= 20.0 ? 1 : 4);
     }
     c->spmv_wps = wps;
     // matrix stream policy.  Measured (MI355X, C3D4 plate): a 198 MB matrix (1 M elements) is re-read every CG

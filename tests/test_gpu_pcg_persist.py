@@ -440,3 +440,56 @@ def test_probe_spmv_times_the_product_in_both_orders(plate):
     with pytest.raises(be.FemcyError):
         ctx.probe_spmv(0, True)
     ctx.set_option(be.OPT_PCG_PERSIST, 1)
+
+
+@pytest.mark.parametrize("cells,spw", [((56, 7, 84), 5), ((60, 8, 90), 6)])
+def test_persistent_pcg_five_and_six_slices_per_wave(gpu_ctx_factory, cells, spw):
+    """round 6: 3 x 3 blocks with 5 and 6 slices per wave (one block row per slice in registers at 5, none at 6) -- C3D10
+    plates of 0.86 / 1.12 M DOF (k = 7, 7.5: matrices of 0.6 / 0.8 GB streamed from HBM every iteration) keep ONE launch
+    per solve.  Iterates against the three-launch loop at fixed counts (this is the test that rejected the shapes hipcc
+    miscompiled: <3,6,1>, <3,7,*>); the default path must be the faster one."""
+    import time
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_quadratic_tetrahedral
+    m = meshgen.twist_plate(*cells, quadratic=True)
+    be, ctx, info, b = _system(gpu_ctx_factory, m, Element_quadratic_tetrahedral())
+    assert 1024 * (spw - 1) < info.nslices <= 1024 * spw
+    out, us = {}, {}
+    for persist in (0, 1):
+        ctx.set_option(be.OPT_PCG_PERSIST, persist)
+        before = _paths(ctx)
+        out[persist] = [_solve(ctx, be, 0.0, k) for k in (1, 9, 30)]
+        assert _paths(ctx)[2 if persist else 0] - before[2 if persist else 0] == 3      # the path that ran
+        ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=50)
+        best = 1e30
+        for _ in range(3):
+            t = time.perf_counter()
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=200)
+            best = min(best, (time.perf_counter() - t) / 200 * 1e6)
+        us[persist] = best
+    for (((it0, r00, rm0), x0), ((it1, r01, rm1), x1)), tol in zip(zip(out[0], out[1]), (1e-13, 1e-12, 1e-10)):
+        assert it0 == it1 and r00 == r01 and abs(rm0 - rm1) <= tol * rm0
+        assert np.linalg.norm(x1 - x0) <= tol * np.linalg.norm(x0)
+    iter_bytes = 8 * info.nnz + 4 * info.nnzb + 4 * (ctx.nn + 1) + 16 * ctx.n + 8 * 11 * ctx.n     # SURVEY 8d: product + 11 vector passes
+    print(f"[C3D10 {cells}: {ctx.n} DOF, {info.nslices} slices, {spw} per wave] three launches {us[0]:.1f} us / iteration, "
+          f"persistent {us[1]:.1f} = {iter_bytes / us[1] / 1e3 / 8000:.2f} of HBM")
+    assert us[1] < us[0]
+    # a second solve on the same context: the same bits (no stale state between launches)
+    ctx.set_option(be.OPT_PCG_PERSIST, 1)
+    r1, x1 = _solve(ctx, be, 0.0, 30)
+    r2, x2 = _solve(ctx, be, 0.0, 30)
+    assert r1 == r2 and np.array_equal(x1, x2)
+    ctx.close()
+
+
+def test_beyond_six_slices_per_wave_takes_three_launches(gpu_ctx_factory):
+    """the C3D10 plate at k = 8 (1.27 M DOF, 6 614 slices = 7 per wave) is beyond the admitted shapes of the persistent
+    kernel: femcy_pcg must take the three-launch loop there by itself (and say so in femcy_timing)"""
+    from femcy_amd import meshgen
+    from femcy_amd.element_zoo import Element_quadratic_tetrahedral
+    be, ctx, info, b = _system(gpu_ctx_factory, meshgen.twist_plate(64, 8, 96, quadratic=True), Element_quadratic_tetrahedral())
+    assert 6144 < info.nslices <= 7168
+    before = _paths(ctx)
+    (it, r0, rm), x = _solve(ctx, be, 0.0, 5)
+    assert it == 5 and np.isfinite(x).all() and _paths(ctx)[0] - before[0] == 1 and _paths(ctx)[2] == before[2]
+    ctx.close()
