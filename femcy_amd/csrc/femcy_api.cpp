@@ -238,6 +238,10 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     Ctx* c = &ctx->c;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // every stream of the context is drained BEFORE the first buffer is freed (round-6 audit: the exchange stream was
+    // synchronised after the frees; its work is ordered behind events of the main stream, so nothing was in flight in
+    // practice, but a freed block may be handed to another context at once)
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     comm_destroy(c);
     pcg_graph_reset(c);
     direct_release(c);

@@ -20,6 +20,7 @@ import hashlib
 import json
 import os
 import sys
+import types
 
 import numpy as np
 
@@ -75,6 +76,7 @@ def main():
     for p in (os.path.join(REF, "element_zoo"), os.path.join(REF, "material_zoo"), os.path.join(REF, "reader"), REF):
         sys.path.insert(0, p)
     import inp_info as ref_reader
+    import body as ref_body
     out = {"source": "mo-hanxuan/FEMcy checkout at /root/reference, imported behind a decorator-only taichi stand-in",
            "decks": {}, "elements": {}, "materials": {}}
     for path in sorted(glob.glob(os.path.join(REF, "tests", "**", "*.inp"), recursive=True)):
@@ -93,6 +95,26 @@ def main():
              "materials": {k: {"class": type(m).__name__, "C": matrix_of(m).tolist()} for k, m in r.materials.items()},
              "geometric_nonlinear": bool(r.geometric_nonlinear),
              "time_incs": {k: float(v) for k, v in r.time_incs.items()}}
+        # Body.get_nodeEles / get_coElement_nodes / get_boundary (body.py:165-234): plain Python on the numpy arrays -- called
+        # unbound on a holder of np_nodes / np_elements / ELE (Body.__init__ only adds Taichi fields for the GGUI).  The
+        # reference lists every set in CPython's set-iteration order; recorded sorted (membership is the data) and, for the
+        # adjacency, also in the reference's own order (the column order of its sparseIJ, stiffnessMtrx.py:78-89)
+        el = list(r.eSets.values())[0]
+        holder = types.SimpleNamespace(np_nodes=np.asarray(r.nodes), np_elements=np.asarray(el), ELE=r.ELE)
+        holder.get_nodeEles = lambda redo=False, h=holder: ref_body.Body.get_nodeEles(h, redo)
+        node_eles = ref_body.Body.get_nodeEles(holder)
+        co_nodes = ref_body.Body.get_coElement_nodes(holder)
+        boundary = ref_body.Body.get_boundary(holder)
+        cnt_e = np.array([len(x) for x in node_eles], dtype=np.int64)
+        cnt_c = np.array([len(x) for x in co_nodes], dtype=np.int64)
+        d["topology"] = {
+            "nodeEles_counts_sha": sha(cnt_e, np.int64), "coElement_counts_sha": sha(cnt_c, np.int64),
+            "nnzb": int(cnt_c.sum()), "max_row_blocks": int(cnt_c.max()), "max_node_elems": int(cnt_e.max()),
+            "nodeEles_sorted_sha": sha(np.concatenate([np.sort(np.asarray(x, dtype=np.int64)) for x in node_eles]), np.int64),
+            "coElement_sorted_sha": sha(np.concatenate([np.sort(np.asarray(x, dtype=np.int64)) for x in co_nodes]), np.int64),
+            "coElement_reference_order_sha": sha(np.concatenate([np.asarray(x, dtype=np.int64) for x in co_nodes]), np.int64),
+            "boundary_facets": len(boundary),
+            "boundary_sha": sha(np.array(sorted([list(k) + [int(v)] for k, v in boundary.items()]), dtype=np.int64), np.int64)}
         out["decks"][os.path.relpath(path, os.path.join(REF, "tests"))] = d
     for etype, mod, cls in FAMILIES:
         e = getattr(__import__(mod), cls)()

@@ -133,3 +133,46 @@ def test_material_matrices_are_the_reference_classes_matrices(name):
     C = np.array(want["C"])
     assert np.array_equal(np.asarray(cls(*want["params"]).C, dtype=float), C)
     assert np.array_equal(np.asarray(orc.Material(kind, tuple(want["params"])).C, dtype=float), C)
+
+
+@pytest.mark.parametrize("ref_path", sorted(REF["decks"]))
+def test_topology_is_what_the_reference_body_computes(ref_path):
+    """Body.get_nodeEles / get_coElement_nodes / get_boundary (body.py:165-234) on every deck: the oracle's Topology (node
+    adjacency = the block pattern of K, nodeEles, boundary facets) and the product's Body hold exactly the reference's
+    sets; the sizes the device pattern is checked against in test_assemble_K (nnzb, longest row, widest nodeEles row) are
+    the reference's.  The reference lists a set in CPython's iteration order of a set of numpy integers; for these decks
+    that order is recorded too, and the C restatement's `sparseIJ` can be built in it (test_oracle_c.py)."""
+    from femcy_amd.body import Body
+    want = REF["decks"][ref_path]["topology"]
+    inp = InpInfo(os.path.join(DECKS, DECK_OF[ref_path]))
+    el = list(inp.eSets.values())[0]
+    topo = orc.Topology(inp.nodes, el, elem_def(list(inp.eSets.keys())[0]))
+    cnt_c = np.diff(topo.adj_ptr)
+    cnt_e = np.diff(topo.nodeEles_ptr)
+    assert sha(cnt_c, np.int64) == want["coElement_counts_sha"] and sha(cnt_e, np.int64) == want["nodeEles_counts_sha"]
+    assert (int(cnt_c.sum()), int(cnt_c.max()), int(cnt_e.max())) == (want["nnzb"], want["max_row_blocks"], want["max_node_elems"])
+    assert sha(topo.adj_idx, np.int64) == want["coElement_sorted_sha"]            # CSR indices are sorted per row
+    ne = np.concatenate([np.sort(topo.nodeEles_idx[topo.nodeEles_ptr[a]:topo.nodeEles_ptr[a + 1]]) for a in range(topo.nn)])
+    assert sha(ne, np.int64) == want["nodeEles_sorted_sha"]
+    b = topo.boundary()
+    assert len(b) == want["boundary_facets"]
+    assert sha(np.array(sorted([list(k) + [int(v)] for k, v in b.items()]), dtype=np.int64), np.int64) == want["boundary_sha"]
+    body = Body(nodes=inp.nodes, elements=el, ELE=inp.ELE)
+    assert sha(np.concatenate([np.asarray(x, dtype=np.int64) for x in body.get_coElement_nodes()]), np.int64) == want["coElement_sorted_sha"]
+    assert sha(np.concatenate([np.asarray(x, dtype=np.int64) for x in body.get_nodeEles()]), np.int64) == want["nodeEles_sorted_sha"]
+    pb = body.get_boundary()
+    assert sha(np.array(sorted([list(k) + [int(v)] for k, v in pb.items()]), dtype=np.int64), np.int64) == want["boundary_sha"]
+
+
+@pytest.mark.parametrize("ref_path", sorted(REF["decks"]))
+def test_set_order_emulation_is_the_reference_column_order(ref_path):
+    """tests/test_oracle_c.py builds the as-written C restatement's sparseIJ "in the order the reference's Python sets
+    produce" by re-running body.py:165-194's set logic (_reference_adjacency): held here to the order the REFERENCE's own
+    get_coElement_nodes produced on every deck -- the README reproduction (93.56 / 93.32 / 84.40 at the reference's stop
+    iterate) runs on the reference's real column order, not on a guess at it."""
+    from test_oracle_c import _reference_adjacency
+    want = REF["decks"][ref_path]["topology"]
+    inp = InpInfo(os.path.join(DECKS, DECK_OF[ref_path]))
+    el = np.asarray(list(inp.eSets.values())[0])
+    ptr, idx = _reference_adjacency(el, inp.nodes.shape[0])
+    assert sha(idx, np.int64) == want["coElement_reference_order_sha"] and int(ptr[-1]) == want["nnzb"]
