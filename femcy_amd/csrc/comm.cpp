@@ -455,7 +455,7 @@ int comm_mailbox_export(Ctx* c, void* blob256) {
             FEMCY_HIP(dmalloc(&c->d_mbox, sizeof(unsigned long long) * words));
         }
         c->mbox_words = words;
-        FEMCY_HIP(hipMemset(c->d_mbox, 0, sizeof(unsigned long long) * words));
+        FEMCY_HIP(dfill_sync(c->d_mbox, 0, sizeof(unsigned long long) * words));
     }
     MboxBlob b;
     std::memset(&b, 0, sizeof(b));

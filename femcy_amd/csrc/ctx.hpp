@@ -27,18 +27,18 @@ void set_error(const char* fmt, ...);
 // freed blocks back -- then fails deterministically: the race / uninitialised-read check of the -m gpu suite
 // (tools/records/r05_gpu2.sh).  In that mode a fill that cannot be issued or completed is an allocation failure, not a
 // silently unpoisoned buffer.
-inline hipError_t dmalloc(void** p, size_t bytes) {
-    static const bool poison = [] {
-        const char* e = getenv("FEMCY_DEBUG_POISON");
-        return e && e[0] && e[0] != '0';
-    }();
-    const hipError_t rc = hipMalloc(p, bytes);
-    if (rc != hipSuccess || !poison || !bytes) return rc;
-    // the fill must have LANDED before the caller's first copy into the new buffer (on the null stream it could land
-    // after it: index arrays of -1 and a memory fault that was the checker's own), and it must not wait for other
-    // streams (a device-wide synchronisation deadlocks against the co-dependent persistent kernels of several ranks
-    // in one process until their spin limit): a non-blocking stream of its own ON THE DEVICE OF THE ALLOCATION (several
-    // ranks of one process hold one device each), synchronised here
+// A fill of device memory that HAS LANDED when the call returns.  hipMemset on the null stream is asynchronous for device
+// memory and the context streams are non-blocking (they do not order behind the null stream): a zero-fill issued by
+// femcy_build_pattern could still be running when the first assembly kernel of the context stream wrote the same
+// buffer, and zeroed what the kernel had just written -- the "NaN after 1 iteration" of round 5 (a K with 160 empty rows ->
+// 1 / 0 in the Jacobi vector), reproduced and bisected in round 6 (profiles/r06_nan_hunt.txt).  The fill runs on a
+// non-blocking stream of its own ON THE DEVICE OF THE ALLOCATION (several ranks of one process hold one device each; a
+// device-wide synchronisation would deadlock against their co-dependent persistent kernels) and is synchronised here.
+inline hipError_t dfill_sync(void* p, int value, size_t bytes) {
+    if (!bytes) return hipSuccess;
+#ifdef FEMCY_TEST_LATE_FILL     /* the behaviour before the fix, for tests/test_gpu_regressions.py to be shown failing on */
+    return hipMemset(p, value, bytes);
+#endif
     constexpr int MAXDEV = 64;
     static hipStream_t fill_stream[MAXDEV] = {};
     static std::mutex mu;
@@ -51,8 +51,21 @@ inline hipError_t dmalloc(void** p, size_t bytes) {
         if (!fill_stream[dev]) e = hipStreamCreateWithFlags(&fill_stream[dev], hipStreamNonBlocking);
         st = fill_stream[dev];
     }
-    if (e == hipSuccess) e = hipMemsetAsync(*p, 0xFF, bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p, value, bytes, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e;
+}
+
+inline hipError_t dmalloc(void** p, size_t bytes) {
+    static const bool poison = [] {
+        const char* e = getenv("FEMCY_DEBUG_POISON");
+        return e && e[0] && e[0] != '0';
+    }();
+    const hipError_t rc = hipMalloc(p, bytes);
+    if (rc != hipSuccess || !poison || !bytes) return rc;
+    // (the fill must have LANDED before the caller's first copy into the new buffer: index arrays of -1 and a memory fault
+    // that was the checker's own)
+    const hipError_t e = dfill_sync(*p, 0xFF, bytes);
     if (e != hipSuccess) {
         (void)hipFree(*p);
         *p = nullptr;

@@ -32,7 +32,7 @@ static int dev_alloc(T** p, size_t count, bool zero = true) {
         set_error("dmalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return FEMCY_ENOMEM;
     }
-    if (zero) FEMCY_HIP(hipMemset(*p, 0, bytes));
+    if (zero) FEMCY_HIP(dfill_sync(*p, 0, bytes));       // landed on return: ctx.hpp
     return FEMCY_OK;
 }
 

@@ -1802,6 +1802,25 @@ int pcg_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_t maxit,
     c->timing.pcg_iters += c->h_state->iters;
     c->timing.solves_three++;
     if (c->h_state->done == 2) {
+        if (getenv("FEMCY_DEBUG_DUMP_BREAKDOWN")) {              // where did the first non-finite entry appear?
+            const int64_t nd = pos ? (int64_t)npos * c->dm : c->n;
+            std::vector<double> h((size_t)nd);
+            const struct { const char* name; const double* p; } vecs[] = {{"b", vb}, {"M", c->d_M}, {"r", c->d_r}, {"d", c->d_d}, {"Ad", c->d_Ad}, {"x", vx}};
+            for (const auto& v : vecs) {
+                (void)hipMemcpy(h.data(), v.p, sizeof(double) * nd, hipMemcpyDeviceToHost);
+                int64_t bad = 0, first = -1, zeros = 0;
+                for (int64_t i = 0; i < nd; ++i) {
+                    if (!std::isfinite(h[i])) { if (first < 0) first = i; ++bad; }
+                    if (h[i] == 0.0) ++zeros;
+                }
+                fprintf(stderr, "[femcy debug] %s: %lld of %lld non-finite (first at %lld = slice %lld lane %lld comp %lld), %lld zeros\n", v.name,
+                        (long long)bad, (long long)nd, (long long)first, (long long)(first / (64 * c->dm)), (long long)(first / c->dm % 64),
+                        (long long)(first % c->dm), (long long)zeros);
+            }
+            fprintf(stderr, "[femcy debug] state: iters %d r0 %g rmax %g dAd %g alpha %g rMr %g %g; pos %d npos %d n %lld g %d\n", c->h_state->iters,
+                    c->h_state->r0, c->h_state->rmax, c->h_state->dAd, c->h_state->alpha, c->h_state->rMr[0], c->h_state->rMr[1], (int)pos, (int)npos,
+                    (long long)c->n, g);
+        }
         set_error("PCG breakdown: NaN/Inf residual after %d iterations (r0 = %g)", c->h_state->iters, c->h_state->r0);
         return FEMCY_ENUMERIC;
     }

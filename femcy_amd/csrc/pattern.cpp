@@ -588,7 +588,7 @@ int build_pattern(Ctx* c) {
     if (c->d_Kvals) (void)hipFree(c->d_Kvals);
     size_t kbytes = (size_t)stored_rows * dm * dm * SLICE * sizeof(double);
     FEMCY_HIP(dmalloc(&c->d_Kvals, std::max<size_t>(kbytes, 8)));
-    FEMCY_HIP(hipMemset(c->d_Kvals, 0, kbytes));
+    FEMCY_HIP(dfill_sync(c->d_Kvals, 0, kbytes));       // landed on return (ctx.hpp: the round-5 NaN was this fill running late)
     return FEMCY_OK;
 }
 
