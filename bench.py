@@ -157,7 +157,7 @@ def pmc_traffic(workload, kernel, layout=None):
 
 def layout_signature(info):
     """what the host decides about the matrix the kernels stream (femcy_get_pattern_info)"""
-    return {"n": int(info.n), "nnzb": int(info.nnzb), "stored_blocks": int(info.stored_blocks), "nslices": int(info.nslices)}
+    return {k: int(getattr(info, k)) for k in ("n", "nnzb", "stored_blocks", "nslices") if hasattr(info, k)}
 
 
 def hbm_copy_probe(torch):
