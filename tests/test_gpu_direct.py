@@ -336,7 +336,8 @@ def test_tile_update_on_the_matrix_cores_equals_the_valu_product(gpu_ctx_factory
         for var in (0, 1, 2, 3):
             assert np.abs(K @ xs[var] - b).max() <= 1e-8 * np.abs(b).max()
             assert np.linalg.norm(xs[var] - xs[0]) <= 1e-9 * np.linalg.norm(xs[0])
-    ctx.close() if not name else None
+    if not name:                             # (a context of gpu_ctx_factory is closed by the fixture)
+        ctx.close()
 
 
 def ctx_nodes(ctx, name, cube):
