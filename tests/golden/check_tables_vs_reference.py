@@ -77,6 +77,7 @@ def _taichi_stub():
     ti.Vector, ti.Matrix = _VM, _VM
     ti.types = types.SimpleNamespace(vector=lambda *a, **k: None, matrix=lambda *a, **k: None)
     ti.ui = types.SimpleNamespace(Window=object, Camera=object, Scene=object, LMB=0)      # names in type annotations of body.py
+    ti.GUI = object                                                                       # ... and of stiffnessMtrx.py
     return ti
 
 

@@ -7,7 +7,8 @@ What of the reference runs without Taichi: everything that is plain Python / num
 classes' elastic matrices (material_zoo/*.py).  They are imported behind the decorator-only `taichi` stand-in of
 check_tables_vs_reference.py (decorators = identity, fields = numpy holders; no Taichi kernel is executed or emulated).
 
-Recorded per deck of /root/reference/tests (47 decks): node / element arrays as shape + sha256 of their bytes, every node
+Also `System_of_equations.neumannBC` (stiffnessMtrx.py:369-411), which is a plain Python loop in the reference: its consistent
+load vector of every *Dsload.  Recorded per deck of /root/reference/tests (47 decks): node / element arrays as shape + sha256 of their bytes, every node
 / element / face set, the boundary-condition lists, material class + parameters + C, nlgeom flag, time increments.
 Recorded per element family: Gauss points, weights, N and dN at the Gauss points and at fixed sample points, the facet
 tables.  tests/test_reference_produced.py holds the product reader, the product element / material plug-ins and the
@@ -73,10 +74,12 @@ def matrix_of(m):
 
 def main():
     sys.modules["taichi"] = chk._taichi_stub()
-    for p in (os.path.join(REF, "element_zoo"), os.path.join(REF, "material_zoo"), os.path.join(REF, "reader"), REF):
+    for p in (os.path.join(REF, "element_zoo"), os.path.join(REF, "material_zoo"), os.path.join(REF, "reader"),
+              os.path.join(REF, "user_defined"), REF):
         sys.path.insert(0, p)
     import inp_info as ref_reader
     import body as ref_body
+    import stiffnessMtrx as ref_sys
     out = {"source": "mo-hanxuan/FEMcy checkout at /root/reference, imported behind a decorator-only taichi stand-in",
            "decks": {}, "elements": {}, "materials": {}}
     for path in sorted(glob.glob(os.path.join(REF, "tests", "**", "*.inp"), recursive=True)):
@@ -115,6 +118,20 @@ def main():
             "coElement_reference_order_sha": sha(np.concatenate([np.asarray(x, dtype=np.int64) for x in co_nodes]), np.int64),
             "boundary_facets": len(boundary),
             "boundary_sha": sha(np.array(sorted([list(k) + [int(v)] for k, v in boundary.items()]), dtype=np.int64), np.int64)}
+        # System_of_equations.neumannBC (stiffnessMtrx.py:369-411: plain Python over the loaded facets, ELE.globalNormal and
+        # shapeFunc_pyscope) called unbound on a holder of body / ELE / rhs / dm: the reference's own consistent load vector
+        # of every *Dsload of the deck -- the loaded entries (index, value) and the resultant
+        if r.neumann_bc_info:
+            holder.boundary = boundary
+            holder.get_boundary = lambda redo=False, h=holder: h.boundary
+            d["neumann_rhs"] = []
+            for nb in r.neumann_bc_info:
+                rhs = np.zeros(np.asarray(r.nodes).size)
+                sysh = types.SimpleNamespace(body=holder, ELE=r.ELE, rhs=rhs, dm=int(np.asarray(r.nodes).shape[1]))
+                ref_sys.System_of_equations.neumannBC(sysh, nb["face_set"], nb["traction"], nb.get("direction", np.array([])))
+                nz = np.nonzero(rhs)[0]
+                d["neumann_rhs"].append({"idx": [int(i) for i in nz], "val": [float(v) for v in rhs[nz]],
+                                         "resultant": [float(v) for v in rhs.reshape(-1, sysh.dm).sum(axis=0)]})
         out["decks"][os.path.relpath(path, os.path.join(REF, "tests"))] = d
     for etype, mod, cls in FAMILIES:
         e = getattr(__import__(mod), cls)()

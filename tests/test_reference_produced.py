@@ -176,3 +176,52 @@ def test_set_order_emulation_is_the_reference_column_order(ref_path):
     el = np.asarray(list(inp.eSets.values())[0])
     ptr, idx = _reference_adjacency(el, inp.nodes.shape[0])
     assert sha(idx, np.int64) == want["coElement_reference_order_sha"] and int(ptr[-1]) == want["nnzb"]
+
+
+NEUMANN_DECKS = sorted(k for k, v in REF["decks"].items() if "neumann_rhs" in v)
+
+
+def _reference_rhs(want, n):
+    out = np.zeros(n)
+    out[np.array(want["idx"], dtype=np.int64)] = np.array(want["val"])
+    return out
+
+
+@pytest.mark.parametrize("ref_path", NEUMANN_DECKS)
+def test_consistent_loads_are_what_the_reference_neumannBC_computes(ref_path):
+    """System_of_equations.neumannBC (stiffnessMtrx.py:369-411) is a plain Python loop in the reference; its load vector of
+    every *Dsload of every deck (35 decks: pressures and TRVEC tractions on 2-node edges, half-edges of the quadratic 2-D
+    families, 3- and 6-node triangles) was produced by the reference itself.  The oracle's restatement against it --
+    entry for entry, 1e-14 of the largest load (the order of the += differs) -- on the product reader's face sets."""
+    assert len(NEUMANN_DECKS) == 35
+    wants = REF["decks"][ref_path]["neumann_rhs"]
+    inp = InpInfo(os.path.join(DECKS, DECK_OF[ref_path]))
+    et = list(inp.eSets.keys())[0]
+    topo = orc.Topology(inp.nodes, np.asarray(inp.eSets[et]), elem_def(et))
+    assert len(wants) == len(inp.neumann_bc_info)
+    for nb, want in zip(inp.neumann_bc_info, wants):
+        ref = _reference_rhs(want, topo.n)
+        got = orc.neumann_rhs(topo, sorted(nb["face_set"]), nb["traction"], nb.get("direction"))
+        assert np.abs(got - ref).max() <= 1e-14 * np.abs(ref).max()
+        assert np.allclose(got.reshape(-1, topo.dm).sum(axis=0), want["resultant"], rtol=0, atol=1e-12 * np.abs(ref).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ref_path", NEUMANN_DECKS)
+def test_device_loads_are_what_the_reference_neumannBC_computes(ref_path):
+    """the same vectors against femcy_loadset_neumann on the device, through the product driver's own facet -> (element,
+    facet type) resolution (row a8 of the scope table on a reference-produced vector)"""
+    from femcy_amd.body import Body
+    from femcy_amd.stiffnessMtrx import System_of_equations
+    wants = REF["decks"][ref_path]["neumann_rhs"]
+    inp = InpInfo(os.path.join(DECKS, DECK_OF[ref_path]))
+    el = list(inp.eSets.values())[0]
+    system = System_of_equations(Body(inp.nodes, el, inp.ELE), list(inp.materials.values())[0], inp.geometric_nonlinear, verbose=False)
+    try:
+        for nb, want in zip(inp.neumann_bc_info, wants):
+            system.neumannBC(nb["face_set"], load_val=nb["traction"], load_dir=nb.get("direction", np.array([])))
+            got = system.rhs.to_numpy()
+            ref = _reference_rhs(want, got.size)
+            assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    finally:
+        system.ctx.close()
