@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
 #define FEMCY_INB_PREFETCH 1
 #endif
     // (seven slices of 3 x 3 blocks per wave: 210 registers of vectors -- no prefetch buffer, its 76 registers are what
-    // the shape does not have; with it hipcc 7.0 produced a kernel whose first iterate was wrong, round 6)
+    // the shape does not have)
     constexpr bool PREFETCH = !(DM == 3 && SPW >= 7);
     const int npf = (!PREFETCH || (a.dbg & 16) || (A2A && wave == 0) || (INB && !FEMCY_INB_PREFETCH)) ? 0 : max(0, min(CH, Ls[0] - JE(0)));
     int32_t pcol[CH];
@@ -487,14 +487,21 @@ __global__ void __launch_bounds__(PBS) k_pcg_persist(PersistPcg a) {
         for (int c = 0; c < DM; ++c) {
             const bool in = node[t] >= 0;
             const int64_t i = in ? (int64_t)node[t] * DM + c : 0;
-            const double bi = in ? a.b[i] : 0.0, mi = in ? a.M[i] : 0.0;
+            // UNCONDITIONAL loads + selects (a padding lane reads entry 0): as `in ? a.b[i] : 0.0` each load sat in its own
+            // exec-masked region, and in the 6- / 7-slice shapes of 3 x 3 blocks hipcc 7.0 placed register copies of
+            // long-lived values (VGPR -> accumulation register) at the join of such a region BEFORE exec was restored --
+            // the padding lanes of those registers kept garbage and the final store of x went through it
+            // (profiles/r06_persist_spw67_fault.txt: a memory fault, or wrong iterates; -O1 was correct)
+            const double bl = a.b[i], ml = a.M[i];
+            const double bi = in ? bl : 0.0, mi = in ? ml : 0.0;
             xo[t][c] = 0.0;
             rr[t][c] = bi;
             mm[t][c] = mi;
             dd[t][c] = mi * bi;
             Ad[t][c] = 0.0;
             // across ranks a shared DOF is counted by its owner only; max|r| is the same on every replica
-            const bool mine = !MULTI || (in && a.owner[i] != 0);
+            const uint8_t own = MULTI ? a.owner[i] : (uint8_t)1;  // unconditional as well (see above)
+            const bool mine = !MULTI || (in && own != 0);
             if (mine) ownbits |= 1u << (t * DM + c);
             if (mine) accs += bi * mi * bi;
             accm = fmax(accm, pabs(bi));
@@ -1184,7 +1191,7 @@ int64_t persist_streamed_bytes(Ctx* c);
 
 // the launch shape of the persistent kernel for this pattern: slices per wave (SPW: the kernel's register arrays),
 // block rows per slice in registers (RJ) and per wave in LDS.  3 x 3 blocks: SPW 3 (RJ 4 / 5) or 4 (RJ 3) -- up to
-// 4 096 slices = 786 k DOF -- and, round 6, 5 (RJ 1) and 6 (RJ 0): up to 6 144 slices = 1.18 M DOF; 2 x 2 blocks (round 5): additionally SPW 6 (RJ 3) and 8 (RJ 2) -- a lane's vectors take
+// 4 096 slices = 786 k DOF -- and, round 6, 5 / 6 (RJ 1) and 7 (RJ 0): up to 7 168 slices = 1.37 M DOF; 2 x 2 blocks (round 5): additionally SPW 6 (RJ 3) and 8 (RJ 2) -- a lane's vectors take
 // 20 registers per slice instead of 30, a block row 9 instead of 19 -- up to 8 192 slices = 1.05 M DOF in 2-D
 // (BASELINE configs[1] at the size of the 3-D headline system).  false = the pattern does not fit.
 struct PersistShape { int G, nwx, SPW, rj, lds_rows; int32_t maxrange; };
@@ -1198,13 +1205,10 @@ bool persist_shape(const Ctx* c, PersistShape* out) {
     const int per_wave = (sh.maxrange + sh.nwx - 1) / sh.nwx;
     const bool on = c->opt_persist_rj != 0;
     if (c->dm == 3) {
-        // (7 slices per wave -- 1.37 M DOF, the C3D10 plate at k = 8 -- is written and compiles without spills, but its
-        // kernel faults or returns a wrong first iterate under hipcc 7.0 with and without the prefetch buffer
-        // (profiles/r06_persist_spw67_fault.txt): not admitted; FEMCY_DEBUG_FORCE_SPW reaches it for whoever debugs it)
-        if (per_wave > 6) return false;
+        if (per_wave > 7) return false;
         sh.SPW = per_wave > 3 ? per_wave : 3;
         if (const char* e = getenv("FEMCY_DEBUG_FORCE_SPW")) sh.SPW = std::min(7, std::max(sh.SPW, atoi(e)));
-        sh.rj = sh.SPW == 3 ? c->opt_persist_rj : (!on ? 0 : (sh.SPW == 4 ? 3 : (sh.SPW >= 6 ? 0 : 1)));
+        sh.rj = sh.SPW == 3 ? c->opt_persist_rj : (!on ? 0 : (sh.SPW == 4 ? 3 : (sh.SPW == 7 ? 0 : 1)));
     } else {
         if (per_wave > 8) return false;
         sh.SPW = per_wave > 6 ? 8 : (per_wave > 4 ? 6 : (per_wave > 3 ? 4 : 3));
@@ -1399,16 +1403,16 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
         } else if (c->dm == 3 && SPW == 4) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(3, 4, 3) } else { FEMCY_PERSIST_V(3, 4, 0) }
         } else if (c->dm == 3) {
-            // round 6: 5 and 6 slices per wave for 3 x 3 blocks (up to 6 144 slices = 1.18 M DOF keep one launch per solve).
-            // A lane's five vectors take 30 registers per slice: 150 / 180 of the 512, so one block row per slice (19
-            // registers) at five slices and none at six is all that stays in registers; default variant only.  Every
-            // shape is held to the three-launch loop's iterates by tests/test_gpu_pcg_persist.py -- <3,6,1> compiled to a
-            // kernel that kept node[t] in an accumulation register it also gave to a double (debug-agent dump in
-            // profiles/r06_persist_spw67_fault.txt) and is NOT used
+            // round 6: 5 .. 7 slices per wave for 3 x 3 blocks (up to 7 168 slices = 1.37 M DOF: the C3D10 plate at k = 8 keeps
+            // one launch per solve).  A lane's five vectors take 30 registers per slice: 150 .. 210 of the 512, so one block
+            // row per slice (19 registers) at five / six slices and none at seven is all that stays in registers; default
+            // variant only.  Every shape is held to the three-launch loop's iterates by tests/test_gpu_pcg_persist.py, and
+            // tools/check_exec_joins.py (a CPU test) guards the compiled code against the miscompile these shapes first
+            // ran into (the comment at the initial loads of b and M)
             FEMCY_REQUIRE((var & 15) == FEMCY_PERSIST_DEFAULT_VARIANT, "5 .. 7 slices per wave exist for the default variant of the persistent PCG only");
-            // (registers, hipcc 7.0: <3,5,1> / <3,6,1> 486 without spills, <3,5,2> and <3,7,1> spill 12 / 32, <3,7,0> 419)
+            // (registers, hipcc 7.0: <3,5,1> / <3,6,1> up to 486 without spills, <3,5,2> and <3,7,1> spill 12 / 32, <3,7,0> 384)
             if (SPW == 5) { if (c->opt_persist_rj) FEMCY_PERSIST(3, 5, 1, FEMCY_PERSIST_DEFAULT_VARIANT); else FEMCY_PERSIST(3, 5, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
-            else if (SPW == 6) { FEMCY_PERSIST(3, 6, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
+            else if (SPW == 6) { if (c->opt_persist_rj) FEMCY_PERSIST(3, 6, 1, FEMCY_PERSIST_DEFAULT_VARIANT); else FEMCY_PERSIST(3, 6, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
             else { FEMCY_PERSIST(3, 7, 0, FEMCY_PERSIST_DEFAULT_VARIANT); }
         } else if (SPW == 3) {
             if (c->opt_persist_rj) { FEMCY_PERSIST_V(2, 3, 5) } else { FEMCY_PERSIST_V(2, 3, 0) }

@@ -442,12 +442,13 @@ def test_probe_spmv_times_the_product_in_both_orders(plate):
     ctx.set_option(be.OPT_PCG_PERSIST, 1)
 
 
-@pytest.mark.parametrize("cells,spw", [((56, 7, 84), 5), ((60, 8, 90), 6)])
-def test_persistent_pcg_five_and_six_slices_per_wave(gpu_ctx_factory, cells, spw):
-    """round 6: 3 x 3 blocks with 5 and 6 slices per wave (one block row per slice in registers at 5, none at 6) -- C3D10
-    plates of 0.86 / 1.12 M DOF (k = 7, 7.5: matrices of 0.6 / 0.8 GB streamed from HBM every iteration) keep ONE launch
-    per solve.  Iterates against the three-launch loop at fixed counts (this is the test that rejected the shapes hipcc
-    miscompiled: <3,6,1>, <3,7,*>); the default path must be the faster one."""
+@pytest.mark.parametrize("cells,spw", [((56, 7, 84), 5), ((60, 8, 90), 6), ((64, 8, 96), 7)])
+def test_persistent_pcg_five_to_seven_slices_per_wave(gpu_ctx_factory, cells, spw):
+    """round 6: 3 x 3 blocks with 5, 6 and 7 slices per wave (one block row per slice in registers, none at 7) -- C3D10
+    plates of 0.86 / 1.12 / 1.27 M DOF (k = 7, 7.5, 8: matrices of 0.6 ... 0.9 GB streamed from HBM every iteration) keep ONE
+    launch per solve.  Iterates against the three-launch loop at fixed counts (this is the test that caught the 6- and
+    7-slice shapes hipcc 7.0 first miscompiled: register copies placed before the exec restore at the join of a masked
+    load, tools/check_exec_joins.py); the default path must be the faster one."""
     import time
     from femcy_amd import meshgen
     from femcy_amd.element_zoo import Element_quadratic_tetrahedral
@@ -482,13 +483,13 @@ def test_persistent_pcg_five_and_six_slices_per_wave(gpu_ctx_factory, cells, spw
     ctx.close()
 
 
-def test_beyond_six_slices_per_wave_takes_three_launches(gpu_ctx_factory):
-    """the C3D10 plate at k = 8 (1.27 M DOF, 6 614 slices = 7 per wave) is beyond the admitted shapes of the persistent
-    kernel: femcy_pcg must take the three-launch loop there by itself (and say so in femcy_timing)"""
+def test_beyond_seven_slices_per_wave_takes_three_launches(gpu_ctx_factory):
+    """a C3D10 plate of 1.6 M DOF (8 slices per wave) is beyond the admitted shapes of the persistent kernel: femcy_pcg
+    must take the three-launch loop there by itself (and say so in femcy_timing)"""
     from femcy_amd import meshgen
     from femcy_amd.element_zoo import Element_quadratic_tetrahedral
-    be, ctx, info, b = _system(gpu_ctx_factory, meshgen.twist_plate(64, 8, 96, quadratic=True), Element_quadratic_tetrahedral())
-    assert 6144 < info.nslices <= 7168
+    be, ctx, info, b = _system(gpu_ctx_factory, meshgen.twist_plate(70, 9, 100, quadratic=True), Element_quadratic_tetrahedral())
+    assert 7168 < info.nslices
     before = _paths(ctx)
     (it, r0, rm), x = _solve(ctx, be, 0.0, 5)
     assert it == 5 and np.isfinite(x).all() and _paths(ctx)[0] - before[0] == 1 and _paths(ctx)[2] == before[2]

@@ -310,3 +310,34 @@ def test_traffic_fingerprint_is_the_kernels_machine_code(tmp_path):
         assert (bad is None and "layout" in why) or doc["workloads"]["c3d4"].get("layout") is None
     else:
         assert val is None and "stale" in src
+
+
+def test_compiled_kernels_restore_exec_before_lane_wise_code(tmp_path):
+    """guard against a hipcc 7.0 miscompile met in round 6 (k_pcg_persist with 6 / 7 slices of 3 x 3 blocks per wave;
+    profiles/r06_persist_spw67_fault.txt): at the join of an exec-masked region the register allocator's copies of
+    long-lived values into accumulation registers were placed BEFORE `s_or_b64 exec, exec, sX` -- lanes outside the mask kept
+    garbage that was used under full exec much later (a memory fault in the final store of x, or wrong iterates; also, silent
+    until then, in the non-default variant <3,4,0,14>).  The source was changed so that the pattern does not arise (masked
+    loads -> unconditional loads + selects); this test compiles every HIP translation unit to assembly and checks EVERY
+    kernel for lane-wise instructions between such a join and its exec restore (tools/check_exec_joins.py)."""
+    import shutil
+    import sys
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_exec_joins as cej
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "femcy_amd", "csrc")
+    units = ["kernels_pcg_persist", "kernels_pcg", "kernels_assembly", "kernels_direct"]
+    procs = [subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-S",
+                               "--cuda-device-only", os.path.join(src, u + ".hip"), "-o", str(tmp_path / (u + ".s"))],
+                              stderr=subprocess.DEVNULL) for u in units]
+    assert all(p.wait() == 0 for p in procs)
+    nk = 0
+    for u in units:
+        for name, lines in cej.kernels((tmp_path / (u + ".s")).read_text()):
+            nk += 1
+            bad = cej.check(lines)
+            assert not bad, (u, name[:100], bad[:2])
+    assert nk > 150                                              # every kernel instantiation of the library was looked at
