@@ -161,3 +161,32 @@ def test_hbm_bound_records_of_the_default_line_have_the_2d_configuration():
     assert rec["spmv"]["bytes_per_launch"] > 0 and rec["pcg_iteration"]["bytes"] == rec["spmv"]["bytes_per_launch"] + 88 * rec["dof"]
     assert rec["stored_matrix_mb"] > 0 and rec["pcg_iteration"]["three_launch_us"] > 0
     json.dumps(rec)
+
+
+def test_committed_pmc_traffic_belongs_to_the_shipped_kernels_and_layout():
+    """`roofline.traffic` of the driver's line (verdict of round 5: it came out null because the record was fingerprinted
+    by whole source files).  The committed profiles/spmv_traffic.json must be the record of THIS library's PCG kernels
+    (machine-code fingerprint) and of the layout `femcy_build_pattern` produces for the headline mesh today -- i.e.
+    `bench.py` on the standard workloads will carry a non-null `traffic` with `traffic_over_moved` close to 1."""
+    import json
+    import bench
+    from femcy_amd import backend as be, meshgen
+    from femcy_amd.element_zoo import Element_linear_tetrahedral
+    from femcy_amd.material_zoo import LinearIsotropic
+    doc = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
+    assert doc["kernel_object_sha"] == bench.kernel_object_sha()
+    assert set(doc["workloads"]) >= {"c3d4", "c3d10", "cpe8"}
+    m = meshgen.twist_plate_k(12)
+    ctx = be.Context(0)
+    try:
+        ctx.set_mesh(m["nodes"], m["elements"])
+        ctx.set_element(Element_linear_tetrahedral())
+        ctx.set_material(LinearIsotropic(*m["elastic"]))
+        layout = bench.layout_signature(ctx.build_pattern())
+    finally:
+        ctx.close()
+    assert doc["workloads"]["c3d4"]["layout"] == layout
+    traffic, src = bench.pmc_traffic("c3d4", "k_pcg_persist", layout)
+    assert traffic is not None and "spmv_traffic.json" in src
+    # 1000 iterations per launch: the PMC bytes per iteration within 20 % of what the layout streams (111.8 MB + vectors)
+    assert 1.0e8 < traffic / 1000 < 1.4e8
