@@ -410,6 +410,7 @@ int probe_stream(Ctx* c, int64_t bytes, int32_t reps, int32_t mode, double* us_p
 int probe_exchange(Ctx* c, int32_t rounds, int32_t form, double* us_per_exchange);
 int probe_mailbox(Ctx* c, int32_t rounds, double* us_per_round);
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch);
+int spmv_public_storage_order(Ctx* c, const double* d_x, double* d_y);   // femcy_spmv through the storage-order kernel
 int64_t persist_streamed_bytes(Ctx* c);
 int ensure_pairs(Ctx* c, int rows_per_chunk, bool spatial_order, int chunks_per_wave);   // pattern.cpp: d_pr_unit / d_pr_ptr / d_pr_code for the current pattern
 int ensure_footprint(Ctx* c);   // pattern.cpp: d_lcol / d_fp_ptr / d_fp for the current pattern and spmv_wps

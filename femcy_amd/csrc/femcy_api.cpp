@@ -1008,6 +1008,9 @@ int femcy_spmv(femcy_ctx* ctx, int x_vec, int y_vec) {
     // (node-order product.  Round 5 tried the PCG's storage-order kernel between two permutations here: 78.0 -> 75.7 us
     // per call on the C3D10 plate, 281 -> 329 us on the 8 M C3D4 plate, whose numbering gathers as well as storage order
     // does -- not adopted; profiles/r05_bench_c3d4_n1_public_spmv_storage_order.json)
+    // round 6: ... except where the internal row order is a coordinate order of the library's choosing AND the vectors are
+    // large -- the caller's numbering then gathers badly (C3D10 at k = 12: 868 us per call against 561 for the kernel)
+    if (!c->comm && c->node_order_used != 0 && c->n >= 1500000) return spmv_public_storage_order(c, c->d_vec[x_vec], c->d_vec[y_vec]);
     int rc = launch_spmv(c, c->d_vec[x_vec], c->d_vec[y_vec], nullptr, nullptr);
     if (rc) return rc;
     if (c->comm) return iface_sum(c, c->d_vec[y_vec]);

@@ -1078,6 +1078,24 @@ int ensure_pos_vectors(Ctx* c) {
     return FEMCY_OK;
 }
 
+// the public product (femcy_spmv) through the storage-order kernel: permute x, multiply, permute back.  Pays when the
+// internal row order is NOT the caller's numbering (FEMCY_OPT_NODE_ORDER chose a coordinate order because the caller's
+// gathers badly: the C3D10 plates) and the vectors are large: 995 k C3D10 / 4.18 M DOF 868 -> ~620 us per call (round 6);
+// equal at 548 k DOF (79 us), a loss where the caller's numbering IS the internal order (8 M C3D4: 281 -> 329 us, round 5)
+int spmv_public_storage_order(Ctx* c, const double* d_x, double* d_y) {
+    int rc = ensure_pos_vectors(c);
+    if (rc) return rc;
+    const int32_t npos = c->nslices * SLICE;
+    const int pg = (npos + BS - 1) / BS;
+    if (c->dm == 3) hipLaunchKernelGGL((k_to_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
+    else hipLaunchKernelGGL((k_to_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, d_x, c->d_posb);
+    if ((rc = launch_spmv(c, c->d_posb, c->d_posx, nullptr, nullptr, true))) return rc;
+    if (c->dm == 3) hipLaunchKernelGGL((k_from_pos<3>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
+    else hipLaunchKernelGGL((k_from_pos<2>), dim3(pg), dim3(BS), 0, c->stream, npos, c->d_node_of, (const double*)c->d_posx, d_y);
+    FEMCY_HIP(hipGetLastError());
+    return FEMCY_OK;
+}
+
 int probe_spmv(Ctx* c, int32_t reps, int32_t storage_order, double* us_per_launch) {
     FEMCY_REQUIRE(c->have_pattern, "femcy_build_pattern must come first");
     FEMCY_REQUIRE(reps >= 1 && reps <= 100000 && us_per_launch, "probe_spmv: reps 1..1e5");
