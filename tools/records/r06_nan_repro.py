@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 import pytest
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); os.chdir(ROOT)
 pre = sys.argv[1] if len(sys.argv) > 1 else "tests/test_gpu_multirank.py::test_neighbour_exchange_equals_allreduce"
 if pre != "none":

@@ -1,7 +1,7 @@
 """FEMCY_DEBUG_FORCE_SPW=<n>: the persistent PCG of that shape against the three-launch loop on a small C3D10 plate"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from femcy_amd import backend as be, meshgen
 from femcy_amd.element_zoo import Element_quadratic_tetrahedral
 from femcy_amd.material_zoo import LinearIsotropic

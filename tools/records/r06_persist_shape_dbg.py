@@ -1,7 +1,7 @@
 """debug: the persistent PCG on a C3D10 plate of given cells, register rows on / off; prints path and time"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from femcy_amd import backend as be, meshgen
 from femcy_amd.element_zoo import Element_quadratic_tetrahedral
 from femcy_amd.material_zoo import LinearIsotropic
