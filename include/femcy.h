@@ -93,7 +93,7 @@ enum femcy_assembly {
                              (no read-for-fill of K: round 3) */
     FEMCY_ASM_ROWS4 = 8,  /* two rows per wavefront at a time (half a wave each, three incident elements per step, the
                              diagonal block computed like the others): round 3, C3D10; AUTO picks it there */
-    FEMCY_ASM_PAIRS = 9   /* round 6: a wavefront owns 16 adjacent rows of a slice; lanes = (row, incident element) pair x
+    FEMCY_ASM_PAIRS = 9   /* round 6: a wavefront owns 8 (or 16) adjacent rows of a slice; lanes = (row, incident element) pair x
                              column node, the element's whole record is read once per pair by coalesced 16-byte loads
                              (the row node's gradients come from the neighbouring lane), the geometric sums are reduced
                              in a wave-private LDS tile and the tile is written as 256-byte runs; any constant C.
