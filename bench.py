@@ -129,11 +129,31 @@ def kernel_object_sha(lib_path=None, patterns=TRAFFIC_KERNELS):
     return h.hexdigest()[:16]
 
 
+def kernel_symbol_fragment(demangled):
+    """'void femcy::(anonymous namespace)::k_pcg_persist<3, 3, 4, 6, false>(...)' -> '13k_pcg_persistILi3ELi3ELi4ELi6ELb0EE':
+    the piece of the Itanium-mangled symbol that names ONE instantiation (integer and bool template arguments)"""
+    import re
+    m = re.search(r"(k_\w+)<([^>]*)>", demangled)
+    if not m:
+        m2 = re.search(r"(k_\w+)", demangled)
+        return f"{len(m2.group(1))}{m2.group(1)}" if m2 else None
+    args = ""
+    for a in (x.strip() for x in m.group(2).split(",")):
+        if a in ("true", "false"):
+            args += "Lb%dE" % (a == "true")
+        elif re.fullmatch(r"-?\d+", a):
+            args += "Li%sE" % a.replace("-", "n")
+        else:
+            return None
+    return f"{len(m.group(1))}{m.group(1)}I{args}E"
+
+
 def pmc_traffic(workload, kernel, layout=None):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
     WRITE_SIZE, separate passes, MI355X_MICROARCH.md HBM section) -- refused (None + reason) when the machine code of
-    the PCG / SpMV kernels changed since, when the matrix layout of the workload (pattern sizes) is not the one the
-    passes saw, or when the passes were taken on a different kernel."""
+    the kernel INSTANTIATION the passes were taken on changed since (`kernel_sha` of the workload; records without one:
+    the fingerprint over all PCG / SpMV kernels), when the matrix layout of the workload (pattern sizes) is not the one
+    the passes saw, or when the passes were taken on a different kernel."""
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if not os.path.exists(tpath):
         return None, "no profiles/spmv_traffic.json"
@@ -142,12 +162,18 @@ def pmc_traffic(workload, kernel, layout=None):
         entry = doc.get("workloads", {}).get(workload)
         if entry is None:
             return None, f"no PMC pass recorded for workload {workload}"
-        sha = kernel_object_sha()
-        if doc.get("kernel_object_sha") != sha:
-            return None, (f"stale: PMC passes were taken on kernel code {doc.get('kernel_object_sha')}, "
-                          f"the library holds {sha}")
         if kernel not in entry.get("kernel", ""):
             return None, f"PMC passes of workload {workload} were taken on {entry.get('kernel', '?')[:60]}, not on {kernel}"
+        frag = kernel_symbol_fragment(entry.get("kernel", "")) if entry.get("kernel_sha") else None
+        if frag:
+            sha = kernel_object_sha(patterns=(frag,))
+            if entry["kernel_sha"] != sha:
+                return None, f"stale: PMC passes were taken on {frag} with code {entry['kernel_sha']}, the library holds {sha}"
+        else:
+            sha = kernel_object_sha()
+            if doc.get("kernel_object_sha") != sha:
+                return None, (f"stale: PMC passes were taken on kernel code {doc.get('kernel_object_sha')}, "
+                              f"the library holds {sha}")
         if layout is not None and entry.get("layout") is not None and entry["layout"] != layout:
             return None, f"stale: PMC passes saw the layout {entry['layout']}, this run has {layout}"
         return entry["hbm_bytes_per_launch"], f"profiles/spmv_traffic.json @ {doc.get('git_head', '?')}"

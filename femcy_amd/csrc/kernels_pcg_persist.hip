@@ -1225,8 +1225,9 @@ bool persist_shape(const Ctx* c, PersistShape* out) {
 bool persist_pattern_fits(Ctx* c) {
     if (!c->opt_persist || !c->have_pattern) return false;
     PersistShape sh;
-    if (!persist_shape(c, &sh) || c->dm != 3 || sh.SPW > 4) return false;   // (the multi-rank kernel is instantiated for 3 x 3 blocks,
-                                                                  // three or four slices per wave)
+    // (the multi-rank kernel is instantiated for 3 x 3 blocks with three or four slices per wave and -- round 6 -- for every
+    // 2 x 2 shape)
+    if (!persist_shape(c, &sh) || (c->dm == 3 && sh.SPW > 4)) return false;
     const int G = sh.G;
     if (c->opt_persist >= 2) return true;
     // evaluated here once so that every rank applies the same verdict.  The single-rank rule "the chip is filled 1.5 times over" (below ~380 slices three launches are
@@ -1387,8 +1388,14 @@ int pcg_persist_solve(Ctx* c, const double* d_b, double* d_x, double eps, int32_
             // across ranks: the default variant, 3 x 3 blocks (the agreement checked dm == 3); register rows as in the
             // single-rank kernel of the same shape
             FEMCY_REQUIRE((var & 15) == FEMCY_PERSIST_DEFAULT_VARIANT, "the multi-rank persistent PCG exists for the default variant only");
-            if (SPW == 3) { FEMCY_PERSIST_M(3, 3, 4, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
-            else { FEMCY_PERSIST_M(3, 4, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            if (c->dm == 3) {
+                FEMCY_REQUIRE(SPW <= 4, "the multi-rank persistent PCG of 3 x 3 blocks exists for up to four slices per wave");
+                if (SPW == 3) { FEMCY_PERSIST_M(3, 3, 4, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+                else { FEMCY_PERSIST_M(3, 4, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            } else if (SPW == 3) { FEMCY_PERSIST_M(2, 3, 5, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            else if (SPW == 4) { FEMCY_PERSIST_M(2, 4, 5, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            else if (SPW == 6) { FEMCY_PERSIST_M(2, 6, 3, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
+            else { FEMCY_PERSIST_M(2, 8, 2, FEMCY_PERSIST_DEFAULT_VARIANT, true); }
         } else
 #ifdef FEMCY_PERSIST_ONLY_334     // compile-time experiments: one shape only
         if (c->dm == 3 && SPW == 3 && c->opt_persist_rj == 4) { FEMCY_PERSIST_V(3, 3, 4) } else return FEMCY_OK;

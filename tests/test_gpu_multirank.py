@@ -409,6 +409,86 @@ def test_persistent_pcg_across_ranks_on_one_gpu(gpu_ctx_factory, nranks, wgs):
                 xg[key] = x[a]
 
 
+@pytest.mark.parametrize("nranks,wgs", [(2, 64), (4, 32)])
+def test_persistent_pcg_across_ranks_2d(gpu_ctx_factory, nranks, wgs):
+    """round 6: the multi-rank persistent kernel for 2 x 2 blocks (until then 2-D meshes split over ranks took three
+    launches + collectives per iteration): a CPE8 beam cut along x into `nranks` parts, N contexts of one process on one GPU
+    -- iterates equal to the single-context solve and to the collective loop of the same ranks, replicas bit-identical."""
+    from femcy_amd import backend as be, meshgen, partition
+    from femcy_amd.element_zoo import Element_quadratic_quadrilateral
+    from femcy_amd.material_zoo import LinearIsotropicPlaneStrain
+    m = meshgen.beam_quad8(320, 32, plane="CPE8")                       # 10 240 CPE8, 31 457 nodes
+    nodes, el = m["nodes"], m["elements"]
+    mat = LinearIsotropicPlaneStrain(*m["elastic"])
+    n = nodes.size
+    cons_nodes = [(np.asarray(b["node_set"]), b["dof"]) for b in m["dirichlet_bc_info"]]
+    cons_g = np.unique(np.concatenate([ns * 2 + d for ns, d in cons_nodes]))
+    b_g = np.sin(np.arange(n) * 0.11) * 1e3
+    ctx = gpu_ctx_factory()
+    ctx.set_mesh(nodes, el)
+    ctx.set_element(Element_quadratic_quadrilateral())
+    ctx.set_material(mat)
+    ctx.build_pattern()
+    ctx.assemble_K(-1)
+    ctx.upload(be.VEC_RESIDUAL, b_g)
+    ctx.dirichlet_newton(cons_g, be.VEC_RESIDUAL)
+    ref = [(ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=k), ctx.download(be.VEC_X)) for k in (1, 7, 40)]
+    parts = partition.build_all_parts(nodes, el, nranks, axis=0)
+    uid = be.Context.comm_local_id()
+    blobs = [None] * nranks
+    gate = threading.Barrier(nranks)
+
+    def rank_main(r):
+        p = parts[r]
+        c = be.Context(0)
+        try:
+            c.set_option(107, wgs)                                      # FEMCY_TUNE_PERSIST_WGS: all ranks' kernels co-resident
+            c.set_mesh(p.nodes, p.elements)
+            c.set_element(Element_quadratic_quadrilateral())
+            c.set_material(mat)
+            c.build_pattern()
+            c.comm_init(p.rank, p.nranks, uid, p.iface_local_dofs, p.iface_global_slot, p.niface_global, p.owner)
+            c.comm_set_neighbours(p)
+            blobs[r] = c.comm_mailbox_export()
+            gate.wait(timeout=60)
+            c.comm_mailbox_import(blobs)
+            assert c.comm_persist_agree()
+            c.assemble_K(-1)
+            c.upload(be.VEC_RESIDUAL, p.scatter_global(b_g))
+            cons = np.unique(np.concatenate([p.localize_nodes(ns) * 2 + d for ns, d in cons_nodes]))
+            c.dirichlet_newton(cons, be.VEC_RESIDUAL)
+            out = {}
+            for multi in (1, 0):
+                c.set_option(be.OPT_PCG_PERSIST_MULTI, multi)
+                t0 = c.timing()
+                out[multi] = [(c.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=k), c.download(be.VEC_X)) for k in (1, 7, 40)]
+                t1 = c.timing()
+                out[multi].append((t1["solves_persist"] - t0["solves_persist"], t1["solves_three"] - t0["solves_three"],
+                                   t1["barrier_timeouts"] - t0["barrier_timeouts"]))
+            return out
+        finally:
+            c.close()
+
+    outs = run_ranks(nranks, rank_main)
+    for p, out in zip(parts, outs):
+        assert out[1][-1] == (3, 0, 0), out[1][-1]                     # three solves, all persistent, no time-out
+        assert out[0][-1] == (0, 3, 0), out[0][-1]
+        for form in (1, 0):
+            for ((k, r0k, rmk), xk), ((kr, r0r, rmr), xr) in zip(out[form][:3], ref):
+                assert k == kr and abs(r0k - r0r) <= 1e-12 * r0r and abs(rmk - rmr) <= 1e-9 * rmr
+                assert np.linalg.norm(xk - p.scatter_global(xr)) <= 1e-9 * np.linalg.norm(xr)
+    assert len({tuple(o[1][k][0] for k in range(3)) for o in outs}) == 1
+    xg = {}
+    for p, o in zip(parts, outs):
+        x = o[1][2][1].reshape(-1, 2)
+        for a_, g in enumerate(p.l2g):
+            key = int(g)
+            if key in xg:
+                assert np.array_equal(xg[key], x[a_])
+            else:
+                xg[key] = x[a_]
+
+
 def test_persistent_pcg_across_ranks_times_out_together(gpu_ctx_factory):
     """a spin limit of 0 on every rank: the first cross-rank poll gives up, every rank's launch ends with done = 3, the
     ranks agree through the communicator and redo the solve with the three-launch + collective loop -- same iterates

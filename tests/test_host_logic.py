@@ -300,14 +300,23 @@ def test_traffic_fingerprint_is_the_kernels_machine_code(tmp_path):
     other = tmp_path / "libother.so"
     other.write_bytes(bytes(data))
     assert bench.kernel_object_sha(str(other)) == a
-    # ... and one whose kernel bytes differ does not: flip a byte inside the first gfx950 code object's .text
+    # since round 6 each workload of the record is pinned to the ONE instantiation its passes ran (`kernel_sha`): adding or
+    # changing OTHER instantiations of the same template does not void it
+    assert bench.kernel_symbol_fragment("void femcy::(anonymous namespace)::k_pcg_persist<3, 3, 4, 6, false>(femcy::X)") == \
+        "13k_pcg_persistILi3ELi3ELi4ELi6ELb0EE"
+    assert bench.kernel_symbol_fragment("void femcy::k_spmv<2, 4, true>(int, femcy::XcdRanges)") == "6k_spmvILi2ELi4ELb1EE"
+    one = bench.kernel_object_sha(patterns=("13k_pcg_persistILi3ELi3ELi4ELi6ELb0EE",))
+    assert one != a and one != bench.kernel_object_sha(patterns=("13k_pcg_persistILi2ELi8ELi2ELi6ELb0EE",))
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     doc = json.load(open(tpath))
+    entry = doc["workloads"]["c3d4"]
     val, src = bench.pmc_traffic("c3d4", "k_pcg_persist")
-    if doc.get("kernel_object_sha") == a:
-        assert val == doc["workloads"]["c3d4"]["hbm_bytes_per_launch"] and "spmv_traffic.json" in src
+    current = (entry.get("kernel_sha") == bench.kernel_object_sha(patterns=(bench.kernel_symbol_fragment(entry["kernel"]),))
+               if entry.get("kernel_sha") else doc.get("kernel_object_sha") == a)
+    if current:
+        assert val == entry["hbm_bytes_per_launch"] and "spmv_traffic.json" in src
         bad, why = bench.pmc_traffic("c3d4", "k_pcg_persist", layout={"n": 1, "nnzb": 1, "stored_blocks": 1, "nslices": 1})
-        assert (bad is None and "layout" in why) or doc["workloads"]["c3d4"].get("layout") is None
+        assert (bad is None and "layout" in why) or entry.get("layout") is None
     else:
         assert val is None and "stale" in src
 

@@ -62,6 +62,9 @@ def main():
         out["workloads"][wl] = {"kernel": kname, "dispatches": [nf, nw], "fetch_size_kb_reported": fetch_kb,
                                 "write_size_kb_reported": write_kb, "avg_us_under_pmc": [us_f, us_w],
                                 "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024)), "layout": layout}
+        frag = bench.kernel_symbol_fragment(kname)               # the ONE instantiation the passes ran: its machine code
+        if frag:
+            out["workloads"][wl]["kernel_sha"] = bench.kernel_object_sha(patterns=(frag,))
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
