@@ -1,5 +1,5 @@
 """CPE8 / C3D10 / C3D4 product: wavefronts per slice (FEMCY_OPT_SPMV_VARIANT 1 / 2 / 4) launch to launch.
-usage: python tools/r06_spmv_wps.py cpe8|c3d10|c3d4 [k]"""
+usage: python tools/r06_spmv_wps.py cpe8|c3d10|c3d4 [k] [quick]   (quick: a few products only, for a PMC pass)"""
 import os
 import sys
 
@@ -28,6 +28,10 @@ ctx.upload(be.VEC_DOF, np.zeros(ctx.n))
 ctx.assemble_K(be.VEC_DOF)
 spmv_b, iter_b = bench.algorithmic_bytes(info, ctx.nn, ctx.n)
 ctx.upload(be.VEC_RESIDUAL, np.sin(np.arange(ctx.n) * 0.11) * 1e3)
+if "quick" in sys.argv:
+    print(f"{wl} {ctx.n} DOF: product {ctx.probe_spmv(5, True):.1f} us; algorithmic bytes {spmv_b}", flush=True)
+    ctx.close()
+    sys.exit(0)
 for wps in (0, 1, 2, 4):
     ctx.set_option(be.OPT_SPMV_VARIANT, wps)
     us = min(ctx.probe_spmv(200, True) for _ in range(3))
