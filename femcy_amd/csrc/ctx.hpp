@@ -125,6 +125,11 @@ struct PcgState {
 struct XcdRanges {
     int32_t start[9];
 };
+// workgroups per XCD of a product whose longest XCD range holds `per` tasks: `cap` (the knob) or `cap_auto` (spmv_split)
+inline int32_t spmv_bpx(int32_t per, int32_t cap, int32_t cap_auto) {
+    if (cap <= 0) cap = cap_auto;
+    return per < 1 ? 1 : (per < cap ? per : cap);
+}
 
 struct EventPair {
     hipEvent_t a, b;
@@ -165,7 +170,11 @@ struct Ctx {
     bool vec_nt = false;              // PCG vector kernels with non-temporal accesses
     int opt_vec_nt = -1;              // -1 auto (same rule as the matrix stream), 0 / 1 forced (test knob 103)
     int opt_spmv_nt = -1;             // -1 auto, 0 / 1 forced (test knob 102)
-    int32_t spmv_bpx_cap = 256;       // SpMV workgroups per XCD (larger slice ranges are looped in the kernel)
+    int32_t spmv_bpx_cap = 0;         // SpMV workgroups per XCD (larger slice ranges are looped in the kernel); 0 = by the
+                                      // size of the matrix (spmv_cap_auto), FEMCY_TUNE_SPMV_WG_PER_XCD fixes it
+    int32_t spmv_cap_auto = 256;      // spmv_split: 512 for long ranges of a large matrix, else 256
+    int32_t opt_spmv_rot = -1;        // FEMCY_TUNE_SPMV_ROT: -1 = by the spread of the row lengths (spmv_split)
+    int32_t spmv_rot = 0;             // rotation of the product's rounds against each other (k_spmv), 0 = none
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
     int64_t nnzb = 0;
     int32_t max_row_blocks = 0, max_node_elems = 0;

@@ -319,7 +319,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->ew_cap = (int)value;
             break;
         case FEMCY_TUNE_SPMV_WG_PER_XCD:   /* test knob: SpMV workgroups per XCD (1 forces the in-kernel loop on small meshes) */
-            FEMCY_REQUIRE(value >= 1 && value <= 512, "workgroups per XCD out of range");
+            FEMCY_REQUIRE(value >= 0 && value <= 512, "workgroups per XCD: 0 (by the size of the range) or 1 .. 512");
             c->spmv_bpx_cap = (int32_t)value;
             if (c->have_pattern) {
                 pcg_graph_reset(c);
@@ -378,6 +378,14 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             FEMCY_REQUIRE(value == 0 || ((value / 1000 == 2 || value / 1000 == 4) && value % 1000 > 0),
                           "ROWS4 tile write-out: 0 (off) or 1000 GP + LCUT with GP 2 or 4 and LCUT > 0 blocks");
             c->tune_rows4_tile = (int)value;
+            break;
+        case FEMCY_TUNE_SPMV_ROT:
+            FEMCY_REQUIRE(value >= -1 && value <= 63, "SpMV round rotation: -1 (by the spread of the row lengths), 0 (none) .. 63");
+            c->opt_spmv_rot = (int32_t)value;
+            if (c->have_pattern) {
+                pcg_graph_reset(c);
+                spmv_split(c);
+            }
             break;
         case FEMCY_TUNE_ROWS4_ORDER:
             FEMCY_REQUIRE(value >= -1 && value <= 3, "ROWS4 launch order: -1 auto, 0 longest slices first, 1 Morton order in XCD-contiguous ranges");

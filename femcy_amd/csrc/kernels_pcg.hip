@@ -91,6 +91,15 @@ __device__ __forceinline__ void gather_x(const __amdgpu_buffer_rsrc_t rs, int32_
 }
 
 // ------------------------------------------------------------------------------------------ SpMV
+// position of workgroup `wgx` of an XCD inside round `rnd` of the XCD's task list (a permutation of 0 .. bpx-1 per round).
+// W = tasks per sort window (rows are sorted by length inside windows of 64 slices): the workgroup's position INSIDE the
+// window advances by `rot` from one round to the next whatever bpx mod W is; rot = 0: the same position every round
+template <int W>
+__device__ __forceinline__ int spmv_rot(int wgx, int rnd, int bpx, int rot) {
+    if (rot == 0) return wgx;
+    const int step = (((rot - bpx) % W) + W) % W;
+    return (int)((unsigned)(wgx + (step * rnd) % W) % (unsigned)bpx);
+}
 // WPS = wavefronts per slice: long rows (C3D10: 27-65 blocks per node) are split into WPS contiguous j-chunks
 // handled by WPS waves of the same workgroup and summed through LDS, so that the chain per wave stays short and
 // the few thousand slices still fill 1024 SIMDs evenly.
@@ -107,7 +116,7 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done,
                                              const int32_t* __restrict__ slice_list, int32_t keep_permille,
-                                             int32_t nreal) {
+                                             int32_t nreal, int32_t rot) {
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
@@ -126,7 +135,14 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
     const int s_end = xr.start[k + 1];
     const int ntask = (s_end - xr.start[k] + SPB - 1) / SPB;
     double dot = 0.0;
-    for (int task = blockIdx.x / NXCD; task < ntask; task += bpx) {   // uniform trip count within a workgroup
+    // rows are sorted by length inside windows of 64 slices: with task = b + i bpx and bpx a multiple of that period (256,
+    // 512) a workgroup takes the SAME position of the window in every round -- the head of the window (C3D10: 65 blocks
+    // per row against a mean of 29) always on the same workgroups, which finish long after the rest.  Where the lengths
+    // spread (host: spmv_split) the rounds are rotated against each other (spmv_rot); a round still covers bpx
+    // consecutive tasks, so the gathers of concurrent workgroups keep sharing the XCD's L2
+    const int wgx = blockIdx.x / NXCD;
+    for (int rnd = 0; rnd * bpx < ntask; ++rnd) {                     // uniform trip count within a workgroup
+        const int task = rnd * bpx + spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot);
         const int spos = xr.start[k] + task * SPB + wave / WPS;
         const bool active = spos < s_end;
         const int s = (active && slice_list) ? slice_list[spos] : spos;
@@ -226,7 +242,7 @@ __global__ void __launch_bounds__(BS) k_spmv_fp(int32_t npos, XcdRanges xr, cons
                                                 const int32_t* __restrict__ fp, const double* __restrict__ vals,
                                                 const double* __restrict__ x, double* __restrict__ y,
                                                 double* __restrict__ partials, const int32_t* __restrict__ done,
-                                                int32_t keep_permille, int32_t nreal, int32_t fcap) {
+                                                int32_t keep_permille, int32_t nreal, int32_t fcap, int32_t rot) {
     extern __shared__ __attribute__((aligned(16))) double xs_all[];      // [BS / 64][fcap][DM]
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
@@ -243,7 +259,9 @@ __global__ void __launch_bounds__(BS) k_spmv_fp(int32_t npos, XcdRanges xr, cons
     const int s_end = xr.start[k + 1];
     const int ntask = (s_end - xr.start[k] + SPB - 1) / SPB;
     double dot = 0.0;
-    for (int task = blockIdx.x / NXCD; task < ntask; task += bpx) {
+    const int wgx = blockIdx.x / NXCD;
+    for (int rnd = 0; rnd * bpx < ntask; ++rnd) {                     // rotated rounds: see k_spmv
+        const int task = rnd * bpx + spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot);
         const int s = xr.start[k] + task * SPB + wave / WPS;
         const bool active = s < s_end;
         double acc[DM];
@@ -979,7 +997,7 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
 #define SPMV_ARGS                                                                                              \
     (pos_space ? c->nslices * SLICE : c->nn), xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,  \
         (const int32_t*)(pos_space ? c->d_bcolp : c->d_bcol), (const int32_t*)(pos_space ? nullptr : c->d_node_of),  \
-        (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list, (int32_t)c->spmv_keep_permille, c->nn
+        (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list, (int32_t)c->spmv_keep_permille, c->nn, c->spmv_rot
 #define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \
@@ -1002,7 +1020,7 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
 #define SPMV_FP_ARGS                                                                                            \
     c->nslices * SLICE, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const uint16_t*)c->d_lcol,  \
         (const int32_t*)c->d_fp_ptr, (const int32_t*)c->d_fp, (const double*)c->d_Kvals, d_x, d_y, d_partials, done,     \
-        (int32_t)c->spmv_keep_permille, c->nn, c->fp_cap
+        (int32_t)c->spmv_keep_permille, c->nn, c->fp_cap, c->spmv_rot
 #define SPMV_FP_LAUNCH_NT(DM_, WPS_, NT_)                                                                        \
     do {                                                                                                        \
         if (lds > 48 * 1024)                                                                                    \
@@ -1168,7 +1186,7 @@ int launch_spmv_part(Ctx* c, int part, const double* d_x, double* d_y, double* d
     int per = 1;
     for (int k = 0; k < NXCD; ++k) per = std::max(per, (xr.start[k + 1] - xr.start[k] + spb - 1) / spb);
     // the two halves together must fit the partial array: each half gets at most half of it
-    const int grid = std::min(std::min(per, std::max(1, c->spmv_bpx_cap)), MAX_PARTIALS / (2 * NXCD)) * NXCD;
+    const int grid = std::min(spmv_bpx(per, c->spmv_bpx_cap, c->spmv_cap_auto), MAX_PARTIALS / (2 * NXCD)) * NXCD;
     return launch_spmv_impl(c, d_x, d_y, d_partials ? d_partials + part_off : nullptr, nblocks_out, xr, grid,
                             c->d_split_list, d_partials ? part_off : 0);
 }

@@ -90,7 +90,44 @@ void spmv_split(Ctx* c) {
     c->xcd.start[NX] = nslices;
     int32_t per = 1;
     for (int k = 0; k < NX; ++k) per = std::max(per, (c->xcd.start[k + 1] - c->xcd.start[k] + spb - 1) / spb);
-    c->spmv_grid = std::min(per, std::max(1, c->spmv_bpx_cap)) * NX;   // <= 2048 workgroups: larger ranges are looped inside the kernel
+    // Workgroups per XCD.  The product's kernels hold 5 waves per SIMD (84-92 registers), i.e. 160 workgroups per XCD at a
+    // time; beyond that the dispatcher hands the next workgroup to whichever CU becomes free, which evens out what the
+    // static task lists leave uneven.  Measured in one process, interleaved (round 6, profiles/r06_spmv_rounds.txt): 512
+    // instead of 256 -- C3D10 k = 12 (3.0 GB) 597 -> 560 us, k = 8 (0.9 GB) 173 -> 152, 8 M C3D4 (1.55 GB) 283.5 -> 280.5;
+    // but twice the d.Ad partials for the vector kernels to sum: the 1 M-DOF CPE8 beam (278 MB) gains 0.5 us in the product
+    // and loses 1.3 in the iteration, and at C3D10 k = 6 (357 tasks per XCD) one task per workgroup is the slower form
+    // (64.6 -> 65.6): long ranges of large matrices only
+    const bool big = per > 512 && matrix_bytes > (int64_t)512 * 1024 * 1024;
+    c->spmv_cap_auto = big ? 512 : 256;
+    const int32_t bpx = spmv_bpx(per, c->spmv_bpx_cap, c->spmv_cap_auto);
+    c->spmv_grid = bpx * NX;                                      // <= 4096 workgroups: larger ranges are looped inside the kernel
+    // Rows are sorted by length inside windows of sigma rows.  Where the head of a window is much longer than its mean
+    // (C3D10: 65 blocks against 29; C3D4: 15 against 14) and the range takes many rounds, the kernel rotates the rounds
+    // against each other so that a workgroup does not take the same position of the window every time (k_spmv): C3D10
+    // k = 12 560 -> 537 us on top of the 512 workgroups (three-launch iteration 658 -> 602 in all).  On uniform rows the
+    // rotation only costs (8 M C3D4: +1.5-2.5 %), as it does with two rounds or fewer (k = 8: 151.6 -> 153.3, k = 6 at 256:
+    // 64.6 -> 68.8): decided per pattern
+    if (c->opt_spmv_rot >= 0)
+        c->spmv_rot = c->opt_spmv_rot;
+    else {
+        const int32_t wsl = std::max(1, c->sell_sigma / SLICE);   // slices per sort window
+        double spread = 0.0;
+        int32_t nw = 0;
+        for (int32_t w0 = 0; w0 < nslices; w0 += wsl) {
+            const int32_t w1 = std::min(nslices, w0 + wsl);
+            int64_t sum = 0;
+            int32_t mx = 0;
+            for (int32_t q = w0; q < w1; ++q) {
+                sum += c->h_slice_len[q];
+                mx = std::max(mx, c->h_slice_len[q]);
+            }
+            if (sum > 0) {
+                spread += (double)mx * (w1 - w0) / (double)sum;
+                ++nw;
+            }
+        }
+        c->spmv_rot = (big && per > 2 * bpx && nw > 0 && spread / nw > 1.25) ? 19 : 0;
+    }
 }
 
 // Footprints of the storage-order product (k_spmv_fp).  A wave multiplies block rows j0 .. j1 of one slice (its part of

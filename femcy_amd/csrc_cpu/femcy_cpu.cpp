@@ -416,7 +416,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->direct_max_bytes = value;
             return FEMCY_OK;
         default:
-            if (option >= 100 && option <= 118) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
+            if (option >= 100 && option <= 119) return FEMCY_OK;   // FEMCY_TUNE_*: device tuning knobs
             set_error("unknown option %d", option);
             return FEMCY_EINVAL;
     }

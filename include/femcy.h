@@ -174,8 +174,11 @@ enum femcy_option {
     FEMCY_TUNE_TIMING_FENCE = 100,   /* 1 (default): an empty kernel precedes every SpMV dispatch that is timed with
                                         dispatch-attached events, so that the start stamp is not taken while the
                                         previous kernel drains                                                     */
-    FEMCY_TUNE_SPMV_WG_PER_XCD = 101,/* SpMV workgroups per XCD (default 256; longer slice ranges are looped inside
-                                        the kernel; 1 forces that loop on small meshes)                            */
+    FEMCY_TUNE_SPMV_WG_PER_XCD = 101,/* SpMV workgroups per XCD; longer slice ranges are looped inside the kernel.  0 (default)
+                                        = 512 where an XCD's range holds more than 512 tasks of a matrix beyond 512 MiB, else
+                                        256 (round 6: 5 workgroups per CU are resident, the rest is handed out as CUs become
+                                        free; 3 GB C3D10 product 597 -> 560 us, profiles/r06_spmv_rounds.txt); 1 forces the
+                                        loop on small meshes (tests)                                               */
     FEMCY_TUNE_SPMV_NT = 102,        /* SpMV matrix stream non-temporal: -1 auto (stored matrix > 256 MiB), 0, 1    */
     FEMCY_TUNE_VEC_NT = 103,         /* PCG vector kernels non-temporal: -1 auto (vector > 12 MB), 0, 1             */
     FEMCY_TUNE_PERSIST_LDS_ROWS = 104,/* persistent PCG: block rows per wave kept in LDS (-1 = as many as fit)      */
@@ -212,6 +215,12 @@ enum femcy_option {
                                         Cache), 1 = slices in Morton order of their centroids, XCD-contiguous ranges (records
                                         re-used inside one L2: best beyond it), -1 (default) = by the size of the records;
                                         the same bits of K either way */
+    FEMCY_TUNE_SPMV_ROT = 119,       /* SpMV: a workgroup's position inside the length-sorted window advances by this many tasks
+                                        from one round of its XCD's task list to the next; 0 = the same position every round
+                                        (rounds 1-5), -1 (default) = 19 where the rows of a window differ in length by more
+                                        than a quarter and the range takes more than two rounds of a matrix beyond 512 MiB
+                                        (C3D10 k = 12: the longest rows no longer always on the same workgroups, 560 -> 537
+                                        us), 0 elsewhere; changes the grouping of the d.Ad partial sums only */
     FEMCY_TUNE_PAIRS = 117,          /* FEMCY_ASM_PAIRS: -1 = default (163), else bit 0 = workgroups take XCD-contiguous ranges of
                                         the processing order, bits 1-2 = rows per wavefront (0: 16, 1: 8), bits 3-4 = steps of
                                         element records in flight - 2 (0..2), bit 5 = chunks processed in Morton order of their

@@ -361,7 +361,14 @@ def test_spmv_and_vectors(gpu_ctx_factory, name):
         ctx.set_option(101, 1)                  # one workgroup per XCD: the in-kernel loop over slice groups
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)      # (what meshes beyond ~6 M elements use)
         assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
-        ctx.set_option(101, 256)
+        y_loop = ctx.download(be.VEC_TMP1)
+        for cap, rot in ((1, 19), (2, 7), (3, 19), (3, 0)):      # rounds rotated against each other (round 6: what the
+            ctx.set_option(be.TUNE_SPMV_WG_PER_XCD, cap)         # length-sorted C3D10 windows get): a relabelling of
+            ctx.set_option(be.TUNE_SPMV_ROT, rot)                # which workgroup multiplies which slice
+            ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)
+            assert np.array_equal(ctx.download(be.VEC_TMP1), y_loop), (cap, rot)
+        ctx.set_option(be.TUNE_SPMV_ROT, -1)
+        ctx.set_option(be.TUNE_SPMV_WG_PER_XCD, 0)
         y_plain = ctx.download(be.VEC_TMP1)
         ctx.set_option(102, 1)                  # non-temporal matrix loads (what matrices beyond 256 MiB use)
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)

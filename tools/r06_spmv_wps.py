@@ -32,6 +32,25 @@ if "quick" in sys.argv:
     print(f"{wl} {ctx.n} DOF: product {ctx.probe_spmv(5, True):.1f} us; algorithmic bytes {spmv_b}", flush=True)
     ctx.close()
     sys.exit(0)
+if "ab" in sys.argv:                     # workgroups per XCD x round rotation, interleaved in ONE process (round 6)
+    cfgs = [(256, 0), (512, 0), (256, 19), (512, 19), (0, -1)]     # (256, 0) = rounds 1-5, (0, -1) = the defaults
+    for rep in range(3):
+        for cap, rot in cfgs:
+            ctx.set_option(be.TUNE_SPMV_WG_PER_XCD, cap)
+            ctx.set_option(be.TUNE_SPMV_ROT, rot)
+            us = sorted(ctx.probe_spmv(200, True) for _ in range(3))
+            ctx.set_option(be.OPT_PCG_PERSIST, 0)
+            ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=20)
+            ctx.set_option(be.OPT_TIMING, 64)
+            ctx.timing_reset()
+            its = ctx.pcg(be.VEC_RESIDUAL, be.VEC_X, eps=0.0, maxit=200)[0]
+            tm = ctx.timing()
+            ctx.set_option(be.OPT_TIMING, 0)
+            ctx.set_option(be.OPT_PCG_PERSIST, 1)
+            print(f"{wl} {ctx.n} DOF rep {rep} wg/xcd {cap} rot {rot}: product {us[1]:.1f} us = {spmv_b / us[1] / 1e3 / 8000:.3f} of HBM; "
+                  f"three-launch iteration {tm['pcg_ms'] * 1e3 / its:.1f} us = {iter_b / (tm['pcg_ms'] * 1e3 / its) / 1e3 / 8000:.3f}", flush=True)
+    ctx.close()
+    sys.exit(0)
 for wps in (0, 1, 2, 4):
     ctx.set_option(be.OPT_SPMV_VARIANT, wps)
     us = min(ctx.probe_spmv(200, True) for _ in range(3))
