@@ -108,6 +108,9 @@ __device__ __forceinline__ int spmv_rot(int wgx, int rnd, int bpx, int rot) {
 // node_of == nullptr: x and y are in storage order and bcol holds storage positions (nn = nslices * 64): lanes of a wave
 // are rows of one length class in ascending order, their j-th neighbours then sit at (nearly) consecutive positions and
 // a wave's gather touches ~14 cache lines instead of 27-45 on the C3D10 plate (tools/gather_lines.py)
+// (84-92 registers = 5 waves per SIMD.  Forcing the budget of 6 / 7 / 8 waves -- amdgpu_waves_per_eu: 80 / 64 / 62
+// registers, no spills -- is slower on every mesh: 3 GB C3D10 product 539 -> 551 / 558 / 567 us, k = 6 66 -> 72 / 79 / 86,
+// profiles/r06_spmv_occupancy.txt)
 template <int DM, int WPS, bool NT>
 __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int32_t* __restrict__ slice_len,
                                              const int64_t* __restrict__ slice_off,
