@@ -56,7 +56,7 @@ TUNE_BARRIER_SPIN_LIMIT = 112
 TUNE_PERSIST_L2_ROWS = 113
 TUNE_ROWS4_TILE = 116       # ROWS4 assembly, round-5 experiment: 1000 GP + LCUT (tile write-out), 0 = off
 TUNE_SPMV_WG_PER_XCD = 101  # SpMV workgroups per XCD: 0 auto (512 beyond 512 tasks per XCD, else 256)
-TUNE_SPMV_ROT = 119         # SpMV round rotation: -1 auto (by the spread of the row lengths), 0 none, else tasks per round
+TUNE_SPMV_ROT = 119         # SpMV task lists: -1 auto (by the spread of the row lengths), 0 plain, 1..63 rotated rounds, 64 balanced
 TUNE_ROWS4_ORDER = 118      # ROWS4 launch order: -1 auto, 0 longest first, 1 Morton / XCD-contiguous
 TUNE_PAIRS = 117            # PAIRS assembly knobs (femcy.h)
 TUNE_DIRECT_UPDATE = 115    # femcy_direct_solve tile update: -1 auto, 0 VALU, 1 / 2 matrix cores

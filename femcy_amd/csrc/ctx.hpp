@@ -173,8 +173,10 @@ struct Ctx {
     int32_t spmv_bpx_cap = 0;         // SpMV workgroups per XCD (larger slice ranges are looped in the kernel); 0 = by the
                                       // size of the matrix (spmv_cap_auto), FEMCY_TUNE_SPMV_WG_PER_XCD fixes it
     int32_t spmv_cap_auto = 256;      // spmv_split: 512 for long ranges of a large matrix, else 256
-    int32_t opt_spmv_rot = -1;        // FEMCY_TUNE_SPMV_ROT: -1 = by the spread of the row lengths (spmv_split)
+    int32_t opt_spmv_rot = -1;        // FEMCY_TUNE_SPMV_ROT: -1 = by the spread of the row lengths (spmv_split), 64 = balanced lists
     int32_t spmv_rot = 0;             // rotation of the product's rounds against each other (k_spmv), 0 = none
+    int32_t* d_spmv_perm = nullptr;   // [8][spmv_perm_rounds][workgroups per XCD] balanced task lists (spmv_split), or nullptr
+    int32_t spmv_perm_rounds = 0;
     int64_t stored_rows = 0;          // sum over slices of slice_len (in block rows of 64 lanes)
     int64_t nnzb = 0;
     int32_t max_row_blocks = 0, max_node_elems = 0;

@@ -249,7 +249,7 @@ int femcy_ctx_destroy(femcy_ctx* ctx) {
     dev_free(&c->d_slice_len); dev_free(&c->d_slice_off); dev_free(&c->d_rowlen); dev_free(&c->d_bcol);
     dev_free(&c->d_pos); dev_free(&c->d_node_of);
     dev_free(&c->d_Kvals); dev_free(&c->d_slotj); dev_free(&c->d_ctr_ptr); dev_free(&c->d_ctr); dev_free(&c->d_tpos);
-    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order); dev_free(&c->d_asm_order_near); dev_free(&c->d_asm_order_id);
+    dev_free(&c->d_ne_ptr); dev_free(&c->d_ne_idx); dev_free(&c->d_asm_order); dev_free(&c->d_asm_order_near); dev_free(&c->d_asm_order_id); dev_free(&c->d_spmv_perm);
     dev_free(&c->d_pr_ptr); dev_free(&c->d_pr_unit); dev_free(&c->d_pr_code);
     dev_free(&c->d_dsdx); dev_free(&c->d_vol); dev_free(&c->d_F); dev_free(&c->d_sigma);
     dev_free(&c->d_strain); dev_free(&c->d_mises); dev_free(&c->d_energy); dev_free(&c->d_fe);
@@ -380,7 +380,7 @@ int femcy_set_option(femcy_ctx* ctx, int option, int64_t value) {
             c->tune_rows4_tile = (int)value;
             break;
         case FEMCY_TUNE_SPMV_ROT:
-            FEMCY_REQUIRE(value >= -1 && value <= 63, "SpMV round rotation: -1 (by the spread of the row lengths), 0 (none) .. 63");
+            FEMCY_REQUIRE(value >= -1 && value <= 64, "SpMV task lists: -1 (by the spread of the row lengths), 0 (plain), 1 .. 63 (rounds rotated), 64 (balanced by the host)");
             c->opt_spmv_rot = (int32_t)value;
             if (c->have_pattern) {
                 pcg_graph_reset(c);

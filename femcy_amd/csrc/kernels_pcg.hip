@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ partials, const int32_t* __restrict__ done,
                                              const int32_t* __restrict__ slice_list, int32_t keep_permille,
-                                             int32_t nreal, int32_t rot) {
+                                             int32_t nreal, int32_t rot, const int32_t* __restrict__ perm,
+                                             int32_t perm_rounds) {
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
     if (done && *done) return;
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(BS) k_spmv(int32_t nn, XcdRanges xr, const int
     // consecutive tasks, so the gathers of concurrent workgroups keep sharing the XCD's L2
     const int wgx = blockIdx.x / NXCD;
     for (int rnd = 0; rnd * bpx < ntask; ++rnd) {                     // uniform trip count within a workgroup
-        const int task = rnd * bpx + spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot);
+        const int task = rnd * bpx + (perm ? perm[((size_t)k * perm_rounds + rnd) * bpx + wgx] : spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot));
         const int spos = xr.start[k] + task * SPB + wave / WPS;
         const bool active = spos < s_end;
         const int s = (active && slice_list) ? slice_list[spos] : spos;
@@ -245,7 +246,8 @@ __global__ void __launch_bounds__(BS) k_spmv_fp(int32_t npos, XcdRanges xr, cons
                                                 const int32_t* __restrict__ fp, const double* __restrict__ vals,
                                                 const double* __restrict__ x, double* __restrict__ y,
                                                 double* __restrict__ partials, const int32_t* __restrict__ done,
-                                                int32_t keep_permille, int32_t nreal, int32_t fcap, int32_t rot) {
+                                                int32_t keep_permille, int32_t nreal, int32_t fcap, int32_t rot,
+                                                const int32_t* __restrict__ perm, int32_t perm_rounds) {
     extern __shared__ __attribute__((aligned(16))) double xs_all[];      // [BS / 64][fcap][DM]
     __shared__ double sm[BS / 64];
     __shared__ double red[(WPS > 1) ? (BS / 64) * 64 * DM : 1];
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(BS) k_spmv_fp(int32_t npos, XcdRanges xr, cons
     double dot = 0.0;
     const int wgx = blockIdx.x / NXCD;
     for (int rnd = 0; rnd * bpx < ntask; ++rnd) {                     // rotated rounds: see k_spmv
-        const int task = rnd * bpx + spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot);
+        const int task = rnd * bpx + (perm ? perm[((size_t)k * perm_rounds + rnd) * bpx + wgx] : spmv_rot<SLICE / SPB>(wgx, rnd, bpx, rot));
         const int s = xr.start[k] + task * SPB + wave / WPS;
         const bool active = s < s_end;
         double acc[DM];
@@ -986,6 +988,9 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
         return FEMCY_EINVAL;
     }
     const int32_t* done = d_partials ? &c->d_state->done : nullptr;
+    // the balanced task lists (spmv_split) belong to the product over all slices in c->xcd's ranges and c->spmv_grid
+    const int32_t* spmv_perm = (c->spmv_rot == 64 && c->spmv_perm_rounds > 0 && !slice_list && grid == c->spmv_grid &&
+                                xr.start[NXCD] == c->xcd.start[NXCD]) ? c->d_spmv_perm : nullptr;
     // timing: start/stop events attached to the dispatch itself (hipExtLaunchKernel), i.e. the kernel's own
     // begin/end timestamps -- no marker packets between the PCG kernels, agrees with rocprofv3's kernel trace
     // FEMCY_OPT_TIMING = k > 1 samples every k-th SpMV launch: a profiled dispatch costs ~5 us of pipeline
@@ -1000,7 +1005,7 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
 #define SPMV_ARGS                                                                                              \
     (pos_space ? c->nslices * SLICE : c->nn), xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off,  \
         (const int32_t*)(pos_space ? c->d_bcolp : c->d_bcol), (const int32_t*)(pos_space ? nullptr : c->d_node_of),  \
-        (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list, (int32_t)c->spmv_keep_permille, c->nn, c->spmv_rot
+        (const double*)c->d_Kvals, d_x, d_y, d_partials, done, slice_list, (int32_t)c->spmv_keep_permille, c->nn, (int32_t)(c->spmv_rot == 64 ? 19 : c->spmv_rot), spmv_perm, c->spmv_perm_rounds
 #define SPMV_LAUNCH_NT(DM_, WPS_, NT_)                                                                         \
     do {                                                                                                       \
         if (ev)                                                                                                \
@@ -1023,7 +1028,7 @@ static int launch_spmv_impl(Ctx* c, const double* d_x, double* d_y, double* d_pa
 #define SPMV_FP_ARGS                                                                                            \
     c->nslices * SLICE, xr, (const int32_t*)c->d_slice_len, (const int64_t*)c->d_slice_off, (const uint16_t*)c->d_lcol,  \
         (const int32_t*)c->d_fp_ptr, (const int32_t*)c->d_fp, (const double*)c->d_Kvals, d_x, d_y, d_partials, done,     \
-        (int32_t)c->spmv_keep_permille, c->nn, c->fp_cap, c->spmv_rot
+        (int32_t)c->spmv_keep_permille, c->nn, c->fp_cap, (int32_t)(c->spmv_rot == 64 ? 19 : c->spmv_rot), spmv_perm, c->spmv_perm_rounds
 #define SPMV_FP_LAUNCH_NT(DM_, WPS_, NT_)                                                                        \
     do {                                                                                                        \
         if (lds > 48 * 1024)                                                                                    \

@@ -101,12 +101,14 @@ void spmv_split(Ctx* c) {
     c->spmv_cap_auto = big ? 512 : 256;
     const int32_t bpx = spmv_bpx(per, c->spmv_bpx_cap, c->spmv_cap_auto);
     c->spmv_grid = bpx * NX;                                      // <= 4096 workgroups: larger ranges are looped inside the kernel
-    // Rows are sorted by length inside windows of sigma rows.  Where the head of a window is much longer than its mean
-    // (C3D10: 65 blocks against 29; C3D4: 15 against 14) and the range takes many rounds, the kernel rotates the rounds
-    // against each other so that a workgroup does not take the same position of the window every time (k_spmv): C3D10
-    // k = 12 560 -> 537 us on top of the 512 workgroups (three-launch iteration 658 -> 602 in all).  On uniform rows the
-    // rotation only costs (8 M C3D4: +1.5-2.5 %), as it does with two rounds or fewer (k = 8: 151.6 -> 153.3, k = 6 at 256:
-    // 64.6 -> 68.8): decided per pattern
+    // Rows are sorted by length inside windows of sigma rows, and with task = b + i * bpx (bpx a multiple of the window) a
+    // workgroup takes the same position of the window in every round: the head of the window (C3D10: 65 blocks per row
+    // against a mean of 29; C3D4: 15 against 14) always on the same workgroups.  Where the lengths spread, the lists are
+    // balanced below (mode 64); modes 1 .. 63 rotate the rounds against each other instead (k_spmv).  Interleaved in one
+    // process (profiles/r06_spmv_rounds.txt), C3D10 k = 12: 596 us plain at 256 workgroups, 560 plain at 512, 538 rotated,
+    // 529 balanced (three-launch iteration 662 -> 597); k = 8: 165 / 144.5 / 147 / 139.  On uniform rows (8 M C3D4) the
+    // rotation costs 1.5-2.5 % and the balanced lists are the plain ones: decided per pattern, large matrices only (the
+    // 1 M-DOF CPE8 beam and C3D10 at k = 6 keep the plain lists: +-1 us either way)
     if (c->opt_spmv_rot >= 0)
         c->spmv_rot = c->opt_spmv_rot;
     else {
@@ -126,7 +128,46 @@ void spmv_split(Ctx* c) {
                 ++nw;
             }
         }
-        c->spmv_rot = (big && per > 2 * bpx && nw > 0 && spread / nw > 1.25) ? 19 : 0;
+        c->spmv_rot = (big && nw > 0 && spread / nw > 1.25) ? 64 : 0;
+    }
+    // 64 = lists balanced here instead of rotated blindly: round by round (a round = bpx consecutive tasks, so that the
+    // gathers of concurrent workgroups keep sharing the XCD's L2) the workgroup that has collected the most work so far
+    // takes the shortest task of the round.  Every workgroup of an XCD then multiplies the same number of stored blocks to
+    // within one task.  Deterministic (ties by index); the table is read with one scalar load per round
+    c->spmv_perm_rounds = 0;
+    if (c->spmv_rot == 64) {
+        int32_t rounds = 1;
+        for (int k = 0; k < NX; ++k)
+            rounds = std::max(rounds, ((c->xcd.start[k + 1] - c->xcd.start[k] + spb - 1) / spb + bpx - 1) / bpx);
+        std::vector<int32_t> perm((size_t)NX * rounds * bpx);
+        std::vector<int64_t> acc(bpx), wgt(bpx);
+        std::vector<int32_t> by_acc(bpx), by_wgt(bpx);
+        for (int k = 0; k < NX; ++k) {
+            const int32_t s0 = c->xcd.start[k], s1 = c->xcd.start[k + 1];
+            std::fill(acc.begin(), acc.end(), 0);
+            for (int32_t r = 0; r < rounds; ++r) {
+                for (int32_t q = 0; q < bpx; ++q) {
+                    int64_t w = 0;
+                    for (int32_t u = 0; u < spb; ++u) {
+                        const int64_t sl = (int64_t)s0 + ((int64_t)r * bpx + q) * spb + u;
+                        if (sl < s1) w += c->h_slice_len[sl];
+                    }
+                    wgt[q] = w;
+                    by_acc[q] = by_wgt[q] = q;
+                }
+                std::stable_sort(by_wgt.begin(), by_wgt.end(), [&](int32_t a, int32_t b) { return wgt[a] < wgt[b]; });
+                std::stable_sort(by_acc.begin(), by_acc.end(), [&](int32_t a, int32_t b) { return acc[a] > acc[b]; });
+                int32_t* row = perm.data() + ((size_t)k * rounds + r) * bpx;
+                for (int32_t q = 0; q < bpx; ++q) {
+                    row[by_acc[q]] = by_wgt[q];
+                    acc[by_acc[q]] += wgt[by_wgt[q]];
+                }
+            }
+        }
+        if (upload(&c->d_spmv_perm, perm) == FEMCY_OK)
+            c->spmv_perm_rounds = rounds;
+        else
+            c->spmv_rot = 19;                                     // no table: the rotation
     }
 }
 

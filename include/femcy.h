@@ -215,12 +215,14 @@ enum femcy_option {
                                         Cache), 1 = slices in Morton order of their centroids, XCD-contiguous ranges (records
                                         re-used inside one L2: best beyond it), -1 (default) = by the size of the records;
                                         the same bits of K either way */
-    FEMCY_TUNE_SPMV_ROT = 119,       /* SpMV: a workgroup's position inside the length-sorted window advances by this many tasks
-                                        from one round of its XCD's task list to the next; 0 = the same position every round
-                                        (rounds 1-5), -1 (default) = 19 where the rows of a window differ in length by more
-                                        than a quarter and the range takes more than two rounds of a matrix beyond 512 MiB
-                                        (C3D10 k = 12: the longest rows no longer always on the same workgroups, 560 -> 537
-                                        us), 0 elsewhere; changes the grouping of the d.Ad partial sums only */
+    FEMCY_TUNE_SPMV_ROT = 119,       /* SpMV task lists of the workgroups of an XCD.  0 = task b + i * (workgroups per XCD) in round i
+                                        (rounds 1-5: always the same position of the length-sorted window); 1 .. 63 = the
+                                        position advances by this many tasks per round; 64 = lists balanced by the host, round
+                                        by round (the workgroup with the most work so far takes the shortest task of the
+                                        round); -1 (default) = 64 where the rows of a window differ in length by more than a
+                                        quarter and an XCD's range holds more than 512 tasks of a matrix beyond 512 MiB (C3D10
+                                        at k >= 8: 3 GB product 596 -> 529 us together with knob 101), 0 elsewhere.  Changes the grouping of the d.Ad partial sums only
+                                        (profiles/r06_spmv_rounds.txt) */
     FEMCY_TUNE_PAIRS = 117,          /* FEMCY_ASM_PAIRS: -1 = default (163), else bit 0 = workgroups take XCD-contiguous ranges of
                                         the processing order, bits 1-2 = rows per wavefront (0: 16, 1: 8), bits 3-4 = steps of
                                         element records in flight - 2 (0..2), bit 5 = chunks processed in Morton order of their

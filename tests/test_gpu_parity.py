@@ -362,7 +362,7 @@ def test_spmv_and_vectors(gpu_ctx_factory, name):
         ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)      # (what meshes beyond ~6 M elements use)
         assert rel(ctx.download(be.VEC_TMP1), K @ x) < 1e-13
         y_loop = ctx.download(be.VEC_TMP1)
-        for cap, rot in ((1, 19), (2, 7), (3, 19), (3, 0)):      # rounds rotated against each other (round 6: what the
+        for cap, rot in ((1, 19), (2, 7), (3, 19), (3, 64), (1, 64), (2, 64), (3, 0)):      # rounds rotated against each other / lists balanced by the host (round 6: what the
             ctx.set_option(be.TUNE_SPMV_WG_PER_XCD, cap)         # length-sorted C3D10 windows get): a relabelling of
             ctx.set_option(be.TUNE_SPMV_ROT, rot)                # which workgroup multiplies which slice
             ctx.spmv(be.VEC_TMP0, be.VEC_TMP1)

@@ -33,7 +33,7 @@ if "quick" in sys.argv:
     ctx.close()
     sys.exit(0)
 if "ab" in sys.argv:                     # workgroups per XCD x round rotation, interleaved in ONE process (round 6)
-    cfgs = [(256, 0), (512, 0), (256, 19), (512, 19), (0, -1)]     # (256, 0) = rounds 1-5, (0, -1) = the defaults
+    cfgs = [(256, 0), (512, 0), (256, 19), (512, 19), (256, 64), (512, 64), (0, -1)]     # (256, 0) = rounds 1-5, (0, -1) = the defaults
     if os.environ.get("FEMCY_AB_CFGS"):                           # e.g. "0:-1,256:0"
         cfgs = [tuple(int(v) for v in c.split(":")) for c in os.environ["FEMCY_AB_CFGS"].split(",")]
     for rep in range(3):
